@@ -1,0 +1,19 @@
+"""CPU oracle for the pixel-space hot path (TEST INFRASTRUCTURE ONLY).
+
+This package restates, with stock torch-CPU / numpy operations, the arithmetic of the
+reference's universal adversarial-image optimisation loop
+(`src/attack_model.py:276-472`, `src/crossattack_models.py:301-517`) and of its four
+differentiable image processors (`src/processors/*.py`).  It exists to CHECK the HIP
+path; nothing under `adversarialvlm_amd/` may import it.  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg use it.
+
+Pinning status (see DESIGN.md "Oracle"):
+  * LLaVA / Qwen2-VL / Phi-3.5 processors: pinned by captures from the imported
+    reference classes (tests/golden/*.npz, generator tests/golden/make_golden.py).
+  * Llama-3.2 (mllama) processor: reference module is not importable here; restated
+    from llama32processor.py:255-405, integer geometry pinned by the installed
+    transformers `image_processing_pil_mllama` helpers, arithmetic by F.interpolate/F.pad.
+  * GaussianBlur / RandomResizedCrop: torchvision is absent -> restated from the
+    published algorithm, "torchvision-unverified" (parity unpinned for these two ops).
+  * The reference has no tests or golden vectors of its own.
+"""

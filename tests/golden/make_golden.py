@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ (run in the BUILD container only).
+
+The reference ships no tests or golden vectors, so the oracle is
+pinned against outputs of the reference's own classes, captured here by importing them
+from /root/reference/src, and against the stock torch calls the reference trainer
+makes.  Only DATA (inputs + expected outputs) is written; no reference source text is
+stored.  The reference tree does not exist on the GPU box - nothing at test time reads it.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Importability notes: llavaprocessor imports directly; qwen2VLprocessor /
+phi3processor have unused torchvision imports, so a bare stub module is registered after
+transformers' symbols are resolved; llama32processor cannot be imported with
+transformers 5.15 (no fixture from it - see mllama_restated.npz, which is produced by
+the oracle's restatement and pinned only by the transformers canvas helpers).
+"""
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/src"
+
+CLIP_MEAN = [0.48145466, 0.4578275, 0.40821073]
+CLIP_STD = [0.26862954, 0.26130258, 0.27577711]
+
+
+def lcg_tensor(shape, salt):
+    """Deterministic pseudo-random float32 in [-0.5, 0.5): exact integer arithmetic, so
+    the tests can rebuild large upstream gradients instead of storing them."""
+    n = int(np.prod(shape))
+    i = np.arange(n, dtype=np.uint64)
+    v = (i * np.uint64(2654435761) + np.uint64(salt) * np.uint64(40503)) % np.uint64(2 ** 32)
+    v = (v * np.uint64(1664525) + np.uint64(1013904223)) % np.uint64(2 ** 32)
+    return torch.from_numpy((v.astype(np.float64) / 2 ** 32 - 0.5).astype(np.float32).reshape(shape))
+
+
+def meta():
+    import transformers
+    return dict(torch_version=torch.__version__, transformers_version=transformers.__version__,
+                numpy_version=np.__version__)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    for k, v in meta().items():
+        out["meta_" + k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name, {k: out[k].shape for k in out if not k.startswith("meta_")})
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    import processors.llavaprocessor as llava
+    # resolve what the other two modules import from transformers BEFORE the stub exists
+    from transformers import AutoProcessor, Qwen2VLForConditionalGeneration, AutoModelForCausalLM  # noqa: F401
+    from transformers.image_processing_utils import BatchFeature  # noqa: F401
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvf = types.ModuleType("torchvision.transforms.functional")
+    tv.transforms, tvt.functional = tvt, tvf
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt,
+                        "torchvision.transforms.functional": tvf})
+    import processors.qwen2VLprocessor as qwen
+    import processors.phi3processor as phi3
+    return llava, qwen, phi3
+
+
+def golden_llava(llava):
+    cases = [("down", (3, 37, 91), (24, 32)), ("mixed", (3, 64, 40), (56, 56)),
+             ("ident", (3, 48, 48), (48, 48)), ("up", (3, 20, 30), (50, 44))]
+    arrays = {}
+    for k, (name, ishape, (ch, cw)) in enumerate(cases):
+        op = SimpleNamespace(image_mean=CLIP_MEAN, image_std=CLIP_STD, do_convert_rgb=True,
+                             crop_size={"height": ch, "width": cw})
+        proc = llava.DifferentiableLlavaImageProcessor(op, "cpu")
+        torch.manual_seed(100 + k)
+        img = torch.rand(ishape, requires_grad=True)
+        pv = proc.process(img)["pixel_values"]
+        up = lcg_tensor(pv.shape, 7 + k)
+        pv.backward(up)
+        arrays.update({f"{name}_image": img, f"{name}_crop": np.array([ch, cw]),
+                       f"{name}_pixel_values": pv, f"{name}_image_grad": img.grad,
+                       f"{name}_salt": np.array(7 + k)})
+    # full-size capture 512 -> 336 : checksums + sampled entries only
+    op = SimpleNamespace(image_mean=CLIP_MEAN, image_std=CLIP_STD, do_convert_rgb=True,
+                         crop_size={"height": 336, "width": 336})
+    proc = llava.DifferentiableLlavaImageProcessor(op, "cpu")
+    img = lcg_tensor((3, 512, 512), 99) + 0.5
+    img.requires_grad_(True)
+    pv = proc.process(img)["pixel_values"]
+    up = lcg_tensor(pv.shape, 98)
+    pv.backward(up)
+    idx = np.arange(0, pv.numel(), 997)
+    gidx = np.arange(0, img.numel(), 1499)
+    arrays.update(full_salt_image=np.array(99), full_salt_up=np.array(98),
+                  full_pv_sum=pv.detach().double().sum(), full_pv_sumsq=(pv.detach().double() ** 2).sum(),
+                  full_pv_idx=idx, full_pv_val=pv.detach().flatten()[idx],
+                  full_grad_sum=img.grad.double().sum(), full_grad_idx=gidx,
+                  full_grad_val=img.grad.flatten()[gidx])
+    save("llava_reference.npz", **arrays)
+
+
+def golden_qwen(qwen):
+    arrays = {}
+    cases = [("a", (3, 60, 90), 28 * 28 * 4, 28 * 28 * 64), ("b", (3, 50, 50), 56 * 56, 28 * 28 * 6),
+             ("c", (3, 20, 33), 56 * 56, 28 * 28 * 1280)]
+    for k, (name, ishape, minp, maxp) in enumerate(cases):
+        op = SimpleNamespace(image_mean=CLIP_MEAN, image_std=CLIP_STD, do_convert_rgb=True,
+                             patch_size=14, merge_size=2, temporal_patch_size=2,
+                             min_pixels=minp, max_pixels=maxp)
+        proc = qwen.DifferentiableQwen2VLImageProcessor(op, "cpu")
+        torch.manual_seed(200 + k)
+        img = torch.rand(ishape, requires_grad=True)
+        out = proc.process(img)
+        pv = out["pixel_values"]
+        up = lcg_tensor(pv.shape, 17 + k)
+        pv.backward(up)
+        arrays.update({f"{name}_image": img, f"{name}_minmax": np.array([minp, maxp]),
+                       f"{name}_pixel_values": pv, f"{name}_num_tiles": np.array(out["num_tiles"]),
+                       f"{name}_image_grad": img.grad, f"{name}_salt": np.array(17 + k),
+                       f"{name}_optimal_size": np.array(proc._optimal_size(img))})
+    # integer geometry sweep
+    op = SimpleNamespace(image_mean=CLIP_MEAN, image_std=CLIP_STD, do_convert_rgb=True, patch_size=14,
+                         merge_size=2, temporal_patch_size=2, min_pixels=56 * 56, max_pixels=28 * 28 * 1280)
+    proc = qwen.DifferentiableQwen2VLImageProcessor(op, "cpu")
+    sizes = [(336, 336), (512, 512), (1352, 1988), (30, 40), (14, 14), (2000, 3000), (377, 1201),
+             (42, 42), (70, 70), (1001, 999)]
+    geo = [list(s) + list(proc._optimal_size(torch.empty(3, *s))) for s in sizes]
+    arrays["geometry"] = np.array(geo, dtype=np.int64)
+    save("qwen2vl_reference.npz", **arrays)
+
+
+def golden_phi3(phi3):
+    arrays = {}
+    cases = [("wide", (3, 100, 150)), ("tall", (3, 150, 100)), ("square", (3, 120, 120))]
+    for k, (name, ishape) in enumerate(cases):
+        op = SimpleNamespace(image_mean=CLIP_MEAN, image_std=CLIP_STD, do_convert_rgb=True,
+                             num_crops=6, num_img_tokens=144)
+        proc = phi3.DifferentiablePhi3VImageProcessor(op, "cpu")
+        torch.manual_seed(300 + k)
+        img = torch.rand(ishape, requires_grad=True)
+        out = proc.process(img)
+        pv = out["pixel_values"]
+        up = lcg_tensor(pv.shape, 27 + k)
+        pv.backward(up)
+        flat = pv.detach().reshape(7, -1).double()
+        idx = np.arange(0, pv.numel(), 1009)
+        arrays.update({f"{name}_image": img, f"{name}_image_sizes": np.array(out["image_sizes"]),
+                       f"{name}_num_img_tokens": np.array(out["num_img_tokens"]),
+                       f"{name}_tile_sum": flat.sum(1), f"{name}_tile_sumsq": (flat ** 2).sum(1),
+                       f"{name}_pv_idx": idx, f"{name}_pv_val": pv.detach().flatten()[idx],
+                       f"{name}_image_grad": img.grad, f"{name}_salt": np.array(27 + k)})
+    sizes = [(336, 336), (512, 512), (1352, 1988), (1988, 1352), (100, 900), (900, 100), (300, 301)]
+    geo = []
+    proc = phi3.DifferentiablePhi3VImageProcessor(
+        SimpleNamespace(image_mean=CLIP_MEAN, image_std=CLIP_STD, do_convert_rgb=True, num_crops=6,
+                        num_img_tokens=144), "cpu")
+    for s in sizes:
+        out = proc.process(torch.full((3, *s), 0.5))
+        geo.append(list(s) + list(out["image_sizes"][0]) + list(out["num_img_tokens"]))
+    arrays["geometry"] = np.array(geo, dtype=np.int64)
+    save("phi3_reference.npz", **arrays)
+
+
+def golden_mllama_helpers():
+    """Integer geometry from the installed transformers helpers the reference calls
+    (llama32processor.py:262-277).  Data only."""
+    import importlib
+    m = importlib.import_module("transformers.models.mllama.image_processing_pil_mllama")
+    sizes = [(336, 336), (512, 512), (1352, 1988), (1988, 1352), (100, 900), (900, 100), (560, 560),
+             (561, 560), (1120, 1120), (2000, 500), (300, 2400), (10, 10), (1121, 1119), (700, 700)]
+    rows = []
+    for (h, w) in sizes:
+        for (mt, ts) in [(4, 560), (4, 448), (6, 224)]:
+            ch, cw = m.get_optimal_tiled_canvas(h, w, mt, ts)
+            nh, nw = m.get_image_size_fit_to_canvas(h, w, ch, cw, ts)
+            rows.append([h, w, mt, ts, int(ch), int(cw), int(nh), int(nw)])
+    ids = m.convert_aspect_ratios_to_ids_np([[(1, 1)], [(2, 2)], [(1, 4)], [(4, 1)], [(2, 1)]], 4)
+    save("mllama_helpers.npz", geometry=np.array(rows, dtype=np.int64), aspect_ids=ids,
+         arrangements4=np.array(m.get_all_supported_aspect_ratios(4), dtype=np.int64))
+
+
+def golden_closed_form():
+    """Fixtures from the stock torch calls the trainer makes (attack_model.py:94-104, 184,
+    216, 300, 340, 343-346, 366-373)."""
+    torch.manual_seed(7)
+    arrays = {}
+    # tanh + image_fit_loss value/grad, expression restated from attack_model.py:94-104
+    p = (torch.randn(3, 9, 11) * 2).requires_grad_(True)
+    x0 = torch.rand(3, 9, 11) * 1.4 - 0.2
+    eps = 0.5
+    x = eps * torch.tanh(p)
+    s = x0 + x
+    loss = torch.mean(torch.relu(0.9 * torch.zeros_like(s) - s) ** 2 + torch.relu(s - 0.9 * torch.ones_like(s)) ** 2)
+    loss.backward()
+    arrays.update(fit_p=p, fit_x0=x0, fit_eps=np.array(eps), fit_x=x, fit_loss=loss, fit_p_grad=p.grad)
+    # AdamW + StepLR trajectory
+    q = torch.zeros(3, 5, 7, requires_grad=True)
+    opt = torch.optim.AdamW([q], lr=1e-2)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=2, gamma=0.5)
+    gs, ps, ms, vs, lrs = [], [], [], [], []
+    for t in range(6):
+        g = torch.randn(3, 5, 7) * (10.0 ** (t - 3))
+        q.grad = g.clone()
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sched.step()
+        st = opt.state[q]
+        gs.append(g); ps.append(q.detach().clone()); ms.append(st["exp_avg"].clone()); vs.append(st["exp_avg_sq"].clone())
+    arrays.update(adamw_g=torch.stack(gs), adamw_p=torch.stack(ps), adamw_m=torch.stack(ms),
+                  adamw_v=torch.stack(vs), adamw_lr=np.array(lrs), adamw_lr0=np.array(1e-2),
+                  adamw_step_size=np.array(2), adamw_gamma=np.array(0.5))
+    # quantiser (tensor2pil -> PNG -> pil_to_tensor == uint8 truncation), incl. lattice points
+    lattice = torch.arange(256, dtype=torch.float32) / 255
+    sv = torch.cat([lattice, torch.rand(3 * 16 * 16 - 256) * 1.3 - 0.15]).reshape(3, 16, 16)
+    qv = torch.tensor((sv.clamp(0, 1) * 255).numpy().astype(np.uint8).astype(np.float32) / 255)
+    d = (qv - sv).abs()
+    arrays.update(q_s=sv, q_q=qv, q_std=d.std(), q_mean=d.mean(), q_l1=d.sum())
+    # grad norm
+    gg = torch.randn(3, 8, 8)
+    arrays.update(norm_g=gg, norm_val=gg.norm())
+    save("closed_form.npz", **arrays)
+
+
+def golden_mllama_restated():
+    """NOT a reference capture: produced by the oracle's restatement of
+    llama32processor.py:360-405 (module not importable here)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle.processors import MllamaOracle
+    arrays = {}
+    for k, (name, ishape, tile) in enumerate([("a", (3, 40, 70), 32), ("b", (3, 90, 50), 32), ("c", (3, 30, 30), 32)]):
+        proc = MllamaOracle(tile=tile, max_tiles=4)
+        torch.manual_seed(400 + k)
+        img = torch.rand(ishape, requires_grad=True)
+        out = proc.process(img)
+        pv = out["pixel_values"]
+        up = lcg_tensor(pv.shape, 37 + k)
+        pv.backward(up)
+        arrays.update({f"{name}_image": img, f"{name}_tile": np.array(tile), f"{name}_pixel_values": pv,
+                       f"{name}_num_tiles": np.array(out["num_tiles"]), f"{name}_image_grad": img.grad,
+                       f"{name}_salt": np.array(37 + k)})
+    save("mllama_restated.npz", **arrays)
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference tree not present: fixtures can only be regenerated in the build container")
+    llava, qwen, phi3 = import_reference()
+    golden_llava(llava)
+    golden_qwen(qwen)
+    golden_phi3(phi3)
+    golden_mllama_helpers()
+    golden_closed_form()
+    golden_mllama_restated()
+
+
+if __name__ == "__main__":
+    main()

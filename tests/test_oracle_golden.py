@@ -1,0 +1,158 @@
+"""CPU tier: the oracle (restatement) against fixtures captured from the imported
+reference classes and from the stock torch calls the reference trainer makes."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, lcg_tensor, rel_err
+from oracle import geometry as G
+from oracle import pixel_ops as P
+from oracle.processors import LlavaOracle, MllamaOracle, Phi3Oracle, Qwen2VLOracle
+
+TOL = 1e-6  # oracle and reference call the same torch ops: expect bit-equality or last-ulp
+
+
+@pytest.mark.parametrize("name", ["down", "mixed", "ident", "up"])
+def test_llava_reference_capture(name):
+    g = load_golden("llava_reference.npz")
+    ch, cw = g[f"{name}_crop"]
+    img = torch.tensor(g[f"{name}_image"], requires_grad=True)
+    pv = LlavaOracle(int(ch), int(cw)).process(img)["pixel_values"]
+    assert pv.shape == g[f"{name}_pixel_values"].shape
+    assert rel_err(pv.detach(), g[f"{name}_pixel_values"]) <= TOL
+    pv.backward(lcg_tensor(pv.shape, int(g[f"{name}_salt"])))
+    assert rel_err(img.grad, g[f"{name}_image_grad"]) <= TOL
+
+
+def test_llava_full_size_checksums():
+    g = load_golden("llava_reference.npz")
+    img = (lcg_tensor((3, 512, 512), int(g["full_salt_image"])) + 0.5).requires_grad_(True)
+    pv = LlavaOracle().process(img)["pixel_values"]
+    pv.backward(lcg_tensor(pv.shape, int(g["full_salt_up"])))
+    assert abs(float(pv.detach().double().sum()) - float(g["full_pv_sum"])) <= 1e-6 * abs(float(g["full_pv_sum"]))
+    assert rel_err(pv.detach().flatten()[g["full_pv_idx"]], g["full_pv_val"]) <= TOL
+    assert rel_err(img.grad.flatten()[g["full_grad_idx"]], g["full_grad_val"]) <= TOL
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_qwen_reference_capture(name):
+    g = load_golden("qwen2vl_reference.npz")
+    minp, maxp = (int(v) for v in g[f"{name}_minmax"])
+    img = torch.tensor(g[f"{name}_image"], requires_grad=True)
+    out = Qwen2VLOracle(min_pixels=minp, max_pixels=maxp).process(img)
+    pv = out["pixel_values"]
+    assert list(out["num_tiles"]) == list(g[f"{name}_num_tiles"])
+    assert pv.shape == g[f"{name}_pixel_values"].shape
+    assert rel_err(pv.detach(), g[f"{name}_pixel_values"]) <= TOL
+    pv.backward(lcg_tensor(pv.shape, int(g[f"{name}_salt"])))
+    assert rel_err(img.grad, g[f"{name}_image_grad"]) <= TOL
+
+
+def test_qwen_geometry_bit_exact():
+    g = load_golden("qwen2vl_reference.npz")
+    for h, w, hb, wb in g["geometry"]:
+        assert G.qwen_smart_resize(int(h), int(w)) == (int(hb), int(wb))
+
+
+def test_qwen_patch_index_matches_permute():
+    # index formula of SURVEY 8(a9) against the 9-D permute, integer-exact
+    proc = Qwen2VLOracle()
+    h, w = 56, 84
+    canvas = torch.arange(3 * h * w, dtype=torch.float32).reshape(3, h, w)
+    vid = canvas.unsqueeze(0).repeat(2, 1, 1, 1)
+    gh, gw = h // 14, w // 14
+    p = vid.reshape(1, 2, 3, gh // 2, 2, 14, gw // 2, 2, 14).permute(0, 3, 6, 4, 7, 2, 1, 5, 8)
+    flat = p.reshape(gh * gw, -1)
+    rng = np.random.default_rng(0)
+    for _ in range(500):
+        c, t, y, x = rng.integers(3), rng.integers(2), rng.integers(h), rng.integers(w)
+        r, col = G.qwen_patch_index(int(c), int(t), int(y), int(x), gw)
+        assert flat[r, col].item() == canvas[c, y, x].item()
+
+
+@pytest.mark.parametrize("name", ["wide", "tall", "square"])
+def test_phi3_reference_capture(name):
+    g = load_golden("phi3_reference.npz")
+    img = torch.tensor(g[f"{name}_image"], requires_grad=True)
+    out = Phi3Oracle().process(img)
+    pv = out["pixel_values"]
+    assert out["image_sizes"] == g[f"{name}_image_sizes"].tolist()
+    assert out["num_img_tokens"] == g[f"{name}_num_img_tokens"].tolist()
+    flat = pv.detach().reshape(7, -1).double()
+    np.testing.assert_allclose(flat.sum(1).numpy(), g[f"{name}_tile_sum"], rtol=1e-7, atol=1e-6)
+    np.testing.assert_allclose((flat ** 2).sum(1).numpy(), g[f"{name}_tile_sumsq"], rtol=1e-7, atol=1e-6)
+    assert rel_err(pv.detach().flatten()[g[f"{name}_pv_idx"]], g[f"{name}_pv_val"]) <= TOL
+    pv.backward(lcg_tensor(pv.shape, int(g[f"{name}_salt"])))
+    assert rel_err(img.grad, g[f"{name}_image_grad"]) <= TOL
+
+
+def test_phi3_geometry_bit_exact():
+    g = load_golden("phi3_reference.npz")
+    for h, w, oh, ow, ntok in g["geometry"]:
+        geo = G.phi3_hd_geometry(int(h), int(w), 6)
+        assert (geo["out_h"], geo["out_w"]) == (int(oh), int(ow))
+        assert G.phi3_num_img_tokens(geo["out_h"], geo["out_w"]) == int(ntok)
+
+
+def test_mllama_geometry_against_transformers_helpers():
+    g = load_golden("mllama_helpers.npz")
+    for h, w, mt, ts, ch, cw, nh, nw in g["geometry"]:
+        assert G.mllama_optimal_canvas(int(h), int(w), int(mt), int(ts)) == (int(ch), int(cw))
+        assert G.mllama_fit_to_canvas(int(h), int(w), int(ch), int(cw), int(ts)) == (int(nh), int(nw))
+    assert G.mllama_supported_arrangements(4) == [tuple(r) for r in g["arrangements4"].tolist()]
+    ids = [G.mllama_aspect_ratio_id(a, b) for (a, b) in [(1, 1), (2, 2), (1, 4), (4, 1), (2, 1)]]
+    assert ids == g["aspect_ids"].flatten().tolist()
+
+
+def test_mllama_tiles_reassemble_to_padded_image():
+    # invariant of llama32processor.py:317-334 / :20-52 : tiles glue back to the padded,
+    # normalised canvas; unused tiles are exact zeros, padding is -mean/std (Q12)
+    proc = MllamaOracle(tile=32, max_tiles=4)
+    img = torch.rand(3, 40, 70)
+    out = proc.process(img)
+    nh, nw, th, tw = G.mllama_geometry(40, 70, 4, 32)
+    pv = out["pixel_values"][0, 0]
+    assert out["num_tiles"] == th * tw
+    assert torch.count_nonzero(pv[th * tw:]) == 0
+    glued = pv[:th * tw].reshape(th, tw, 3, 32, 32).permute(2, 0, 3, 1, 4).reshape(3, th * 32, tw * 32)
+    mean = torch.tensor(proc.mean).view(3, 1, 1)
+    std = torch.tensor(proc.std).view(3, 1, 1)
+    pad_region = glued[:, nh:, :]
+    assert torch.allclose(pad_region, ((0 - mean) / std).expand_as(pad_region))
+
+
+def test_closed_form_fixtures():
+    g = load_golden("closed_form.npz")
+    p = torch.tensor(g["fit_p"], requires_grad=True)
+    x0 = torch.tensor(g["fit_x0"])
+    x = P.tanh_reparam(p, float(g["fit_eps"]))
+    loss = P.image_fit_loss(x0, x)
+    loss.backward()
+    assert rel_err(x.detach(), g["fit_x"]) <= TOL
+    assert abs(float(loss.detach()) - float(g["fit_loss"])) <= 1e-6 * float(g["fit_loss"])
+    assert rel_err(p.grad, g["fit_p_grad"]) <= TOL
+    s = torch.tensor(g["q_s"])
+    assert torch.equal(P.quantise(s), torch.tensor(g["q_q"]))        # bit-exact lattice
+    std, mean, l1 = P.quantise_error_stats(s)
+    assert float(std) == pytest.approx(float(g["q_std"]), rel=1e-6)
+    assert float(mean) == pytest.approx(float(g["q_mean"]), rel=1e-6)
+    assert float(l1) == pytest.approx(float(g["q_l1"]), rel=1e-6)
+
+
+def test_blur_separable_equals_product_kernel():
+    # torchvision-unverified restatement; internal consistency only
+    x = torch.rand(3, 20, 24)
+    g = P.gaussian_kernel1d(5, 7.0)
+    assert g.numpy().round(5).tolist() == pytest.approx([0.19593, 0.20202, 0.20409, 0.20202, 0.19593], abs=1e-5)
+    y = P.gaussian_blur(x, 5, 7.0)
+    xp = torch.nn.functional.pad(x[None], [2, 2, 2, 2], mode="reflect")
+    yh = torch.nn.functional.conv2d(xp, g.view(1, 1, 1, 5).expand(3, 1, 1, 5), groups=3)
+    yv = torch.nn.functional.conv2d(yh, g.view(1, 1, 5, 1).expand(3, 1, 5, 1), groups=3)[0]
+    assert rel_err(yv, y) < 1e-6
+
+
+def test_random_resized_crop_params_in_bounds():
+    gen = torch.Generator().manual_seed(0)
+    for _ in range(50):
+        i, j, h, w = P.random_resized_crop_params(336, 336, (0.6, 1.0), (0.75, 1.33), gen)
+        assert 0 <= i and i + h <= 336 and 0 <= j and j + w <= 336 and h > 0 and w > 0
