@@ -1,0 +1,128 @@
+"""ctypes binding of libadvx_hip.so (include/advx.h).
+
+There is NO CPU fallback: if the HIP library is missing or an entry point fails, this
+module raises.  `tests/` use the torch-CPU oracle to CHECK results; the product path never
+routes through it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadvx_hip.so")
+
+ADVX_OK = 0
+KIND_LLAVA, KIND_MLLAMA, KIND_PHI3, KIND_QWEN2VL = 0, 1, 2, 3
+MODE_AA_BILINEAR, MODE_BILINEAR, MODE_BICUBIC = 0, 1, 2
+OPT_ADAMW, OPT_SIGN = 0, 1
+STAT_SIGMA, STAT_QERR_STD, STAT_QERR_MEAN, STAT_QERR_L1, STAT_IMGFIT, STAT_X_MEAN, STAT_X_STD, STAT_GRAD_NORM = range(8)
+STATS_N = 16
+MAX_STAGES = 2
+
+
+class AdvxError(RuntimeError):
+    pass
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
+                ("a0", C.c_int64), ("a1", C.c_int64), ("a2", C.c_int64), ("a3", C.c_int64), ("a4", C.c_int64),
+                ("mean", C.c_float * 3), ("std", C.c_float * 3)]
+
+
+class StageInfo(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("src", C.c_int32), ("src_h", C.c_int32), ("src_w", C.c_int32),
+                ("res_h", C.c_int32), ("res_w", C.c_int32), ("can_h", C.c_int32), ("can_w", C.c_int32),
+                ("off_y", C.c_int32), ("off_x", C.c_int32), ("pad_value", C.c_float),
+                ("normalise", C.c_int32), ("inner_axis_h", C.c_int32)]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32), ("out_rank", C.c_int32),
+                ("out_shape", C.c_int64 * 6), ("out_numel", C.c_int64), ("n_stage", C.c_int32),
+                ("stage", StageInfo * MAX_STAGES), ("tiles_h", C.c_int32), ("tiles_w", C.c_int32),
+                ("num_tiles", C.c_int32), ("grid_h", C.c_int32), ("grid_w", C.c_int32),
+                ("image_h", C.c_int32), ("image_w", C.c_int32), ("num_img_tokens", C.c_int32),
+                ("aspect_ratio_id", C.c_int32), ("workspace_floats", C.c_int64)]
+
+
+class OptScalars(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("apply", C.c_int32), ("lr", C.c_float), ("decay", C.c_float),
+                ("w1", C.c_float), ("beta2", C.c_float), ("w2", C.c_float), ("bias2_sqrt", C.c_float),
+                ("eps", C.c_float), ("neg_step_size", C.c_float)]
+
+
+_P = C.c_void_p
+_I32, _I64, _U64, _F = C.c_int32, C.c_int64, C.c_uint64, C.c_float
+_PI32 = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); every symbol include/advx.h declares
+SIGNATURES = {
+    "advx_version": (_I32, []),
+    "advx_last_error": (C.c_char_p, []),
+    "advx_plan_create": (_I32, [C.POINTER(PlanDesc), C.POINTER(_P)]),
+    "advx_plan_destroy": (_I32, [_P]),
+    "advx_plan_describe": (_I32, [_P, C.POINTER(PlanInfo)]),
+    "advx_plan_upload": (_I32, [_P, _P]),
+    "advx_plan_taps": (_I32, [_P, _I32, _I32, _I32, _PI32, _PI32, _P, _P, _P]),
+    "advx_plan_out_index": (_I32, [_P, _I32, _I32, _I32, _I32, _PI32, C.POINTER(C.c_int64)]),
+    "advx_taps_compute": (_I32, [_I32, _I32, _I32, _I32, _PI32, _PI32, _P, _P, _P]),
+    "advx_emit": (_I32, [_P, _P, _I32, _P, _P, _I32, _U64, _U64, _P, _P, _I64, _P]),
+    "advx_collect": (_I32, [_P, _P, _I32, _P, _I32, _P, _I64, _P]),
+    "advx_image_scratch_floats": (_I64, [_I32, _I32, _I32]),
+    "advx_image_fwd": (_I32, [_P, _P, _I32, _I32, _F, _I32, _F, _P, _P, _P, _P, _P, _P]),
+    "advx_image_bwd": (_I32, [_P, _P, _P, _I32, _I32, _F, _I32, _F, _P, _F, _P, _I32, _P, _P]),
+    "advx_update": (_I32, [_P, _P, _P, _P, _P, _I64, C.POINTER(OptScalars), _P, _P, _P]),
+    "advx_update_scratch_floats": (_I64, [_I64]),
+    "advx_fused_supported": (_I32, [_P]),
+    "advx_fused_fwd": (_I32, [_P, _P, _P, _F, _I32, _P, _I32, _U64, _U64, _P, _P, _P, _P, _P]),
+    "advx_fused_bwd": (_I32, [_P, _P, _I32, _P, _P, _F, _F, _P, _P, _P, _P, C.POINTER(OptScalars), _P, _P, _P]),
+    "advx_fused_scratch_floats": (_I64, [_P]),
+    "advx_tanh_fwd": (_I32, [_P, _F, _P, _I64, _P]),
+    "advx_tanh_bwd": (_I32, [_P, _P, _F, _P, _I64, _P]),
+    "advx_blur_fwd": (_I32, [_P, _I32, _I32, _I32, _F, _P, _P]),
+    "advx_blur_bwd": (_I32, [_P, _I32, _I32, _I32, _F, _P, _P, _P]),
+    "advx_crop_resize_fwd": (_I32, [_P, _I32, _I32, _P, _P, _P, _P]),
+    "advx_crop_resize_bwd": (_I32, [_P, _I32, _I32, _P, _P, _P, _P]),
+    "advx_crop_scratch_floats": (_I64, [_I32, _I32]),
+    "advx_batch_reduce": (_I32, [_P, _I32, _I64, _P, _P]),
+    "advx_philox_normal": (_I32, [_P, _I64, _U64, _U64, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libadvx_hip.so; raises AdvxError (never falls back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AdvxError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != ADVX_OK:
+        msg = load().advx_last_error()
+        raise AdvxError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device (or host) pointer of a contiguous torch tensor / None."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise AdvxError("advx: tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

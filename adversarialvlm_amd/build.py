@@ -1,0 +1,35 @@
+"""Build libadvx_hip.so in-tree with hipcc for gfx950 (no JIT cache, no CPU variant)."""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = [os.path.join(CSRC, "advx.hip")]
+HEADERS = [os.path.join(CSRC, f) for f in ("advx_taps.h", "advx_device.h", "advx_kernels.h")] + [
+    os.path.join(os.path.dirname(_HERE), "include", "advx.h")]
+OUT = os.path.join(_HERE, "libadvx_hip.so")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+
+
+def _stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS)
+
+
+def build_library(force=False, verbose=False):
+    """Compile the HIP library if it is missing or older than its sources."""
+    if not force and not _stale():
+        return OUT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: libadvx_hip.so cannot be built (there is no CPU fallback)")
+    cmd = [hipcc] + FLAGS + ["-o", OUT] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    return OUT

@@ -1,0 +1,916 @@
+// advx.hip - host side of libadvx_hip.so: plans (geometry + tap tables), launch logic and
+// the extern "C" entry points declared in include/advx.h.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/advx.h"
+#include "advx_kernels.h"
+
+using namespace advx;
+
+// ------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int32_t fail(int32_t code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      return fail(ADVX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+  } while (0)
+#define LAUNCH_CHECK()                                                                    \
+  do {                                                                                    \
+    hipError_t _e = hipGetLastError();                                                    \
+    if (_e != hipSuccess) return fail(ADVX_E_HIP, std::string("launch: ") + hipGetErrorString(_e)); \
+  } while (0)
+#define REQUIRE(cond, code, msg) \
+  do {                           \
+    if (!(cond)) return fail(code, msg); \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int grid_for(long long n, int cap = 2048) {
+  long long b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------- host tables
+struct HostTaps {
+  int n = 0, stride = 0;
+  std::vector<int> start, count;
+  std::vector<float> w;
+};
+
+static HostTaps host_taps(int mode, int in_size, int out_size) {
+  HostTaps t;
+  t.n = out_size;
+  t.stride = tap_stride(mode, in_size, out_size);
+  t.start.resize(out_size);
+  t.count.resize(out_size);
+  t.w.assign((size_t)out_size * t.stride, 0.0f);
+  for (int i = 0; i < out_size; ++i) {
+    TapRow r = tap_row(mode, in_size, out_size, i, t.stride, &t.w[(size_t)i * t.stride]);
+    t.start[i] = r.start;
+    t.count[i] = r.count;
+  }
+  return t;
+}
+
+static HostTaps host_taps_transposed(int mode, int in_size, int out_size, const HostTaps& f) {
+  HostTaps t;
+  t.n = in_size;
+  t.start.resize(in_size);
+  t.count.resize(in_size);
+  int mx = 1;
+  for (int j = 0; j < in_size; ++j) {
+    TapRow r = tap_bounds_transposed(mode, in_size, out_size, j);
+    t.start[j] = r.start;
+    t.count[j] = r.count;
+    mx = std::max(mx, r.count);
+  }
+  t.stride = mx;
+  t.w.assign((size_t)in_size * mx, 0.0f);
+  for (int j = 0; j < in_size; ++j)
+    for (int q = 0; q < t.count[j]; ++q) {
+      int i = t.start[j] + q;
+      int slot = j - f.start[i];
+      if (slot >= 0 && slot < f.count[i]) t.w[(size_t)j * mx + q] = f.w[(size_t)i * f.stride + slot];
+    }
+  return t;
+}
+
+// ------------------------------------------------------------------------------- plans
+struct StageHost {
+  advx_stage_info info;
+  HostTaps th, tw, tth, ttw;
+};
+
+struct advx_plan {
+  advx_plan_desc desc;
+  advx_plan_info info;
+  StageHost st[ADVX_MAX_STAGES];
+  DPlan dplan;                 // layout (no device pointers inside)
+  DStage dstage[ADVX_MAX_STAGES];  // filled at upload (device table pointers)
+  bool uploaded = false;
+  int device = -1;
+  void* dev_block = nullptr;
+};
+
+// ---- integer geometry (restated from the reference / transformers helpers; see oracle/geometry.py)
+static void mllama_canvas(int H, int W, int max_tiles, int tile, int* ch, int* cw) {
+  // transformers image_processing_pil_mllama.get_optimal_tiled_canvas (llama32processor.py:262)
+  std::vector<std::pair<int, int>> cands;
+  for (int a = 1; a <= max_tiles; ++a)
+    for (int b = 1; b <= max_tiles; ++b)
+      if (a * b <= max_tiles) cands.push_back({a * tile, b * tile});
+  std::vector<double> scales;
+  for (auto& c : cands) {
+    double sh = (double)c.first / (double)H, sw = (double)c.second / (double)W;
+    scales.push_back(sw > sh ? sh : sw);
+  }
+  bool any_up = false;
+  double sel = 0.0;
+  for (double s : scales)
+    if (s >= 1.0) {
+      if (!any_up || s < sel) sel = s;
+      any_up = true;
+    }
+  if (!any_up) {
+    bool first = true;
+    for (double s : scales)
+      if (s < 1.0) {
+        if (first || s > sel) sel = s;
+        first = false;
+      }
+  }
+  int best = -1;
+  for (size_t k = 0; k < cands.size(); ++k)
+    if (scales[k] == sel) {
+      if (best < 0 || (long long)cands[k].first * cands[k].second < (long long)cands[best].first * cands[best].second)
+        best = (int)k;
+    }
+  *ch = cands[best].first;
+  *cw = cands[best].second;
+}
+
+static void mllama_fit(int H, int W, int ch, int cw, int tile, int* nh, int* nw) {
+  // get_image_size_fit_to_canvas (llama32processor.py:271)
+  int tw = std::min(std::max(W, tile), cw), th = std::min(std::max(H, tile), ch);
+  double sh = (double)th / (double)H, sw = (double)tw / (double)W;
+  if (sw < sh) {
+    *nw = tw;
+    long long f = (long long)std::floor((double)H * sw);
+    if (f == 0) f = 1;
+    *nh = (int)std::min<long long>(f, th);
+  } else {
+    *nh = th;
+    long long f = (long long)std::floor((double)W * sh);
+    if (f == 0) f = 1;
+    *nw = (int)std::min<long long>(f, tw);
+  }
+}
+
+static void qwen_smart_resize(int H, int W, int patch, int merge, long long minp, long long maxp, int* hb, int* wb) {
+  // qwen2VLprocessor.py:176-197; Python round() is round-half-even = nearbyint
+  double factor = (double)(patch * merge);
+  long long h = (long long)std::nearbyint((double)H / factor) * (long long)factor;
+  long long w = (long long)std::nearbyint((double)W / factor) * (long long)factor;
+  if (h * w > maxp) {
+    double beta = std::sqrt(((double)H * (double)W) / (double)maxp);
+    h = (long long)std::floor((double)H / beta / factor) * (long long)factor;
+    w = (long long)std::floor((double)W / beta / factor) * (long long)factor;
+  } else if (h * w < minp) {
+    double beta = std::sqrt((double)minp / ((double)H * (double)W));
+    h = (long long)std::ceil((double)H * beta / factor) * (long long)factor;
+    w = (long long)std::ceil((double)W * beta / factor) * (long long)factor;
+  }
+  *hb = (int)h;
+  *wb = (int)w;
+}
+
+struct Phi3Geo {
+  bool trans;
+  int new_h, new_w, pad_top, pad_bottom, out_h, out_w;
+};
+static Phi3Geo phi3_geo(int H, int W, int hd_num) {
+  // phi3processor.py:173-216
+  Phi3Geo g;
+  int height = H, width = W;
+  g.trans = false;
+  if (width < height) {
+    g.trans = true;
+    std::swap(height, width);
+  }
+  double ratio = (double)width / (double)height;
+  int scale = 1;
+  while ((double)scale * std::ceil((double)scale / ratio) <= (double)hd_num) scale += 1;
+  scale -= 1;
+  g.new_w = (int)((double)scale * 336.0);
+  g.new_h = (int)((double)g.new_w / ratio);
+  int target_h = (int)(std::ceil((double)g.new_h / 336.0) * 336.0);
+  g.pad_top = (target_h - g.new_h) / 2;
+  g.pad_bottom = target_h - g.new_h - g.pad_top;
+  if (g.trans) {
+    g.out_h = g.new_w;
+    g.out_w = target_h;
+  } else {
+    g.out_h = target_h;
+    g.out_w = g.new_w;
+  }
+  return g;
+}
+
+static void fill_stage(StageHost& s, int mode, int src, int src_h, int src_w, int res_h, int res_w, int can_h,
+                       int can_w, int off_y, int off_x, float pad, int normalise, int inner_h) {
+  advx_stage_info& i = s.info;
+  i.mode = mode; i.src = src; i.src_h = src_h; i.src_w = src_w; i.res_h = res_h; i.res_w = res_w;
+  i.can_h = can_h; i.can_w = can_w; i.off_y = off_y; i.off_x = off_x; i.pad_value = pad;
+  i.normalise = normalise; i.inner_axis_h = inner_h;
+  s.th = host_taps(mode, src_h, res_h);
+  s.tw = host_taps(mode, src_w, res_w);
+  s.tth = host_taps_transposed(mode, src_h, res_h, s.th);
+  s.ttw = host_taps_transposed(mode, src_w, res_w, s.tw);
+}
+
+extern "C" int32_t advx_version(void) { return ADVX_VERSION; }
+extern "C" const char* advx_last_error(void) { return g_err.c_str(); }
+
+extern "C" int32_t advx_plan_create(const advx_plan_desc* d, advx_plan** out) {
+  REQUIRE(d && out, ADVX_E_BADARG, "advx_plan_create: null argument");
+  REQUIRE(d->in_h > 0 && d->in_w > 0 && d->in_h <= 16384 && d->in_w <= 16384, ADVX_E_SHAPE,
+          "advx_plan_create: image size out of range");
+  for (int c = 0; c < 3; ++c) REQUIRE(d->std[c] != 0.0f, ADVX_E_BADARG, "advx_plan_create: zero std");
+  advx_plan* p = new advx_plan();
+  p->desc = *d;
+  advx_plan_info& I = p->info;
+  std::memset(&I, 0, sizeof(I));
+  std::memset(&p->dplan, 0, sizeof(p->dplan));
+  I.kind = d->kind; I.in_h = d->in_h; I.in_w = d->in_w;
+  DPlan& L = p->dplan;
+  const int H = d->in_h, W = d->in_w;
+  if (d->kind == ADVX_KIND_LLAVA) {
+    int ch = (int)d->a0, cw = (int)d->a1;
+    if (!(ch > 0 && cw > 0 && ch <= 8192 && cw <= 8192)) { delete p; return fail(ADVX_E_SHAPE, "llava: bad crop size"); }
+    fill_stage(p->st[0], ADVX_MODE_AA_BILINEAR, 0, H, W, ch, cw, ch, cw, 0, 0, 0.0f, 1, 0);
+    I.n_stage = 1;
+    I.out_rank = 4;
+    I.out_shape[0] = 1; I.out_shape[1] = 3; I.out_shape[2] = ch; I.out_shape[3] = cw;
+    L.n_emit = 1;
+    L.e[0].kind = ADVX_EMIT_PLAIN; L.e[0].stage = 0; L.e[0].out_begin = 0; L.e[0].out_count = 3LL * ch * cw;
+    L.e[0].can_h = ch; L.e[0].can_w = cw;
+  } else if (d->kind == ADVX_KIND_MLLAMA) {
+    int tile = (int)d->a0, max_tiles = (int)d->a1;
+    if (!(tile > 0 && tile <= 4096 && max_tiles > 0 && max_tiles <= 16)) { delete p; return fail(ADVX_E_SHAPE, "mllama: bad tile parameters"); }
+    int ch, cw, nh, nw;
+    mllama_canvas(H, W, max_tiles, tile, &ch, &cw);
+    mllama_fit(H, W, ch, cw, tile, &nh, &nw);
+    int th = ch / tile, tw = cw / tile;
+    fill_stage(p->st[0], ADVX_MODE_AA_BILINEAR, 0, H, W, nh, nw, ch, cw, 0, 0, 0.0f, 1, 0);
+    I.n_stage = 1;
+    I.tiles_h = th; I.tiles_w = tw; I.num_tiles = th * tw;
+    int id = 0, k = 0;
+    for (int a = 1; a <= max_tiles; ++a)
+      for (int b = 1; b <= max_tiles; ++b)
+        if (a * b <= max_tiles) { ++k; if (a == th && b == tw) id = k; }
+    I.aspect_ratio_id = id;
+    I.out_rank = 6;
+    I.out_shape[0] = 1; I.out_shape[1] = 1; I.out_shape[2] = max_tiles; I.out_shape[3] = 3;
+    I.out_shape[4] = tile; I.out_shape[5] = tile;
+    L.n_emit = 1;
+    L.e[0].kind = ADVX_EMIT_TILES; L.e[0].stage = 0; L.e[0].out_begin = 0;
+    L.e[0].out_count = 3LL * ch * cw; L.e[0].can_h = ch; L.e[0].can_w = cw; L.e[0].tile = tile; L.e[0].tiles_w = tw;
+  } else if (d->kind == ADVX_KIND_PHI3) {
+    int num_crops = (int)d->a0;
+    if (!(num_crops > 0 && num_crops <= 64)) { delete p; return fail(ADVX_E_SHAPE, "phi3: bad num_crops"); }
+    Phi3Geo g = phi3_geo(H, W, num_crops);
+    // in the ORIGINAL orientation: when the reference transposes (W < H) the resize runs
+    // H -> new_w and W -> new_h and the padding goes left/right; the inner 1-D pass of ATen's
+    // bilinear then runs along the original H axis.
+    int res_h = g.trans ? g.new_w : g.new_h, res_w = g.trans ? g.new_h : g.new_w;
+    int off_y = g.trans ? 0 : g.pad_top, off_x = g.trans ? g.pad_top : 0;
+    int th = g.out_h / 336, tw = g.out_w / 336;
+    if (g.out_h % 336 != 0 || g.out_w % 336 != 0 || th * tw > num_crops || th * tw < 1) {
+      delete p;
+      return fail(ADVX_E_SHAPE, "phi3: HD geometry not divisible by 336 / exceeds num_crops");  // phi3processor.py:200-201
+    }
+    fill_stage(p->st[0], ADVX_MODE_BILINEAR, 0, H, W, res_h, res_w, g.out_h, g.out_w, off_y, off_x, 1.0f, 1, g.trans ? 1 : 0);
+    fill_stage(p->st[1], ADVX_MODE_BICUBIC, 1, g.out_h, g.out_w, 336, 336, 336, 336, 0, 0, 0.0f, 0, 0);
+    I.n_stage = 2;
+    I.tiles_h = th; I.tiles_w = tw; I.num_tiles = 1 + th * tw;
+    I.image_h = g.out_h; I.image_w = g.out_w;
+    I.num_img_tokens = (th * tw + 1) * 144 + 1 + (th + 1) * 12;  // phi3processor.py:244
+    I.out_rank = 5;
+    I.out_shape[0] = 1; I.out_shape[1] = num_crops + 1; I.out_shape[2] = 3; I.out_shape[3] = 336; I.out_shape[4] = 336;
+    const long long T = 3LL * 336 * 336;
+    L.n_emit = 2;
+    L.e[0].kind = ADVX_EMIT_PLAIN; L.e[0].stage = 1; L.e[0].out_begin = 0; L.e[0].out_count = T;
+    L.e[0].can_h = 336; L.e[0].can_w = 336;
+    L.e[1].kind = ADVX_EMIT_TILES; L.e[1].stage = 0; L.e[1].out_begin = T; L.e[1].out_count = T * th * tw;
+    L.e[1].can_h = g.out_h; L.e[1].can_w = g.out_w; L.e[1].tile = 336; L.e[1].tiles_w = tw;
+  } else if (d->kind == ADVX_KIND_QWEN2VL) {
+    int patch = (int)d->a0, merge = (int)d->a1, temporal = (int)d->a2;
+    if (!(patch > 0 && merge > 0 && temporal > 0 && patch <= 64 && merge <= 8 && temporal <= 8 && d->a3 > 0 && d->a4 >= d->a3)) {
+      delete p;
+      return fail(ADVX_E_SHAPE, "qwen2vl: bad patch parameters");
+    }
+    int hb, wb;
+    qwen_smart_resize(H, W, patch, merge, d->a3, d->a4, &hb, &wb);
+    if (hb <= 0 || wb <= 0 || hb % (patch * merge) || wb % (patch * merge)) { delete p; return fail(ADVX_E_SHAPE, "qwen2vl: degenerate resized grid"); }
+    fill_stage(p->st[0], ADVX_MODE_AA_BILINEAR, 0, H, W, hb, wb, hb, wb, 0, 0, 0.0f, 1, 0);
+    I.n_stage = 1;
+    I.grid_h = hb / patch; I.grid_w = wb / patch; I.num_tiles = I.grid_h * I.grid_w;
+    I.out_rank = 2;
+    I.out_shape[0] = (long long)I.grid_h * I.grid_w;
+    I.out_shape[1] = 3LL * temporal * patch * patch;
+    L.n_emit = 1;
+    L.e[0].kind = ADVX_EMIT_QWEN; L.e[0].stage = 0; L.e[0].out_begin = 0;
+    L.e[0].out_count = I.out_shape[0] * I.out_shape[1]; L.e[0].can_h = hb; L.e[0].can_w = wb;
+    L.e[0].patch = patch; L.e[0].merge = merge; L.e[0].temporal = temporal; L.e[0].grid_w = I.grid_w;
+  } else {
+    delete p;
+    return fail(ADVX_E_UNSUPPORTED, "advx_plan_create: unknown kind");
+  }
+  I.out_numel = 1;
+  for (int k = 0; k < I.out_rank; ++k) I.out_numel *= I.out_shape[k];
+  for (int k = 0; k < I.n_stage; ++k) I.stage[k] = p->st[k].info;
+  // workspace: canvases, gradient buffers of canvases that feed a later stage, gsum
+  long long off = 0;
+  L.n_stage = I.n_stage;
+  L.out_numel = I.out_numel;
+  for (int k = 0; k < 2; ++k) { L.canvas_off[k] = -1; L.dgrad_off[k] = -1; }
+  for (int k = 0; k < I.n_stage; ++k) {
+    L.canvas_off[k] = off;
+    off += (3LL * p->st[k].info.can_h * p->st[k].info.can_w + 63) / 64 * 64;
+  }
+  for (int k = 0; k < I.n_stage; ++k)
+    if (p->st[k].info.src > 0) {
+      int sc = p->st[k].info.src - 1;
+      if (L.dgrad_off[sc] < 0) {
+        L.dgrad_off[sc] = off;
+        off += (3LL * p->st[sc].info.can_h * p->st[sc].info.can_w + 63) / 64 * 64;
+      }
+    }
+  L.gsum_off = off;
+  off += (I.out_numel + 63) / 64 * 64;
+  I.workspace_floats = off;
+  *out = p;
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_plan_destroy(advx_plan* p) {
+  if (!p) return ADVX_OK;
+  if (p->dev_block) (void)hipFree(p->dev_block);
+  delete p;
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_plan_describe(const advx_plan* p, advx_plan_info* info) {
+  REQUIRE(p && info, ADVX_E_BADARG, "advx_plan_describe: null argument");
+  *info = p->info;
+  return ADVX_OK;
+}
+
+static int32_t copy_taps(const HostTaps& t, int32_t* n, int32_t* stride, int32_t* start, int32_t* count, float* w) {
+  if (n) *n = t.n;
+  if (stride) *stride = t.stride;
+  if (start) {
+    REQUIRE(count && w, ADVX_E_BADARG, "taps: start given without count/weight");
+    std::memcpy(start, t.start.data(), sizeof(int) * t.n);
+    std::memcpy(count, t.count.data(), sizeof(int) * t.n);
+    std::memcpy(w, t.w.data(), sizeof(float) * (size_t)t.n * t.stride);
+  }
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_plan_taps(const advx_plan* p, int32_t stage, int32_t axis, int32_t transposed, int32_t* n,
+                                  int32_t* stride, int32_t* start, int32_t* count, float* weight) {
+  REQUIRE(p, ADVX_E_BADARG, "advx_plan_taps: null plan");
+  REQUIRE(stage >= 0 && stage < p->info.n_stage && (axis == 0 || axis == 1), ADVX_E_BADARG, "advx_plan_taps: bad stage/axis");
+  const StageHost& s = p->st[stage];
+  const HostTaps& t = transposed ? (axis == 0 ? s.tth : s.ttw) : (axis == 0 ? s.th : s.tw);
+  return copy_taps(t, n, stride, start, count, weight);
+}
+
+extern "C" int32_t advx_taps_compute(int32_t mode, int32_t in_size, int32_t out_size, int32_t transposed, int32_t* n,
+                                     int32_t* stride, int32_t* start, int32_t* count, float* weight) {
+  REQUIRE(mode >= 0 && mode <= 2 && in_size > 0 && out_size > 0 && in_size <= 65536 && out_size <= 65536, ADVX_E_BADARG,
+          "advx_taps_compute: bad arguments");
+  HostTaps f = host_taps(mode, in_size, out_size);
+  if (!transposed) return copy_taps(f, n, stride, start, count, weight);
+  HostTaps t = host_taps_transposed(mode, in_size, out_size, f);
+  return copy_taps(t, n, stride, start, count, weight);
+}
+
+extern "C" int32_t advx_plan_out_index(const advx_plan* p, int32_t stage, int32_t c, int32_t y, int32_t x, int32_t* n_idx,
+                                       int64_t idx[2]) {
+  REQUIRE(p && n_idx && idx, ADVX_E_BADARG, "advx_plan_out_index: null argument");
+  REQUIRE(stage >= 0 && stage < p->info.n_stage, ADVX_E_BADARG, "advx_plan_out_index: bad stage");
+  const advx_stage_info& s = p->st[stage].info;
+  REQUIRE(c >= 0 && c < 3 && y >= 0 && y < s.can_h && x >= 0 && x < s.can_w, ADVX_E_BADARG, "advx_plan_out_index: out of canvas");
+  *n_idx = 0;
+  for (int k = 0; k < p->dplan.n_emit; ++k) {
+    const DEmit& e = p->dplan.e[k];
+    if (e.stage != stage) continue;
+    long long i0 = emit_index(e, c, y, x);
+    for (int t = 0; t < emit_copies(e) && *n_idx < 2; ++t) idx[(*n_idx)++] = i0 + t * emit_copy_stride(e);
+  }
+  return ADVX_OK;
+}
+
+// ---- upload of the tap tables
+static size_t taps_bytes(const HostTaps& t) { return (((size_t)t.n * 2 * sizeof(int) + (size_t)t.n * t.stride * sizeof(float)) + 255) / 256 * 256; }
+
+static void place_taps(const HostTaps& t, char* host, char* dev, size_t& off, DevTaps* d) {
+  size_t ints = (size_t)t.n * sizeof(int);
+  std::memcpy(host + off, t.start.data(), ints);
+  std::memcpy(host + off + ints, t.count.data(), ints);
+  std::memcpy(host + off + 2 * ints, t.w.data(), (size_t)t.n * t.stride * sizeof(float));
+  d->n = t.n;
+  d->stride = t.stride;
+  d->start = reinterpret_cast<const int*>(dev + off);
+  d->count = reinterpret_cast<const int*>(dev + off + ints);
+  d->w = reinterpret_cast<const float*>(dev + off + 2 * ints);
+  off += taps_bytes(t);
+}
+
+extern "C" int32_t advx_plan_upload(advx_plan* p, void* stream) {
+  REQUIRE(p, ADVX_E_BADARG, "advx_plan_upload: null plan");
+  int dev = -1;
+  HIP_TRY(hipGetDevice(&dev));
+  if (p->uploaded && p->device == dev) return ADVX_OK;
+  if (p->dev_block) {
+    (void)hipFree(p->dev_block);
+    p->dev_block = nullptr;
+    p->uploaded = false;
+  }
+  size_t total = 0;
+  for (int k = 0; k < p->info.n_stage; ++k)
+    total += taps_bytes(p->st[k].th) + taps_bytes(p->st[k].tw) + taps_bytes(p->st[k].tth) + taps_bytes(p->st[k].ttw);
+  std::vector<char> host(total, 0);
+  void* block = nullptr;
+  HIP_TRY(hipMalloc(&block, total));
+  size_t off = 0;
+  for (int k = 0; k < p->info.n_stage; ++k) {
+    DStage& D = p->dstage[k];
+    const advx_stage_info& s = p->st[k].info;
+    D.mode = s.mode; D.src_h = s.src_h; D.src_w = s.src_w; D.res_h = s.res_h; D.res_w = s.res_w;
+    D.can_h = s.can_h; D.can_w = s.can_w; D.off_y = s.off_y; D.off_x = s.off_x; D.pad_value = s.pad_value;
+    D.normalise = s.normalise; D.inner_axis_h = s.inner_axis_h;
+    for (int c = 0; c < 3; ++c) { D.mean[c] = p->desc.mean[c]; D.stdv[c] = p->desc.std[c]; }
+    place_taps(p->st[k].th, host.data(), (char*)block, off, &D.th);
+    place_taps(p->st[k].tw, host.data(), (char*)block, off, &D.tw);
+    place_taps(p->st[k].tth, host.data(), (char*)block, off, &D.tth);
+    place_taps(p->st[k].ttw, host.data(), (char*)block, off, &D.ttw);
+  }
+  hipError_t e = hipMemcpy(block, host.data(), total, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(block);
+    return fail(ADVX_E_HIP, std::string("hipMemcpy(tables): ") + hipGetErrorString(e));
+  }
+  (void)stream;
+  p->dev_block = block;
+  p->device = dev;
+  p->uploaded = true;
+  return ADVX_OK;
+}
+
+// ------------------------------------------------------------------ emit / collect
+static void emit_slices(long long n4, int batch, int* gx, int* slices, int* b_per_slice) {
+  long long bx = (n4 + kBlock - 1) / kBlock;
+  if (bx < 1) bx = 1;
+  int want = (int)std::max<long long>(1, (2048 + bx - 1) / bx);
+  int sl = std::min(batch, want);
+  int bps = (batch + sl - 1) / sl;
+  sl = (batch + bps - 1) / bps;
+  *gx = (int)bx;
+  *slices = sl;
+  *b_per_slice = bps;
+}
+
+extern "C" int32_t advx_emit(advx_plan* p, const float* argument, int32_t batch, const float* sigma_dev,
+                             const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset, float* out,
+                             float* ws, int64_t ws_floats, void* stream) {
+  REQUIRE(p && argument && out && ws, ADVX_E_BADARG, "advx_emit: null argument");
+  REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_emit: batch out of range");
+  REQUIRE(ws_floats >= p->info.workspace_floats, ADVX_E_SHAPE, "advx_emit: workspace too small");
+  REQUIRE(aligned16(out) && aligned16(ws) && (!unit_noise || aligned16(unit_noise)), ADVX_E_BADARG,
+          "advx_emit: pointers must be 16-byte aligned");
+  int noise = unit_noise ? 1 : (use_philox ? 2 : 0);
+  REQUIRE(noise == 0 || sigma_dev, ADVX_E_BADARG, "advx_emit: noise requested without sigma_dev");
+  int32_t rc = advx_plan_upload(p, stream);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  for (int k = 0; k < p->info.n_stage; ++k) {
+    const DStage& D = p->dstage[k];
+    const advx_stage_info& s = p->st[k].info;
+    const float* src = (s.src == 0) ? argument : ws + p->dplan.canvas_off[s.src - 1];
+    long long n = 3LL * D.can_h * D.can_w;
+    hipLaunchKernelGGL(k_stage_fwd, dim3(grid_for(n)), dim3(kBlock), 0, st, D, src, (long long)D.src_h * D.src_w, D.src_w,
+                       ws + p->dplan.canvas_off[k]);
+    LAUNCH_CHECK();
+  }
+  long long n4 = (p->info.out_numel + 3) >> 2;
+  int gx, slices, bps;
+  emit_slices(n4, batch, &gx, &slices, &bps);
+  dim3 grid(gx, slices);
+  if (noise == 0)
+    hipLaunchKernelGGL(k_emit<0>, grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, offset, out);
+  else if (noise == 1)
+    hipLaunchKernelGGL(k_emit<1>, grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, offset, out);
+  else
+    hipLaunchKernelGGL(k_emit<2>, grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, offset, out);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
+static int32_t launch_batch_reduce(const float* g, int batch, long long n, float* out, hipStream_t st) {
+  REQUIRE(aligned16(g) && aligned16(out), ADVX_E_BADARG, "batch_reduce: pointers must be 16-byte aligned");
+  if ((n & 3) == 0) {
+    long long n4 = n >> 2;
+    int blocks = (int)((n4 + kWave - 1) / kWave);
+    hipLaunchKernelGGL(k_batch_reduce, dim3(blocks), dim3(kBlock), 0, st, g, batch, n, out);
+  } else {
+    // rows are not 16-byte aligned: scalar columns (test-sized inputs only)
+    hipLaunchKernelGGL(k_batch_reduce_scalar, dim3(grid_for(n)), dim3(kBlock), 0, st, g, batch, n, out);
+  }
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_collect(advx_plan* p, const float* grad_out, int32_t batch, float* grad_argument,
+                                int32_t accumulate, float* ws, int64_t ws_floats, void* stream) {
+  REQUIRE(p && grad_out && grad_argument && ws, ADVX_E_BADARG, "advx_collect: null argument");
+  REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_collect: batch out of range");
+  REQUIRE(ws_floats >= p->info.workspace_floats, ADVX_E_SHAPE, "advx_collect: workspace too small");
+  int32_t rc = advx_plan_upload(p, stream);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const float* gsum = grad_out;
+  if (batch > 1) {
+    rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st);
+    if (rc) return rc;
+    gsum = ws + p->dplan.gsum_off;
+  }
+  for (int k = p->info.n_stage - 1; k >= 0; --k) {
+    const DStage& D = p->dstage[k];
+    const advx_stage_info& s = p->st[k].info;
+    const float* dgrad = (p->dplan.dgrad_off[k] >= 0) ? ws + p->dplan.dgrad_off[k] : nullptr;
+    float* gsrc = (s.src == 0) ? grad_argument : ws + p->dplan.dgrad_off[s.src - 1];
+    int acc = (s.src == 0) ? accumulate : 0;
+    long long n = 3LL * D.src_h * D.src_w;
+    hipLaunchKernelGGL(k_stage_bwd, dim3(grid_for(n)), dim3(kBlock), 0, st, D, p->dplan, k, gsum, dgrad, gsrc,
+                       (long long)D.src_h * D.src_w, D.src_w, acc);
+    LAUNCH_CHECK();
+  }
+  return ADVX_OK;
+}
+
+// ------------------------------------------------------------------------- image level
+namespace {
+struct Bump {
+  float* base;
+  long long used = 0;
+  float* take(long long floats) {
+    float* p = base + used;
+    used += (floats + 63) / 64 * 64;
+    return p;
+  }
+};
+constexpr int kMaxStatBlocks = 1024;
+constexpr int kMaxCropTStride = 40;
+
+long long blur_tiles(int H, int W) { return (long long)((H + kBlurTile - 1) / kBlurTile) * ((W + kBlurTile - 1) / kBlurTile) * 3; }
+long long partial_floats(int H, int W) { return 2 * kStatSlots * std::max<long long>(kMaxStatBlocks, blur_tiles(H, W)); }
+long long crop_table_floats(int H, int W) { return 2LL * (H + W) * (2 + 8) + 2LL * (H + W) * (2 + kMaxCropTStride) + 512; }
+
+struct CropTables {
+  DStage st;
+};
+
+// carve the crop's tap tables out of scratch and launch their device-side construction
+int32_t build_crop_stage(int H, int W, const int32_t* crop, Bump& b, hipStream_t stq, DStage* out) {
+  int ci = crop[0], cj = crop[1], ch = crop[2], cw = crop[3];
+  REQUIRE(ch > 0 && cw > 0 && ci >= 0 && cj >= 0 && ci + ch <= H && cj + cw <= W, ADVX_E_BADARG, "crop window outside the image");
+  int sh = tap_stride(ADVX_MODE_AA_BILINEAR, ch, H), sw = tap_stride(ADVX_MODE_AA_BILINEAR, cw, W);
+  auto tbound = [](int in_size, int out_size) {
+    float scale = tap_scale(in_size, out_size);
+    float support = (scale >= 1.0f) ? scale : 1.0f;
+    return (int)std::ceil(2.0 * support / scale) + 2;
+  };
+  int tsh = std::min(H, tbound(ch, H)), tsw = std::min(W, tbound(cw, W));
+  REQUIRE(sh <= 8 && sw <= 8 && tsh <= kMaxCropTStride && tsw <= kMaxCropTStride, ADVX_E_UNSUPPORTED,
+          "crop window smaller than 1/16 of the image is not supported");
+  TapBuild a[2];
+  int ins[2] = {ch, cw}, outs[2] = {H, W}, strides[2] = {sh, sw}, tstrides[2] = {tsh, tsw};
+  DevTaps f[2], t[2];
+  for (int ax = 0; ax < 2; ++ax) {
+    a[ax].mode = ADVX_MODE_AA_BILINEAR; a[ax].in_size = ins[ax]; a[ax].out_size = outs[ax];
+    a[ax].stride = strides[ax]; a[ax].tstride = tstrides[ax];
+    a[ax].start = reinterpret_cast<int*>(b.take(outs[ax]));
+    a[ax].count = reinterpret_cast<int*>(b.take(outs[ax]));
+    a[ax].w = b.take((long long)outs[ax] * strides[ax]);
+    a[ax].tstart = reinterpret_cast<int*>(b.take(ins[ax]));
+    a[ax].tcount = reinterpret_cast<int*>(b.take(ins[ax]));
+    a[ax].tw = b.take((long long)ins[ax] * tstrides[ax]);
+    f[ax] = DevTaps{outs[ax], strides[ax], a[ax].start, a[ax].count, a[ax].w};
+    t[ax] = DevTaps{ins[ax], tstrides[ax], a[ax].tstart, a[ax].tcount, a[ax].tw};
+  }
+  int rows = std::max(H + ch, W + cw);
+  hipLaunchKernelGGL(k_build_taps, dim3((rows + kBlock - 1) / kBlock, 2), dim3(kBlock), 0, stq, a[0], a[1]);
+  LAUNCH_CHECK();
+  DStage D;
+  std::memset(&D, 0, sizeof(D));
+  D.mode = ADVX_MODE_AA_BILINEAR; D.src_h = ch; D.src_w = cw; D.res_h = H; D.res_w = W; D.can_h = H; D.can_w = W;
+  D.normalise = 0; D.inner_axis_h = 0;
+  for (int c = 0; c < 3; ++c) { D.mean[c] = 0.0f; D.stdv[c] = 1.0f; }
+  D.th = f[0]; D.tw = f[1]; D.tth = t[0]; D.ttw = t[1];
+  *out = D;
+  return ADVX_OK;
+}
+}  // namespace
+
+extern "C" int64_t advx_crop_scratch_floats(int32_t H, int32_t W) { return crop_table_floats(H, W); }
+
+extern "C" int64_t advx_image_scratch_floats(int32_t H, int32_t W, int32_t blur_k) {
+  if (H <= 0 || W <= 0) return 0;
+  long long n = 3LL * H * W;
+  int r = blur_k > 0 ? blur_k / 2 : 0;
+  long long ext = 3LL * (H + 2 * r) * (W + 2 * r);
+  return partial_floats(H, W) + 3 * (n + 64) + ext + 64 + crop_table_floats(H, W) + 1024;
+}
+
+static int32_t check_blur(int H, int W, int k, float sigma) {
+  REQUIRE(k % 2 == 1 && k >= 1 && k <= 2 * kBlurMaxR + 1, ADVX_E_UNSUPPORTED, "blur kernel size must be odd and <= 31");
+  REQUIRE(k / 2 <= std::min(H, W) - 1, ADVX_E_SHAPE, "blur radius does not fit the reflect padding");
+  REQUIRE(sigma > 0.0f, ADVX_E_BADARG, "blur sigma must be positive");
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_image_fwd(const float* p, const float* x0, int32_t H, int32_t W, float eps, int32_t blur_k,
+                                  float blur_sigma, const int32_t* crop, float* s, float* argument, float* stats,
+                                  float* scratch, void* stream) {
+  REQUIRE(p && x0 && s && stats && scratch, ADVX_E_BADARG, "advx_image_fwd: null argument");
+  REQUIRE(H > 0 && W > 0 && H <= 16384 && W <= 16384, ADVX_E_SHAPE, "advx_image_fwd: bad image size");
+  REQUIRE(!crop || argument, ADVX_E_BADARG, "advx_image_fwd: crop needs an argument buffer");
+  REQUIRE(!crop || argument != s, ADVX_E_BADARG, "advx_image_fwd: with a crop, argument must not alias s");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = 3LL * H * W;
+  Bump b{scratch};
+  double* partials = reinterpret_cast<double*>(b.take(partial_floats(H, W)));
+  int nblk;
+  if (blur_k > 0) {
+    int32_t rc = check_blur(H, W, blur_k, blur_sigma);
+    if (rc) return rc;
+    float* xbuf = b.take(n);
+    hipLaunchKernelGGL(k_prep<false>, dim3(grid_for(n, kMaxStatBlocks)), dim3(kBlock), 0, st, p, x0, eps, n, xbuf, partials);
+    LAUNCH_CHECK();
+    dim3 grid((W + kBlurTile - 1) / kBlurTile, (H + kBlurTile - 1) / kBlurTile, 3);
+    hipLaunchKernelGGL(k_blur<0>, grid, dim3(kBlock), 0, st, xbuf, H, W, blur_k / 2, blur_sigma, x0, s, partials);
+    LAUNCH_CHECK();
+    nblk = (int)blur_tiles(H, W);
+  } else {
+    nblk = grid_for(n, kMaxStatBlocks);
+    hipLaunchKernelGGL(k_prep<true>, dim3(nblk), dim3(kBlock), 0, st, p, x0, eps, n, s, partials);
+    LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_finalize_image, dim3(1), dim3(kBlock), 0, st, partials, nblk, n, stats);
+  LAUNCH_CHECK();
+  if (crop) {
+    DStage D;
+    int32_t rc = build_crop_stage(H, W, crop, b, st, &D);
+    if (rc) return rc;
+    const float* src = s + (size_t)crop[0] * W + crop[1];
+    hipLaunchKernelGGL(k_stage_fwd, dim3(grid_for(n)), dim3(kBlock), 0, st, D, src, (long long)H * W, W, argument);
+    LAUNCH_CHECK();
+  } else if (argument && argument != s) {
+    HIP_TRY(hipMemcpyAsync(argument, s, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+  }
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_image_bwd(const float* p, const float* s, const float* garg, int32_t H, int32_t W, float eps,
+                                  int32_t blur_k, float blur_sigma, const int32_t* crop, float imgfit_scale,
+                                  float* grad_p, int32_t accumulate, float* scratch, void* stream) {
+  REQUIRE(p && s && garg && grad_p && scratch, ADVX_E_BADARG, "advx_image_bwd: null argument");
+  REQUIRE(H > 0 && W > 0 && H <= 16384 && W <= 16384, ADVX_E_SHAPE, "advx_image_bwd: bad image size");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = 3LL * H * W;
+  const float c_fit = imgfit_scale / (float)n;
+  Bump b{scratch};
+  (void)b.take(partial_floats(H, W));
+  const float* gs = garg;
+  if (crop) {
+    float* gsbuf = b.take(n);
+    DStage D;
+    int32_t rc = build_crop_stage(H, W, crop, b, st, &D);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(gsbuf, 0, sizeof(float) * n, st));
+    float* dst = gsbuf + (size_t)crop[0] * W + crop[1];
+    hipLaunchKernelGGL(k_resize_bwd_plain, dim3(grid_for(3LL * crop[2] * crop[3])), dim3(kBlock), 0, st, D, garg, dst,
+                       (long long)H * W, W);
+    LAUNCH_CHECK();
+    gs = gsbuf;
+  }
+  if (blur_k > 0) {
+    int32_t rc = check_blur(H, W, blur_k, blur_sigma);
+    if (rc) return rc;
+    int r = blur_k / 2;
+    float* gpre = b.take(n);
+    float* c2 = b.take(3LL * (H + 2 * r) * (W + 2 * r));
+    hipLaunchKernelGGL(k_add_imgfit, dim3(grid_for(n)), dim3(kBlock), 0, st, gs, s, c_fit, n, gpre);
+    LAUNCH_CHECK();
+    dim3 grid((W + 2 * r + kBlurTile - 1) / kBlurTile, (H + 2 * r + kBlurTile - 1) / kBlurTile, 3);
+    hipLaunchKernelGGL(k_blur<1>, grid, dim3(kBlock), 0, st, gpre, H, W, r, blur_sigma, (const float*)nullptr, c2,
+                       (double*)nullptr);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_tanh_bwd<true>, dim3(grid_for(n)), dim3(kBlock), 0, st, p, s, gs, c2, H, W, r, eps, c_fit,
+                       accumulate, grad_p);
+    LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(k_tanh_bwd<false>, dim3(grid_for(n)), dim3(kBlock), 0, st, p, s, gs, (const float*)nullptr, H, W, 0,
+                       eps, c_fit, accumulate, grad_p);
+    LAUNCH_CHECK();
+  }
+  return ADVX_OK;
+}
+
+// ------------------------------------------------------------------------------ update
+static OptScalars to_dev(const advx_opt_scalars* o) {
+  OptScalars d;
+  d.kind = o->kind; d.apply = o->apply; d.lr = o->lr; d.decay = o->decay; d.w1 = o->w1; d.beta2 = o->beta2;
+  d.w2 = o->w2; d.bias2_sqrt = o->bias2_sqrt; d.eps = o->eps; d.neg_step_size = o->neg_step_size;
+  return d;
+}
+static int32_t check_opt(const advx_opt_scalars* o, const float* m, const float* v) {
+  REQUIRE(o->kind == ADVX_OPT_ADAMW || o->kind == ADVX_OPT_SIGN, ADVX_E_UNSUPPORTED, "unknown optimiser kind");
+  if (o->kind == ADVX_OPT_ADAMW && o->apply) {
+    REQUIRE(m && v, ADVX_E_BADARG, "AdamW needs m and v");
+    REQUIRE(o->bias2_sqrt > 0.0f, ADVX_E_BADARG, "AdamW bias2_sqrt must be positive");
+  }
+  return ADVX_OK;
+}
+
+extern "C" int64_t advx_update_scratch_floats(int64_t n) {
+  (void)n;
+  return 2 * 2048 + 64;
+}
+
+extern "C" int32_t advx_update(float* p, float* m, float* v, float* grad_p, const float* mask, int64_t n,
+                               const advx_opt_scalars* opt, float* stats, float* scratch, void* stream) {
+  REQUIRE(p && grad_p && mask && opt && stats && scratch, ADVX_E_BADARG, "advx_update: null argument");
+  REQUIRE(n > 0, ADVX_E_SHAPE, "advx_update: n must be positive");
+  int32_t rc = check_opt(opt, m, v);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  double* partials = reinterpret_cast<double*>(scratch);
+  int nblk = grid_for(n, 2048);
+  hipLaunchKernelGGL(k_update, dim3(nblk), dim3(kBlock), 0, st, p, m, v, grad_p, mask, (long long)n, to_dev(opt), partials);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_finalize_norm, dim3(1), dim3(kBlock), 0, st, partials, nblk, stats);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
+// ------------------------------------------------------------------------------- fused
+extern "C" int32_t advx_fused_supported(const advx_plan* p) {
+  if (!p) return 0;
+  const advx_stage_info& s = p->st[0].info;
+  return (p->info.kind == ADVX_KIND_LLAVA && s.src_h == s.res_h && s.src_w == s.res_w && ((s.src_h * s.src_w) % 4 == 0)) ? 1 : 0;
+}
+
+extern "C" int64_t advx_fused_scratch_floats(const advx_plan* p) {
+  if (!p) return 0;
+  long long n = 3LL * p->info.in_h * p->info.in_w;
+  long long fwd_blocks = (n / 4 + kBlock - 1) / kBlock;
+  long long bwd_blocks = (n / 4 + kWave - 1) / kWave;
+  return 2 * kStatSlots * fwd_blocks + 2 * bwd_blocks + 256;
+}
+
+extern "C" int32_t advx_fused_fwd(advx_plan* p, const float* pp, const float* x0, float eps, int32_t batch,
+                                  const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset, float* out,
+                                  float* s_out, float* stats, float* scratch, void* stream) {
+  REQUIRE(p && pp && x0 && out && stats && scratch, ADVX_E_BADARG, "advx_fused_fwd: null argument");
+  REQUIRE(advx_fused_supported(p), ADVX_E_UNSUPPORTED, "advx_fused_fwd: plan is not an identity LLaVA plan");
+  REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_fused_fwd: batch out of range");
+  REQUIRE(aligned16(pp) && aligned16(x0) && aligned16(out) && (!unit_noise || aligned16(unit_noise)) &&
+              (!s_out || aligned16(s_out)), ADVX_E_BADARG,
+          "advx_fused_fwd: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int plane = p->info.in_h * p->info.in_w;
+  const long long n = 3LL * plane, n4 = n >> 2;
+  int gx, slices, bps;
+  emit_slices(n4, batch, &gx, &slices, &bps);
+  double* partials = reinterpret_cast<double*>(scratch);
+  const float* m = p->desc.mean;
+  const float* sd = p->desc.std;
+  dim3 grid(gx, slices);
+  int noise = unit_noise ? 1 : (use_philox ? 2 : 0);
+#define ADVX_FF(N)                                                                                              \
+  hipLaunchKernelGGL(k_fused_fwd<N>, grid, dim3(kBlock), 0, st, pp, x0, eps, plane, m[0], m[1], m[2], sd[0], sd[1], \
+                     sd[2], batch, bps, stats, unit_noise, seed, offset, out, s_out, partials)
+  if (noise == 0) ADVX_FF(0); else if (noise == 1) ADVX_FF(1); else ADVX_FF(2);
+#undef ADVX_FF
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_finalize_image, dim3(1), dim3(kBlock), 0, st, partials, gx, n, stats);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_fused_bwd(advx_plan* p, const float* g, int32_t batch, float* pp, const float* x0, float eps,
+                                  float imgfit_scale, const float* mask, float* m, float* v, float* grad_p,
+                                  const advx_opt_scalars* opt, float* stats, float* scratch, void* stream) {
+  REQUIRE(p && g && pp && x0 && grad_p && scratch, ADVX_E_BADARG, "advx_fused_bwd: null argument");
+  REQUIRE(advx_fused_supported(p), ADVX_E_UNSUPPORTED, "advx_fused_bwd: plan is not an identity LLaVA plan");
+  REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_fused_bwd: batch out of range");
+  REQUIRE(aligned16(g), ADVX_E_BADARG, "advx_fused_bwd: grad_out must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int plane = p->info.in_h * p->info.in_w;
+  const long long n = 3LL * plane, n4 = n >> 2;
+  const float c_fit = imgfit_scale / (float)n;
+  const float* sd = p->desc.std;
+  int blocks = (int)((n4 + kWave - 1) / kWave);
+  long long fwd_blocks = (n4 + kBlock - 1) / kBlock;
+  double* partials = reinterpret_cast<double*>(scratch) + kStatSlots * fwd_blocks;
+  if (opt) {
+    REQUIRE(mask && stats, ADVX_E_BADARG, "advx_fused_bwd: update needs mask and stats");
+    int32_t rc = check_opt(opt, m, v);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fused_bwd<true>, dim3(blocks), dim3(kBlock), 0, st, g, batch, pp, x0, eps, plane, sd[0], sd[1],
+                       sd[2], c_fit, mask, m, v, grad_p, to_dev(opt), partials);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_finalize_norm, dim3(1), dim3(kBlock), 0, st, partials, blocks, stats);
+    LAUNCH_CHECK();
+  } else {
+    OptScalars none;
+    std::memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL(k_fused_bwd<false>, dim3(blocks), dim3(kBlock), 0, st, g, batch, pp, x0, eps, plane, sd[0], sd[1],
+                       sd[2], c_fit, mask, m, v, grad_p, none, partials);
+    LAUNCH_CHECK();
+  }
+  return ADVX_OK;
+}
+
+// -------------------------------------------------------------------------- single ops
+extern "C" int32_t advx_tanh_fwd(const float* p, float eps, float* x, int64_t n, void* stream) {
+  REQUIRE(p && x && n > 0, ADVX_E_BADARG, "advx_tanh_fwd: bad argument");
+  hipLaunchKernelGGL(k_tanh_fwd, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, p, eps, (long long)n, x);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+extern "C" int32_t advx_tanh_bwd(const float* p, const float* gx, float eps, float* gp, int64_t n, void* stream) {
+  REQUIRE(p && gx && gp && n > 0, ADVX_E_BADARG, "advx_tanh_bwd: bad argument");
+  hipLaunchKernelGGL(k_tanh_bwd_plain, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, p, gx, eps, (long long)n, gp);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+extern "C" int32_t advx_blur_fwd(const float* x, int32_t H, int32_t W, int32_t k, float sigma, float* y, void* stream) {
+  REQUIRE(x && y && H > 0 && W > 0, ADVX_E_BADARG, "advx_blur_fwd: bad argument");
+  int32_t rc = check_blur(H, W, k, sigma);
+  if (rc) return rc;
+  dim3 grid((W + kBlurTile - 1) / kBlurTile, (H + kBlurTile - 1) / kBlurTile, 3);
+  hipLaunchKernelGGL(k_blur<0>, grid, dim3(kBlock), 0, (hipStream_t)stream, x, H, W, k / 2, sigma, (const float*)nullptr, y,
+                     (double*)nullptr);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+extern "C" int32_t advx_blur_bwd(const float* gy, int32_t H, int32_t W, int32_t k, float sigma, float* gx, float* scratch,
+                                 void* stream) {
+  REQUIRE(gy && gx && scratch && H > 0 && W > 0, ADVX_E_BADARG, "advx_blur_bwd: bad argument");
+  int32_t rc = check_blur(H, W, k, sigma);
+  if (rc) return rc;
+  int r = k / 2;
+  dim3 grid((W + 2 * r + kBlurTile - 1) / kBlurTile, (H + 2 * r + kBlurTile - 1) / kBlurTile, 3);
+  hipLaunchKernelGGL(k_blur<1>, grid, dim3(kBlock), 0, (hipStream_t)stream, gy, H, W, r, sigma, (const float*)nullptr,
+                     scratch, (double*)nullptr);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_blur_fold, dim3(grid_for(3LL * H * W)), dim3(kBlock), 0, (hipStream_t)stream, scratch, H, W, r, gx);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+extern "C" int32_t advx_crop_resize_fwd(const float* src, int32_t H, int32_t W, const int32_t* crop, float* dst,
+                                        float* scratch, void* stream) {
+  REQUIRE(src && crop && dst && scratch && H > 0 && W > 0, ADVX_E_BADARG, "advx_crop_resize_fwd: bad argument");
+  Bump b{scratch};
+  DStage D;
+  int32_t rc = build_crop_stage(H, W, crop, b, (hipStream_t)stream, &D);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_stage_fwd, dim3(grid_for(3LL * H * W)), dim3(kBlock), 0, (hipStream_t)stream, D,
+                     src + (size_t)crop[0] * W + crop[1], (long long)H * W, W, dst);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+extern "C" int32_t advx_crop_resize_bwd(const float* gdst, int32_t H, int32_t W, const int32_t* crop, float* gsrc,
+                                        float* scratch, void* stream) {
+  REQUIRE(gdst && crop && gsrc && scratch && H > 0 && W > 0, ADVX_E_BADARG, "advx_crop_resize_bwd: bad argument");
+  Bump b{scratch};
+  DStage D;
+  int32_t rc = build_crop_stage(H, W, crop, b, (hipStream_t)stream, &D);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(gsrc, 0, sizeof(float) * 3 * (size_t)H * W, (hipStream_t)stream));
+  hipLaunchKernelGGL(k_resize_bwd_plain, dim3(grid_for(3LL * crop[2] * crop[3])), dim3(kBlock), 0, (hipStream_t)stream, D,
+                     gdst, gsrc + (size_t)crop[0] * W + crop[1], (long long)H * W, W);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+extern "C" int32_t advx_batch_reduce(const float* g, int32_t batch, int64_t n, float* out, void* stream) {
+  REQUIRE(g && out && batch >= 1 && n > 0, ADVX_E_BADARG, "advx_batch_reduce: bad argument");
+  return launch_batch_reduce(g, batch, n, out, (hipStream_t)stream);
+}
+extern "C" int32_t advx_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+  REQUIRE(out && n > 0, ADVX_E_BADARG, "advx_philox_normal: bad argument");
+  long long n4 = (n + 3) >> 2;
+  hipLaunchKernelGGL(k_philox_normal, dim3((int)((n4 + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out,
+                     (long long)n, seed, offset);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}

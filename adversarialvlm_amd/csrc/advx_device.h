@@ -1,0 +1,202 @@
+// advx_device.h - device-side structs and helpers shared by the kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "advx_taps.h"
+
+namespace advx {
+
+constexpr int kBlock = 256;       // 4 wave64 per workgroup
+constexpr int kWave = 64;
+constexpr int kStatSlots = 6;     // per-block partial sums (double)
+
+// ----------------------------------------------------------------------------- tables
+struct DevTaps {
+  int n;
+  int stride;
+  const int* start;
+  const int* count;
+  const float* w;
+};
+
+// one separable resize into a padded (and optionally normalised) canvas
+struct DStage {
+  int mode;
+  int src_h, src_w;
+  int res_h, res_w;
+  int can_h, can_w;
+  int off_y, off_x;
+  float pad_value;
+  int normalise;
+  int inner_axis_h;
+  float mean[3];
+  float stdv[3];
+  DevTaps th, tw;    // per output row / column: taps into the source
+  DevTaps tth, ttw;  // per source row / column: taps into the output (backward gather)
+};
+
+#define ADVX_EMIT_PLAIN 0
+#define ADVX_EMIT_TILES 1
+#define ADVX_EMIT_QWEN 2
+
+// how a canvas is laid out inside one sample's pixel_values (flat index space)
+struct DEmit {
+  int kind;
+  int stage;            // which canvas
+  long long out_begin;  // first flat index written by this emit
+  long long out_count;  // number of flat indices
+  int can_h, can_w;
+  int tile, tiles_w;                   // TILES
+  int patch, merge, temporal, grid_w;  // QWEN
+};
+
+struct DPlan {
+  int n_emit;
+  DEmit e[2];
+  long long out_numel;
+  int n_stage;
+  long long canvas_off[2];  // float offsets into the workspace
+  long long dgrad_off[2];   // gradient buffers of canvases that feed a later stage (-1: none)
+  long long gsum_off;       // batch-reduced gradient in output layout
+};
+
+// ------------------------------------------------------------------ layout index maps
+// flat output index (first temporal copy) of canvas element (c,y,x)
+__device__ __host__ inline long long emit_index(const DEmit& e, int c, int y, int x) {
+  if (e.kind == ADVX_EMIT_PLAIN) {
+    return e.out_begin + ((long long)c * e.can_h + y) * e.can_w + x;
+  }
+  if (e.kind == ADVX_EMIT_TILES) {
+    int tyi = y / e.tile, ty = y - tyi * e.tile;
+    int txi = x / e.tile, tx = x - txi * e.tile;
+    long long t = (long long)tyi * e.tiles_w + txi;
+    return e.out_begin + ((t * 3 + c) * e.tile + ty) * e.tile + tx;
+  }
+  // QWEN: row = ((by*(grid_w/merge)+bx)*merge+mh)*merge+mw ; col = ((c*T+t)*P+ph)*P+pw
+  int gy = y / e.patch, ph = y - gy * e.patch;
+  int gx = x / e.patch, pw = x - gx * e.patch;
+  int by = gy / e.merge, mh = gy - by * e.merge;
+  int bx = gx / e.merge, mw = gx - bx * e.merge;
+  long long row = (((long long)by * (e.grid_w / e.merge) + bx) * e.merge + mh) * e.merge + mw;
+  long long col = (((long long)c * e.temporal + 0) * e.patch + ph) * e.patch + pw;
+  long long row_len = 3LL * e.temporal * e.patch * e.patch;
+  return e.out_begin + row * row_len + col;
+}
+
+// stride between the temporal copies of one canvas element (QWEN), number of copies
+__device__ __host__ inline int emit_copies(const DEmit& e) { return e.kind == ADVX_EMIT_QWEN ? e.temporal : 1; }
+__device__ __host__ inline long long emit_copy_stride(const DEmit& e) { return (long long)e.patch * e.patch; }
+
+// inverse: flat index (inside this emit's range) -> canvas element
+__device__ __host__ inline void emit_inverse(const DEmit& e, long long idx, int& c, int& y, int& x) {
+  long long r = idx - e.out_begin;
+  if (e.kind == ADVX_EMIT_PLAIN) {
+    long long plane = (long long)e.can_h * e.can_w;
+    c = (int)(r / plane);
+    long long q = r - (long long)c * plane;
+    y = (int)(q / e.can_w);
+    x = (int)(q - (long long)y * e.can_w);
+    return;
+  }
+  if (e.kind == ADVX_EMIT_TILES) {
+    long long tt = (long long)e.tile * e.tile;
+    long long t = r / (3 * tt);
+    long long q = r - t * 3 * tt;
+    c = (int)(q / tt);
+    q -= (long long)c * tt;
+    int ty = (int)(q / e.tile);
+    int tx = (int)(q - (long long)ty * e.tile);
+    int tyi = (int)(t / e.tiles_w), txi = (int)(t - (long long)tyi * e.tiles_w);
+    y = tyi * e.tile + ty;
+    x = txi * e.tile + tx;
+    return;
+  }
+  long long row_len = 3LL * e.temporal * e.patch * e.patch;
+  long long row = r / row_len;
+  int col = (int)(r - row * row_len);
+  int pp = e.patch * e.patch;
+  int ct = col / pp;
+  int q = col - ct * pp;
+  c = ct / e.temporal;
+  int ph = q / e.patch, pw = q - ph * e.patch;
+  int mw = (int)(row % e.merge);
+  long long r2 = row / e.merge;
+  int mh = (int)(r2 % e.merge);
+  long long blk = r2 / e.merge;
+  int bw = e.grid_w / e.merge;
+  int by = (int)(blk / bw), bx = (int)(blk - (long long)by * bw);
+  y = (by * e.merge + mh) * e.patch + ph;
+  x = (bx * e.merge + mw) * e.patch + pw;
+}
+
+// ------------------------------------------------------------------------- reductions
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+
+// Block-wide sum of NS doubles per thread; thread 0 writes the NS totals to dst.
+template <int NS>
+__device__ inline void block_sum_store(const double (&acc)[NS], double* dst) {
+  __shared__ double red[kBlock / kWave][NS];
+  int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    double v = wave_sum(acc[k]);
+    if (lane == 0) red[wid][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      double t = 0.0;
+      for (int w = 0; w < (int)(blockDim.x / kWave); ++w) t += red[w][k];
+      dst[k] = t;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------- Philox noise
+struct Philox {
+  uint32_t k0, k1;
+};
+__device__ inline uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+// four N(0,1) draws from one Philox block (Box-Muller on 24-bit uniforms)
+__device__ inline float4 philox_normal4(unsigned long long gidx, unsigned long long offset,
+                                        unsigned long long seed) {
+  uint4 c = make_uint4((uint32_t)gidx, (uint32_t)(gidx >> 32), (uint32_t)offset, (uint32_t)(offset >> 32));
+  uint4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const float k24 = 1.0f / 16777216.0f;
+  float u1 = (float)((r.x >> 8) + 1u) * k24;  // (0,1]
+  float u2 = (float)(r.y >> 8) * k24;         // [0,1)
+  float u3 = (float)((r.z >> 8) + 1u) * k24;
+  float u4 = (float)(r.w >> 8) * k24;
+  // v_log_f32 is log2; -2 ln u = -2 ln2 log2 u.  v_sin/v_cos take revolutions.
+  float ra = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+  float rb = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u3));
+  float4 z;
+  z.x = ra * __builtin_amdgcn_cosf(u2);
+  z.y = ra * __builtin_amdgcn_sinf(u2);
+  z.z = rb * __builtin_amdgcn_cosf(u4);
+  z.w = rb * __builtin_amdgcn_sinf(u4);
+  return z;
+}
+
+}  // namespace advx

@@ -1,0 +1,676 @@
+// advx_kernels.h - the HIP kernels of the pixel-space hot path (gfx950, wave64).
+//
+// All kernels are HBM/L2-bound elementwise, stencil, gather or reduction work: no MFMA.
+// The two kernels that move B*P_out floats (k_emit, k_batch_reduce / the fused pair) are
+// the ones the roofline refers to; everything else touches ~1-15 MB and is bounded by
+// launch latency.  Compiled with -ffp-contract=off so that a*b+c rounds like torch's
+// separate mul / add unless fmaf is written explicitly.
+#pragma once
+#include "advx_device.h"
+
+namespace advx {
+
+// =========================================================================== image fwd
+// per-element statistics of s = x0 + x accumulated in double (attack_model.py:86-106,
+// 366-373, 386-391): [0] sum d, [1] sum d^2 with d = |q - s|, q = trunc(clamp(s)*255)/255;
+// [2] sum relu(-s)^2 + relu(s-0.9)^2 ; [3] sum x ; [4] sum x^2
+__device__ inline void stat_accumulate(float s, float x, double (&acc)[kStatSlots]) {
+  float cl = fminf(fmaxf(s, 0.0f), 1.0f);
+  float q = (float)(uint32_t)(cl * 255.0f) / 255.0f;  // C truncation, like astype(uint8)
+  float d = fabsf(q - s);
+  float lo = fmaxf(0.9f * 0.0f - s, 0.0f);
+  float up = fmaxf(s - 0.9f * 1.0f, 0.0f);
+  acc[0] += (double)d;
+  acc[1] += (double)d * (double)d;
+  acc[2] += (double)(lo * lo + up * up);
+  acc[3] += (double)x;
+  acc[4] += (double)x * (double)x;
+}
+
+// x = eps*tanh(p); WRITE_S: s = x0 + x and statistics partials, else write x (blur follows)
+template <bool WRITE_S>
+__global__ void __launch_bounds__(kBlock) k_prep(const float* __restrict__ p, const float* __restrict__ x0,
+                                                 float eps, long long n, float* __restrict__ out,
+                                                 double* __restrict__ partials) {
+  double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float x = eps * tanhf(p[i]);
+    if (WRITE_S) {
+      float s = x0[i] + x;
+      out[i] = s;
+      stat_accumulate(s, x, acc);
+    } else {
+      out[i] = x;
+    }
+  }
+  if (WRITE_S) block_sum_store<kStatSlots>(acc, partials + (size_t)blockIdx.x * kStatSlots);
+}
+
+// single block: reduce the per-block partials, rotate SIGMA <- QERR_STD, write stats
+__global__ void __launch_bounds__(kBlock) k_finalize_image(const double* __restrict__ partials, int nblk,
+                                                           long long n, float* __restrict__ stats) {
+  double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x)
+    for (int k = 0; k < kStatSlots; ++k) acc[k] += partials[(size_t)b * kStatSlots + k];
+  __shared__ double tot[kStatSlots];
+  block_sum_store<kStatSlots>(acc, tot);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double N = (double)n;
+    double mean_d = tot[0] / N;
+    double var_d = (n > 1) ? (tot[1] - tot[0] * tot[0] / N) / (N - 1.0) : 0.0;
+    double mean_x = tot[3] / N;
+    double var_x = (n > 1) ? (tot[4] - tot[3] * tot[3] / N) / (N - 1.0) : 0.0;
+    stats[0] = stats[1];  // ADVX_STAT_SIGMA <- previous step's QERR_STD
+    stats[1] = (float)sqrt(var_d > 0.0 ? var_d : 0.0);
+    stats[2] = (float)mean_d;
+    stats[3] = (float)tot[0];
+    stats[4] = (float)(tot[2] / N);
+    stats[5] = (float)mean_x;
+    stats[6] = (float)sqrt(var_x > 0.0 ? var_x : 0.0);
+  }
+}
+
+// ================================================================================ blur
+// Separable Gaussian, LDS-staged 32x32 output tile with halo r on every side; one block =
+// one tile of one channel.  REFLECT: torchvision GaussianBlur forward (reflect pad).
+// ZERO + extended domain: the full correlation over [-r, n-1+r]^2 that the backward folds.
+constexpr int kBlurTile = 32;
+constexpr int kBlurMaxR = 15;
+
+__device__ inline int reflect_index(int u, int n) {
+  if (u < 0) u = -u;
+  if (u > n - 1) u = 2 * (n - 1) - u;
+  if (u < 0) u = 0;  // only for positions no valid output reads
+  if (u > n - 1) u = n - 1;
+  return u;
+}
+
+// MODE 0: reflect, output HxW, epilogue s = x0 + blur(x) with statistics (x0 may be null: plain store)
+// MODE 1: zero padding, output (H+2r)x(W+2r)
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_blur(const float* __restrict__ in, int H, int W, int r, float sigma,
+                                                 const float* __restrict__ x0, float* __restrict__ out,
+                                                 double* __restrict__ partials) {
+  __shared__ float wgt[2 * kBlurMaxR + 1];
+  __shared__ float tile[kBlurTile + 2 * kBlurMaxR][kBlurTile + 2 * kBlurMaxR + 1];
+  __shared__ float tmp[kBlurTile + 2 * kBlurMaxR][kBlurTile + 1];
+  const int k = 2 * r + 1;
+  const int ext = (MODE == 1) ? r : 0;
+  const int OH = H + 2 * ext, OW = W + 2 * ext;
+  const int c = blockIdx.z;
+  const int oy0 = blockIdx.y * kBlurTile, ox0 = blockIdx.x * kBlurTile;
+  // weights: exp(-0.5 (t/sigma)^2) / sum  (torchvision _get_gaussian_kernel1d)
+  if (threadIdx.x < k) {
+    float t = (float)((int)threadIdx.x - r);
+    float q = t / sigma;
+    wgt[threadIdx.x] = expf(-0.5f * (q * q));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float sum = 0.0f;
+    for (int i = 0; i < k; ++i) sum += wgt[i];
+    for (int i = 0; i < k; ++i) wgt[i] = wgt[i] / sum;
+  }
+  const float* src = in + (size_t)c * H * W;
+  const int th = kBlurTile + 2 * r, tw = kBlurTile + 2 * r;
+  for (int e = threadIdx.x; e < th * tw; e += blockDim.x) {
+    int ty = e / tw, tx = e - ty * tw;
+    int gy = oy0 - ext - r + ty, gx = ox0 - ext - r + tx;  // image coordinates
+    float v;
+    if (MODE == 0) {
+      v = src[(size_t)reflect_index(gy, H) * W + reflect_index(gx, W)];
+    } else {
+      v = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[(size_t)gy * W + gx] : 0.0f;
+    }
+    tile[ty][tx] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < th * kBlurTile; e += blockDim.x) {
+    int ty = e / kBlurTile, x = e - ty * kBlurTile;
+    float a = 0.0f;
+    for (int t = 0; t < k; ++t) a += wgt[t] * tile[ty][x + t];
+    tmp[ty][x] = a;
+  }
+  __syncthreads();
+  double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
+  for (int e = threadIdx.x; e < kBlurTile * kBlurTile; e += blockDim.x) {
+    int y = e / kBlurTile, x = e - y * kBlurTile;
+    int oy = oy0 + y, ox = ox0 + x;
+    if (oy < OH && ox < OW) {
+      float a = 0.0f;
+      for (int t = 0; t < k; ++t) a += wgt[t] * tmp[y + t][x];
+      size_t o = ((size_t)c * OH + oy) * OW + ox;
+      if (MODE == 0 && x0 != nullptr) {
+        float s = x0[o] + a;
+        out[o] = s;
+        stat_accumulate(s, a, acc);
+      } else {
+        out[o] = a;
+      }
+    }
+  }
+  if (MODE == 0 && partials != nullptr) {
+    size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    block_sum_store<kStatSlots>(acc, partials + blk * kStatSlots);
+  }
+}
+
+// adjoint of reflect-pad + correlation = fold of the zero-padded full correlation `c2`
+// (extended domain (H+2r)x(W+2r)): g[i] = c[i] + [1<=i<=r] c[-i] + [n-1-r<=i<=n-2] c[2(n-1)-i]
+__device__ inline float blur_fold(const float* __restrict__ c2, int H, int W, int r, int y, int x) {
+  const int OW = W + 2 * r;
+  // an index folds from the left side, the right side, or (tiny images) both
+  int yy[3], xx[3], ny = 0, nx = 0;
+  yy[ny++] = y;
+  if (y >= 1 && y <= r) yy[ny++] = -y;
+  if (y <= H - 2 && y >= H - 1 - r) yy[ny++] = 2 * (H - 1) - y;
+  xx[nx++] = x;
+  if (x >= 1 && x <= r) xx[nx++] = -x;
+  if (x <= W - 2 && x >= W - 1 - r) xx[nx++] = 2 * (W - 1) - x;
+  float a = 0.0f;
+  for (int i = 0; i < ny; ++i)
+    for (int j = 0; j < nx; ++j) a += c2[(size_t)(yy[i] + r) * OW + (xx[j] + r)];
+  return a;
+}
+
+__global__ void __launch_bounds__(kBlock) k_blur_fold(const float* __restrict__ c2, int H, int W, int r,
+                                                      float* __restrict__ gx) {
+  long long n = 3LL * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    int ch = (int)(i / ((long long)H * W));
+    int rem = (int)(i - (long long)ch * H * W);
+    int y = rem / W, x = rem - y * W;
+    gx[i] = blur_fold(c2 + (size_t)ch * (H + 2 * r) * (W + 2 * r), H, W, r, y, x);
+  }
+}
+
+// ============================================================================ image bwd
+// d(image_fit_loss)/ds * scale, scale = imgfit_scale / N  (autograd of attack_model.py:94-104)
+__device__ inline float imgfit_grad(float s, float c) {
+  float lo = fmaxf(0.9f * 0.0f - s, 0.0f);
+  float up = fmaxf(s - 0.9f * 1.0f, 0.0f);
+  return c * (2.0f * up) - c * (2.0f * lo);
+}
+
+// g_pre[i] = grad_s[i] + imgfit'(s[i])   (input of the blur adjoint)
+__global__ void __launch_bounds__(kBlock) k_add_imgfit(const float* __restrict__ gs, const float* __restrict__ s,
+                                                       float c, long long n, float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    out[i] = gs[i] + imgfit_grad(s[i], c);
+}
+
+// grad_p (+)= (g_x * eps) * (1 - tanh(p)^2) ; g_x = folded blur adjoint or gs + imgfit'
+template <bool BLUR>
+__global__ void __launch_bounds__(kBlock) k_tanh_bwd(const float* __restrict__ p, const float* __restrict__ s,
+                                                     const float* __restrict__ gs, const float* __restrict__ c2,
+                                                     int H, int W, int r, float eps, float c_fit, int accumulate,
+                                                     float* __restrict__ grad_p) {
+  long long n = 3LL * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float gx;
+    if (BLUR) {
+      int ch = (int)(i / ((long long)H * W));
+      int rem = (int)(i - (long long)ch * H * W);
+      int y = rem / W, x = rem - y * W;
+      gx = blur_fold(c2 + (size_t)ch * (H + 2 * r) * (W + 2 * r), H, W, r, y, x);
+    } else {
+      gx = gs[i] + imgfit_grad(s[i], c_fit);
+    }
+    float t = tanhf(p[i]);
+    float g = (gx * eps) * (1.0f - t * t);
+    grad_p[i] = accumulate ? (grad_p[i] + g) : g;
+  }
+}
+
+// plain tanh ops (unit tests / plugin-level autograd)
+__global__ void __launch_bounds__(kBlock) k_tanh_fwd(const float* __restrict__ p, float eps, long long n,
+                                                     float* __restrict__ x) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    x[i] = eps * tanhf(p[i]);
+}
+__global__ void __launch_bounds__(kBlock) k_tanh_bwd_plain(const float* __restrict__ p, const float* __restrict__ gx,
+                                                           float eps, long long n, float* __restrict__ gp) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float t = tanhf(p[i]);
+    gp[i] = (gx[i] * eps) * (1.0f - t * t);
+  }
+}
+
+// ===================================================================== tap-table builder
+// Device-side construction of the tables of a dynamic resize (the random-resized-crop
+// window changes every step).  blockIdx.y = axis; rows [0,out) forward, [out,out+in) transposed.
+struct TapBuild {
+  int mode, in_size, out_size, stride, tstride;
+  int* start;
+  int* count;
+  float* w;
+  int* tstart;
+  int* tcount;
+  float* tw;
+};
+__global__ void __launch_bounds__(kBlock) k_build_taps(TapBuild a0, TapBuild a1) {
+  const TapBuild a = (blockIdx.y == 0) ? a0 : a1;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float row[64];
+  if (i < a.out_size) {
+    float* w = a.w + (size_t)i * a.stride;
+    TapRow r = tap_row(a.mode, a.in_size, a.out_size, i, a.stride, w);
+    a.start[i] = r.start;
+    a.count[i] = r.count;
+  } else if (i < a.out_size + a.in_size) {
+    int j = i - a.out_size;
+    TapRow t = tap_bounds_transposed(a.mode, a.in_size, a.out_size, j);
+    if (t.count > a.tstride) t.count = a.tstride;  // guarded by the host-side bound
+    a.tstart[j] = t.start;
+    a.tcount[j] = t.count;
+    float* tw = a.tw + (size_t)j * a.tstride;
+    for (int q = 0; q < a.tstride; ++q) tw[q] = 0.0f;
+    int st = a.stride < 64 ? a.stride : 64;
+    for (int q = 0; q < t.count; ++q) {
+      TapRow r = tap_row(a.mode, a.in_size, a.out_size, t.start + q, st, row);
+      int slot = j - r.start;
+      tw[q] = (slot >= 0 && slot < st) ? row[slot] : 0.0f;
+    }
+  }
+}
+
+// ========================================================================== stage fwd
+// canvas[c,y,x] = normalise(pad | sum_a wa sum_b wb src[...])  - one thread per canvas element
+__global__ void __launch_bounds__(kBlock) k_stage_fwd(DStage st, const float* __restrict__ src, long long src_cstride,
+                                                      int src_rstride, float* __restrict__ canvas) {
+  long long n = 3LL * st.can_h * st.can_w;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i / ((long long)st.can_h * st.can_w));
+    int rem = (int)(i - (long long)c * st.can_h * st.can_w);
+    int y = rem / st.can_w, x = rem - y * st.can_w;
+    int ry = y - st.off_y, rx = x - st.off_x;
+    float v;
+    if (ry >= 0 && ry < st.res_h && rx >= 0 && rx < st.res_w) {
+      const float* sp = src + (size_t)c * src_cstride;
+      int ys = st.th.start[ry], yc = st.th.count[ry];
+      int xs = st.tw.start[rx], xc = st.tw.count[rx];
+      const float* wy = st.th.w + (size_t)ry * st.th.stride;
+      const float* wx = st.tw.w + (size_t)rx * st.tw.stride;
+      v = 0.0f;
+      if (!st.inner_axis_h) {
+        for (int a = 0; a < yc; ++a) {
+          const float* rowp = sp + (size_t)(ys + a) * src_rstride + xs;
+          float h = 0.0f;
+          for (int b = 0; b < xc; ++b) h += wx[b] * rowp[b];
+          v += wy[a] * h;
+        }
+      } else {
+        for (int b = 0; b < xc; ++b) {
+          float h = 0.0f;
+          for (int a = 0; a < yc; ++a) h += wy[a] * sp[(size_t)(ys + a) * src_rstride + xs + b];
+          v += wx[b] * h;
+        }
+      }
+    } else {
+      v = st.pad_value;
+    }
+    if (st.normalise) v = (v - st.mean[c]) / st.stdv[c];
+    canvas[i] = v;
+  }
+}
+
+// ========================================================================== stage bwd
+// gradient of canvas element (c,y,x): sum over the emits that publish it (+ temporal
+// copies) plus the gradient that a later stage propagated into this canvas.
+__device__ inline float canvas_grad_at(const DPlan& pl, int stage, const float* __restrict__ gsum,
+                                       const float* __restrict__ dgrad, int can_h, int can_w, int c, int y, int x) {
+  float g = 0.0f;
+  for (int k = 0; k < pl.n_emit; ++k) {
+    const DEmit& e = pl.e[k];
+    if (e.stage != stage) continue;
+    long long idx = emit_index(e, c, y, x);
+    int copies = emit_copies(e);
+    long long cs = emit_copy_stride(e);
+    for (int t = 0; t < copies; ++t) g += gsum[idx + t * cs];
+  }
+  if (dgrad != nullptr) g += dgrad[((size_t)c * can_h + y) * can_w + x];
+  return g;
+}
+
+// one thread per SOURCE element: transposed-tap gather (no atomics)
+__global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, DPlan pl, int stage, const float* __restrict__ gsum,
+                                                      const float* __restrict__ dgrad, float* __restrict__ gsrc,
+                                                      long long gsrc_cstride, int gsrc_rstride, int accumulate) {
+  long long n = 3LL * st.src_h * st.src_w;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i / ((long long)st.src_h * st.src_w));
+    int rem = (int)(i - (long long)c * st.src_h * st.src_w);
+    int ys = rem / st.src_w, xs = rem - ys * st.src_w;
+    int oy = st.tth.start[ys], oyc = st.tth.count[ys];
+    int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
+    const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
+    const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
+    float v = 0.0f;
+    for (int a = 0; a < oyc; ++a) {
+      float h = 0.0f;
+      for (int b = 0; b < oxc; ++b)
+        h += wx[b] * canvas_grad_at(pl, stage, gsum, dgrad, st.can_h, st.can_w, c, st.off_y + oy + a, st.off_x + ox + b);
+      v += wy[a] * h;
+    }
+    if (st.normalise) v = v / st.stdv[c];
+    size_t o = (size_t)c * gsrc_cstride + (size_t)ys * gsrc_rstride + xs;
+    gsrc[o] = accumulate ? (gsrc[o] + v) : v;
+  }
+}
+
+// plain-canvas variants used by the crop (no layout, gradient given in canvas order)
+__global__ void __launch_bounds__(kBlock) k_resize_bwd_plain(DStage st, const float* __restrict__ gcan,
+                                                             float* __restrict__ gsrc, long long gsrc_cstride,
+                                                             int gsrc_rstride) {
+  long long n = 3LL * st.src_h * st.src_w;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i / ((long long)st.src_h * st.src_w));
+    int rem = (int)(i - (long long)c * st.src_h * st.src_w);
+    int ys = rem / st.src_w, xs = rem - ys * st.src_w;
+    int oy = st.tth.start[ys], oyc = st.tth.count[ys];
+    int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
+    const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
+    const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
+    const float* gp = gcan + (size_t)c * st.can_h * st.can_w;
+    float v = 0.0f;
+    for (int a = 0; a < oyc; ++a) {
+      float h = 0.0f;
+      for (int b = 0; b < oxc; ++b) h += wx[b] * gp[(size_t)(oy + a) * st.can_w + ox + b];
+      v += wy[a] * h;
+    }
+    gsrc[(size_t)c * gsrc_cstride + (size_t)ys * gsrc_rstride + xs] = v;
+  }
+}
+
+// ================================================================================ emit
+// out[b, idx] = canvas value of flat index idx (+ sigma * N(0,1)); one thread = 4
+// consecutive flat indices (16-byte coalesced stores), blockIdx.y = slice of the batch.
+__device__ inline float emit_value(const DPlan& pl, const float* __restrict__ ws, long long idx) {
+  for (int k = 0; k < pl.n_emit; ++k) {
+    const DEmit& e = pl.e[k];
+    if (idx >= e.out_begin && idx < e.out_begin + e.out_count) {
+      int c, y, x;
+      emit_inverse(e, idx, c, y, x);
+      return ws[pl.canvas_off[e.stage] + ((size_t)c * e.can_h + y) * e.can_w + x];
+    }
+  }
+  return 0.0f;  // zero tiles (llama32processor.py:344-346, phi3processor.py:232-235)
+}
+
+// NOISE: 0 none, 1 unit-noise tensor supplied, 2 in-kernel Philox
+template <int NOISE>
+__global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restrict__ ws, int batch, int b_per_slice,
+                                                 const float* __restrict__ sigma_dev, const float* __restrict__ unit_noise,
+                                                 unsigned long long seed, unsigned long long offset,
+                                                 float* __restrict__ out) {
+  const long long n = pl.out_numel;
+  const long long n4 = (n + 3) >> 2;
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n4) return;
+  const long long i0 = q << 2;
+  float v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? emit_value(pl, ws, i0 + k) : 0.0f;
+  const float sigma = (NOISE != 0) ? sigma_dev[0] : 0.0f;
+  const int b0 = blockIdx.y * b_per_slice;
+  const int b1 = min(batch, b0 + b_per_slice);
+  const bool vec = ((n & 3) == 0);
+  for (int b = b0; b < b1; ++b) {
+    float o[4] = {v[0], v[1], v[2], v[3]};
+    if (NOISE == 1) {
+      if (vec) {
+        float4 z = *reinterpret_cast<const float4*>(unit_noise + (size_t)b * n + i0);
+        o[0] = v[0] + z.x * sigma; o[1] = v[1] + z.y * sigma; o[2] = v[2] + z.z * sigma; o[3] = v[3] + z.w * sigma;
+      } else {
+        for (int k = 0; k < 4; ++k)
+          if (i0 + k < n) o[k] = v[k] + unit_noise[(size_t)b * n + i0 + k] * sigma;
+      }
+    } else if (NOISE == 2) {
+      float4 z = philox_normal4((unsigned long long)b * (unsigned long long)n4 + (unsigned long long)q, offset, seed);
+      o[0] = v[0] + z.x * sigma; o[1] = v[1] + z.y * sigma; o[2] = v[2] + z.z * sigma; o[3] = v[3] + z.w * sigma;
+    }
+    if (vec) {
+      *reinterpret_cast<float4*>(out + (size_t)b * n + i0) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (i0 + k < n) out[(size_t)b * n + i0 + k] = o[k];
+    }
+  }
+}
+
+// ======================================================================== batch reduce
+// out[i] = sum_b g[b, i].  Block = 64 float4 columns; the 4 waves split the batch and
+// meet in LDS; every wave-level load is 1 KiB contiguous.  Summation order is fixed
+// (b ascending inside a wave, waves 0..3) so the result is bitwise reproducible.
+__device__ inline float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+__device__ inline float4 batch_column_sum(const float* __restrict__ g, int batch, long long n, long long i0,
+                                          int wid, int nw) {
+  float4 a = make_float4(0, 0, 0, 0);
+  int b = wid;
+  // 4 loads in flight per iteration
+  for (; b + 3 * nw < batch; b += 4 * nw) {
+    float4 v0 = *reinterpret_cast<const float4*>(g + (size_t)b * n + i0);
+    float4 v1 = *reinterpret_cast<const float4*>(g + (size_t)(b + nw) * n + i0);
+    float4 v2 = *reinterpret_cast<const float4*>(g + (size_t)(b + 2 * nw) * n + i0);
+    float4 v3 = *reinterpret_cast<const float4*>(g + (size_t)(b + 3 * nw) * n + i0);
+    a = f4add(f4add(f4add(f4add(a, v0), v1), v2), v3);
+  }
+  for (; b < batch; b += nw) a = f4add(a, *reinterpret_cast<const float4*>(g + (size_t)b * n + i0));
+  return a;
+}
+
+__global__ void __launch_bounds__(kBlock) k_batch_reduce(const float* __restrict__ g, int batch, long long n,
+                                                         float* __restrict__ out) {
+  __shared__ float4 part[kBlock / kWave][kWave];
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  const long long q = (long long)blockIdx.x * kWave + lane;  // float4 column
+  const long long n4 = n >> 2;
+  float4 a = make_float4(0, 0, 0, 0);
+  if (q < n4) a = batch_column_sum(g, batch, n, q << 2, wid, kBlock / kWave);
+  part[wid][lane] = a;
+  __syncthreads();
+  if (wid == 0 && q < n4) {
+    float4 t = f4add(f4add(f4add(part[0][lane], part[1][lane]), part[2][lane]), part[3][lane]);
+    *reinterpret_cast<float4*>(out + (q << 2)) = t;
+  }
+  // scalar tail (n not a multiple of 4): last block, first threads
+  if (blockIdx.x == gridDim.x - 1) {
+    long long tail0 = n4 << 2;
+    long long i = tail0 + threadIdx.x;
+    if (i < n) {
+      float s = 0.0f;
+      for (int b = 0; b < batch; ++b) s += g[(size_t)b * n + i];
+      out[i] = s;
+    }
+  }
+}
+
+// rows not 16-byte aligned (n % 4 != 0): one thread per column, test-sized inputs only
+__global__ void __launch_bounds__(kBlock) k_batch_reduce_scalar(const float* __restrict__ g, int batch, long long n,
+                                                                float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float s = 0.0f;
+    for (int b = 0; b < batch; ++b) s += g[(size_t)b * n + i];
+    out[i] = s;
+  }
+}
+
+// ============================================================================== update
+struct OptScalars {
+  int kind, apply;
+  float lr, decay, w1, beta2, w2, bias2_sqrt, eps, neg_step_size;
+};
+
+// torch.optim.AdamW single-tensor arithmetic on one element
+__device__ inline void adamw_element(float& p, float& m, float& v, float g, const OptScalars& o) {
+  p = p * o.decay;                       // param.mul_(1 - lr*wd)
+  m = m + o.w1 * (g - m);                // exp_avg.lerp_(grad, 1-beta1)   (weight < 0.5 form)
+  v = v * o.beta2;                       // exp_avg_sq.mul_(beta2)
+  v = v + (o.w2 * g) * g;                //   .addcmul_(grad, grad, value=1-beta2)
+  float denom = sqrtf(v) / o.bias2_sqrt + o.eps;
+  p = p + o.neg_step_size * (m / denom); // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+__global__ void __launch_bounds__(kBlock) k_update(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                   float* __restrict__ grad, const float* __restrict__ mask,
+                                                   long long n, OptScalars o, double* __restrict__ partials) {
+  double acc[1] = {0.0};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float g = grad[i] * mask[i];          // attack_model.py:336
+    grad[i] = g;
+    acc[0] += (double)g * (double)g;
+    if (o.apply) {
+      if (o.kind == 0) {
+        float pp = p[i], mm = m[i], vv = v[i];
+        adamw_element(pp, mm, vv, g, o);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+      } else {
+        float sg = (g > 0.0f) ? 1.0f : ((g < 0.0f) ? -1.0f : 0.0f);
+        p[i] = p[i] - o.lr * sg;
+      }
+    }
+  }
+  block_sum_store<1>(acc, partials + blockIdx.x);
+}
+
+__global__ void __launch_bounds__(kBlock) k_finalize_norm(const double* __restrict__ partials, int nblk,
+                                                          float* __restrict__ stats) {
+  double acc[1] = {0.0};
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) acc[0] += partials[b];
+  __shared__ double tot[1];
+  block_sum_store<1>(acc, tot);
+  __syncthreads();
+  if (threadIdx.x == 0) stats[7] = (float)sqrt(tot[0]);
+}
+
+// ================================================================= fused (identity plan)
+// LLaVA at native resolution: process() is (s - mean)/std, so the whole forward is one
+// streaming kernel: out[b,i] = (x0[i] + eps*tanh(p[i]) - mean_c)/std_c + sigma*z.
+// blockIdx.y slices the batch; slice 0 also produces the statistics partials.
+template <int NOISE>
+__global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ p, const float* __restrict__ x0,
+                                                      float eps, int plane, float m0, float m1, float m2, float s0,
+                                                      float s1, float s2, int batch, int b_per_slice,
+                                                      const float* __restrict__ stats, const float* __restrict__ unit_noise,
+                                                      unsigned long long seed, unsigned long long offset,
+                                                      float* __restrict__ out, float* __restrict__ s_out,
+                                                      double* __restrict__ partials) {
+  const long long n = 3LL * plane;
+  const long long n4 = n >> 2;  // host guarantees plane % 4 == 0
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
+  if (q < n4) {
+    const long long i0 = q << 2;
+    const int c = (int)(i0 / plane);
+    const float mean = (c == 0) ? m0 : ((c == 1) ? m1 : m2);
+    const float sd = (c == 0) ? s0 : ((c == 1) ? s1 : s2);
+    float4 pp = *reinterpret_cast<const float4*>(p + i0);
+    float4 xx = *reinterpret_cast<const float4*>(x0 + i0);
+    float x[4] = {eps * tanhf(pp.x), eps * tanhf(pp.y), eps * tanhf(pp.z), eps * tanhf(pp.w)};
+    float s[4] = {xx.x + x[0], xx.y + x[1], xx.z + x[2], xx.w + x[3]};
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (s[k] - mean) / sd;
+    if (blockIdx.y == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) stat_accumulate(s[k], x[k], acc);
+      if (s_out != nullptr) *reinterpret_cast<float4*>(s_out + i0) = make_float4(s[0], s[1], s[2], s[3]);
+    }
+    // the sigma of THIS step is the previous step's QERR_STD: k_finalize_image has not run
+    // yet for this step, so read slot QERR_STD (1) directly.
+    const float sigma = (NOISE != 0) ? stats[1] : 0.0f;
+    const int b0 = blockIdx.y * b_per_slice;
+    const int b1 = min(batch, b0 + b_per_slice);
+    for (int b = b0; b < b1; ++b) {
+      float4 o = make_float4(v[0], v[1], v[2], v[3]);
+      if (NOISE == 1) {
+        float4 z = *reinterpret_cast<const float4*>(unit_noise + (size_t)b * n + i0);
+        o = make_float4(v[0] + z.x * sigma, v[1] + z.y * sigma, v[2] + z.z * sigma, v[3] + z.w * sigma);
+      } else if (NOISE == 2) {
+        float4 z = philox_normal4((unsigned long long)b * (unsigned long long)n4 + (unsigned long long)q, offset, seed);
+        o = make_float4(v[0] + z.x * sigma, v[1] + z.y * sigma, v[2] + z.z * sigma, v[3] + z.w * sigma);
+      }
+      *reinterpret_cast<float4*>(out + (size_t)b * n + i0) = o;
+    }
+  }
+  if (blockIdx.y == 0) block_sum_store<kStatSlots>(acc, partials + (size_t)blockIdx.x * kStatSlots);
+}
+
+// backward + update in one pass over grad_out: block = 64 float4 columns (256 pixels);
+// waves split the batch, LDS combines, then thread t owns pixel t of the block:
+// /std, + imgfit', tanh', [mask, ||g||, AdamW | store grad].
+template <bool UPDATE>
+__global__ void __launch_bounds__(kBlock) k_fused_bwd(const float* __restrict__ g, int batch, float* __restrict__ p,
+                                                      const float* __restrict__ x0, float eps, int plane, float s0,
+                                                      float s1, float s2, float c_fit, const float* __restrict__ mask,
+                                                      float* __restrict__ m, float* __restrict__ v,
+                                                      float* __restrict__ grad_p, OptScalars o,
+                                                      double* __restrict__ partials) {
+  __shared__ float4 part4[kBlock / kWave][kWave];
+  const long long n = 3LL * plane;
+  const long long n4 = n >> 2;
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  const long long q = (long long)blockIdx.x * kWave + lane;
+  float4 a = make_float4(0, 0, 0, 0);
+  if (q < n4) a = batch_column_sum(g, batch, n, q << 2, wid, kBlock / kWave);
+  part4[wid][lane] = a;
+  __syncthreads();
+  const float(*part)[kWave * 4] = reinterpret_cast<const float(*)[kWave * 4]>(&part4[0][0]);
+  const long long i = (long long)blockIdx.x * (kWave * 4) + threadIdx.x;
+  double acc[1] = {0.0};
+  if (i < n) {
+    float gs = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+    const int c = (int)(i / plane);
+    const float sd = (c == 0) ? s0 : ((c == 1) ? s1 : s2);
+    float pp = p[i];
+    float t = tanhf(pp);
+    float s = x0[i] + eps * t;
+    float gx = gs / sd + imgfit_grad(s, c_fit);
+    float gp = (gx * eps) * (1.0f - t * t);
+    if (UPDATE) {
+      gp = gp * mask[i];
+      acc[0] = (double)gp * (double)gp;
+      grad_p[i] = gp;
+      if (o.apply) {
+        if (o.kind == 0) {
+          float mm = m[i], vv = v[i];
+          adamw_element(pp, mm, vv, gp, o);
+          p[i] = pp; m[i] = mm; v[i] = vv;
+        } else {
+          float sg = (gp > 0.0f) ? 1.0f : ((gp < 0.0f) ? -1.0f : 0.0f);
+          p[i] = pp - o.lr * sg;
+        }
+      }
+    } else {
+      grad_p[i] = gp;
+    }
+  }
+  if (UPDATE) block_sum_store<1>(acc, partials + blockIdx.x);
+}
+
+// stats finalisation for the fused pair: image statistics + (optionally) the gradient norm
+__global__ void __launch_bounds__(kBlock) k_philox_normal(float* __restrict__ out, long long n,
+                                                          unsigned long long seed, unsigned long long offset) {
+  long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n4 = (n + 3) >> 2;
+  if (q >= n4) return;
+  float4 z = philox_normal4((unsigned long long)q, offset, seed);
+  float zz[4] = {z.x, z.y, z.z, z.w};
+  for (int k = 0; k < 4; ++k)
+    if ((q << 2) + k < n) out[(q << 2) + k] = zz[k];
+}
+
+}  // namespace advx

@@ -1,0 +1,233 @@
+"""torch-facing wrappers over the C ABI (include/advx.h).
+
+torch is plumbing here: it owns device memory and streams; every arithmetic operation of
+the pixel path runs in libadvx_hip.so.  Nothing in this file computes on the CPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise L.AdvxError("advx ops need tensors on a ROCm device (there is no CPU fallback)")
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise L.AdvxError("advx ops take float32 tensors")
+    return t.contiguous()
+
+
+def _stream(t):
+    return L.current_stream(t.device)
+
+
+def _crop_arg(crop):
+    if crop is None:
+        return None, None
+    arr = (C.c_int32 * 4)(*[int(v) for v in crop])
+    return arr, C.cast(arr, C.c_void_p)
+
+
+# ------------------------------------------------------------------- processor level
+def emit(plan, argument, batch, sigma_dev=None, unit_noise=None, philox=None, workspace=None, out=None):
+    """process(argument) -> repeat(batch) -> + sigma*noise   (attack_model.py:314-321).
+
+    philox = (seed, offset) switches on the in-kernel generator; unit_noise is the parity
+    mode (N(0,1) tensor supplied by the caller)."""
+    _require_cuda(argument)
+    argument = _f32c(argument)
+    dev = argument.device
+    if workspace is None:
+        workspace = torch.empty(plan.workspace_floats, dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty((batch, plan.out_numel), dtype=torch.float32, device=dev)
+    seed, offset = (philox if philox is not None else (0, 0))
+    if unit_noise is not None:
+        unit_noise = _f32c(unit_noise)
+        if unit_noise.numel() != batch * plan.out_numel:
+            raise L.AdvxError("unit_noise has the wrong number of elements")
+    L.check(L.load().advx_emit(plan.handle, L.ptr(argument), int(batch), L.ptr(sigma_dev), L.ptr(unit_noise),
+                               int(philox is not None), int(seed), int(offset), L.ptr(out), L.ptr(workspace),
+                               int(workspace.numel()), _stream(argument)), "advx_emit")
+    return out
+
+
+def collect(plan, grad_out, batch, grad_argument=None, accumulate=False, workspace=None):
+    """Backward of `emit`: grad_out [batch, out_numel] -> grad wrt the [3,H,W] argument."""
+    _require_cuda(grad_out)
+    grad_out = _f32c(grad_out)
+    dev = grad_out.device
+    if grad_out.numel() != batch * plan.out_numel:
+        raise L.AdvxError("grad_out has the wrong number of elements")
+    if workspace is None:
+        workspace = torch.empty(plan.workspace_floats, dtype=torch.float32, device=dev)
+    if grad_argument is None:
+        grad_argument = torch.empty((3, plan.in_h, plan.in_w), dtype=torch.float32, device=dev)
+        accumulate = False
+    L.check(L.load().advx_collect(plan.handle, L.ptr(grad_out), int(batch), L.ptr(grad_argument), int(accumulate),
+                                  L.ptr(workspace), int(workspace.numel()), _stream(grad_out)), "advx_collect")
+    return grad_argument
+
+
+class ProcessFunction(torch.autograd.Function):
+    """Differentiable `process(image)` of the plugin API: forward = advx_emit (batch 1, no
+    noise), backward = advx_collect.  Keeps autograd users of the reference API working."""
+
+    @staticmethod
+    def forward(ctx, image, plan):
+        ctx.plan = plan
+        out = emit(plan, image.detach(), 1)
+        return out.view(plan.out_shape)
+
+    @staticmethod
+    def backward(ctx, grad):
+        plan = ctx.plan
+        g = collect(plan, grad.contiguous().view(1, plan.out_numel), 1)
+        return g, None
+
+
+# ----------------------------------------------------------------------- image level
+def image_scratch(H, W, blur_k, device):
+    n = L.load().advx_image_scratch_floats(int(H), int(W), int(blur_k))
+    return torch.empty(int(n), dtype=torch.float32, device=device)
+
+
+def image_fwd(p, x0, epsilon, stats, scratch, blur=None, crop=None, s=None, argument=None):
+    """x = eps*tanh(p) -> [blur] -> s = x0 + x -> [crop+resize] -> argument; statistics into
+    `stats` (attack_model.py:300-312,329,366-373).  blur = (kernel_size, sigma)."""
+    _require_cuda(p, x0, stats, scratch)
+    _, H, W = p.shape
+    if s is None:
+        s = torch.empty_like(p)
+    if crop is not None and argument is None:
+        argument = torch.empty_like(p)
+    k, sig = (blur if blur is not None else (0, 0.0))
+    keep, cptr = _crop_arg(crop)
+    L.check(L.load().advx_image_fwd(L.ptr(p), L.ptr(x0), H, W, float(epsilon), int(k), float(sig), cptr, L.ptr(s),
+                                    L.ptr(argument) if argument is not None else None, L.ptr(stats), L.ptr(scratch),
+                                    _stream(p)), "advx_image_fwd")
+    return s, (argument if argument is not None else s)
+
+
+def image_bwd(p, s, grad_argument, epsilon, imgfit_scale, grad_p, scratch, blur=None, crop=None, accumulate=False):
+    _require_cuda(p, s, grad_argument, grad_p, scratch)
+    _, H, W = p.shape
+    k, sig = (blur if blur is not None else (0, 0.0))
+    keep, cptr = _crop_arg(crop)
+    L.check(L.load().advx_image_bwd(L.ptr(p), L.ptr(s), L.ptr(_f32c(grad_argument)), H, W, float(epsilon), int(k),
+                                    float(sig), cptr, float(imgfit_scale), L.ptr(grad_p), int(accumulate), L.ptr(scratch),
+                                    _stream(p)), "advx_image_bwd")
+    return grad_p
+
+
+def update(p, m, v, grad_p, mask, opt, stats, scratch):
+    _require_cuda(p, grad_p, mask, stats, scratch)
+    L.check(L.load().advx_update(L.ptr(p), L.ptr(m), L.ptr(v), L.ptr(grad_p), L.ptr(mask), p.numel(), C.byref(opt),
+                                 L.ptr(stats), L.ptr(scratch), _stream(p)), "advx_update")
+
+
+def update_scratch(n, device):
+    return torch.empty(int(L.load().advx_update_scratch_floats(int(n))), dtype=torch.float32, device=device)
+
+
+# ----------------------------------------------------------------------------- fused
+def fused_scratch(plan, device):
+    return torch.empty(int(L.load().advx_fused_scratch_floats(plan.handle)), dtype=torch.float32, device=device)
+
+
+def fused_fwd(plan, p, x0, epsilon, batch, stats, scratch, unit_noise=None, philox=None, out=None, s_out=None):
+    _require_cuda(p, x0, stats, scratch)
+    if out is None:
+        out = torch.empty((batch, plan.out_numel), dtype=torch.float32, device=p.device)
+    seed, offset = (philox if philox is not None else (0, 0))
+    L.check(L.load().advx_fused_fwd(plan.handle, L.ptr(p), L.ptr(x0), float(epsilon), int(batch), L.ptr(unit_noise),
+                                    int(philox is not None), int(seed), int(offset), L.ptr(out), L.ptr(s_out),
+                                    L.ptr(stats), L.ptr(scratch), _stream(p)), "advx_fused_fwd")
+    return out
+
+
+def fused_bwd(plan, grad_out, batch, p, x0, epsilon, imgfit_scale, grad_p, scratch, mask=None, m=None, v=None,
+              opt=None, stats=None):
+    _require_cuda(grad_out, p, x0, grad_p, scratch)
+    L.check(L.load().advx_fused_bwd(plan.handle, L.ptr(_f32c(grad_out)), int(batch), L.ptr(p), L.ptr(x0), float(epsilon),
+                                    float(imgfit_scale), L.ptr(mask), L.ptr(m), L.ptr(v), L.ptr(grad_p),
+                                    C.byref(opt) if opt is not None else None, L.ptr(stats), L.ptr(scratch),
+                                    _stream(p)), "advx_fused_bwd")
+
+
+# ------------------------------------------------------------------------ single ops
+def tanh_fwd(p, epsilon):
+    _require_cuda(p)
+    x = torch.empty_like(p)
+    L.check(L.load().advx_tanh_fwd(L.ptr(_f32c(p)), float(epsilon), L.ptr(x), p.numel(), _stream(p)), "advx_tanh_fwd")
+    return x
+
+
+def tanh_bwd(p, grad_x, epsilon):
+    _require_cuda(p, grad_x)
+    g = torch.empty_like(p)
+    L.check(L.load().advx_tanh_bwd(L.ptr(_f32c(p)), L.ptr(_f32c(grad_x)), float(epsilon), L.ptr(g), p.numel(), _stream(p)),
+            "advx_tanh_bwd")
+    return g
+
+
+def blur_fwd(x, kernel_size, sigma):
+    _require_cuda(x)
+    _, H, W = x.shape
+    y = torch.empty_like(x)
+    L.check(L.load().advx_blur_fwd(L.ptr(_f32c(x)), H, W, int(kernel_size), float(sigma), L.ptr(y), _stream(x)), "advx_blur_fwd")
+    return y
+
+
+def blur_bwd(grad_y, kernel_size, sigma):
+    _require_cuda(grad_y)
+    _, H, W = grad_y.shape
+    r = kernel_size // 2
+    scratch = torch.empty(3 * (H + 2 * r) * (W + 2 * r), dtype=torch.float32, device=grad_y.device)
+    g = torch.empty_like(grad_y)
+    L.check(L.load().advx_blur_bwd(L.ptr(_f32c(grad_y)), H, W, int(kernel_size), float(sigma), L.ptr(g), L.ptr(scratch),
+                                   _stream(grad_y)), "advx_blur_bwd")
+    return g
+
+
+def crop_resize_fwd(src, crop):
+    _require_cuda(src)
+    _, H, W = src.shape
+    scratch = torch.empty(int(L.load().advx_crop_scratch_floats(H, W)), dtype=torch.float32, device=src.device)
+    dst = torch.empty_like(src)
+    keep, cptr = _crop_arg(crop)
+    L.check(L.load().advx_crop_resize_fwd(L.ptr(_f32c(src)), H, W, cptr, L.ptr(dst), L.ptr(scratch), _stream(src)),
+            "advx_crop_resize_fwd")
+    return dst
+
+
+def crop_resize_bwd(grad_dst, crop):
+    _require_cuda(grad_dst)
+    _, H, W = grad_dst.shape
+    scratch = torch.empty(int(L.load().advx_crop_scratch_floats(H, W)), dtype=torch.float32, device=grad_dst.device)
+    g = torch.empty_like(grad_dst)
+    keep, cptr = _crop_arg(crop)
+    L.check(L.load().advx_crop_resize_bwd(L.ptr(_f32c(grad_dst)), H, W, cptr, L.ptr(g), L.ptr(scratch), _stream(grad_dst)),
+            "advx_crop_resize_bwd")
+    return g
+
+
+def batch_reduce(g):
+    _require_cuda(g)
+    B = g.shape[0]
+    n = g.numel() // B
+    out = torch.empty(n, dtype=torch.float32, device=g.device)
+    L.check(L.load().advx_batch_reduce(L.ptr(_f32c(g)), B, n, L.ptr(out), _stream(g)), "advx_batch_reduce")
+    return out
+
+
+def philox_normal(n, seed, offset, device):
+    out = torch.empty(int(n), dtype=torch.float32, device=device)
+    L.check(L.load().advx_philox_normal(L.ptr(out), int(n), int(seed), int(offset), L.current_stream(device)),
+            "advx_philox_normal")
+    return out

@@ -1,0 +1,193 @@
+"""PixelPGD: the owned half of one PGD step, driven through the C ABI.
+
+Host-side mirror of the per-step order of `attack_model.py:300-346,366-373` (single model)
+and `crossattack_models.py:329-406,425-432` (several models):
+
+    forward()          p -> x = eps*tanh(p) -> [blur] -> s = x0+x -> [crop] -> per model:
+                       process -> repeat(B) -> + sigma*noise            (HIP)
+    <VLM forward/backward under PyTorch-ROCm - not owned>
+    backward_update()  per model: sum_b, un-tile, /std, resize^T ; crop^T, + imgfit',
+                       blur^T, tanh' -> grad_p ; [all-reduce over the DP group] ;
+                       mask, ||g||, AdamW|sign, StepLR                   (HIP)
+
+All statistics stay on the device (`self.stats`); nothing here synchronises the stream.
+"""
+import math
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+class PixelPGD:
+    def __init__(self, x0, plans, epsilon=0.5, lr=1e-2, sigma0=1e-3, mask=None, scheduler_step_size=100,
+                 scheduler_gamma=1.0, grad_accum_steps=1, blur_kernel=None, model_weights=None, optimizer="adamw",
+                 cross_mode=False, betas=(0.9, 0.999), adam_eps=1e-8, weight_decay=1e-2, seed=0,
+                 process_group=None, allow_fused=True):
+        if not x0.is_cuda:
+            raise L.AdvxError("PixelPGD needs x0 on a ROCm device (there is no CPU fallback)")
+        if not isinstance(plans, (list, tuple)):
+            plans = [plans]
+        self.plans = list(plans)
+        self.x0 = x0.detach().float().contiguous()
+        dev = self.x0.device
+        C, H, W = self.x0.shape
+        for pl in self.plans:
+            if (pl.in_h, pl.in_w) != (H, W):
+                raise L.AdvxError("plan geometry does not match x0")
+        self.H, self.W = H, W
+        self.eps = float(epsilon)
+        self.p = torch.zeros_like(self.x0)                       # attack_model.py:182
+        self.m = torch.zeros_like(self.x0)
+        self.v = torch.zeros_like(self.x0)
+        self.grad = torch.zeros_like(self.x0)
+        self.mask = (torch.ones_like(self.x0) if mask is None else mask.to(dev).float().contiguous())
+        self.stats = torch.zeros(L.STATS_N, dtype=torch.float32, device=dev)
+        self.stats[L.STAT_QERR_STD] = float(sigma0)             # resave_error_std, attack_model.py:261
+        self.s = torch.empty_like(self.x0)
+        self.argument = torch.empty_like(self.x0)
+        self.garg = torch.empty_like(self.x0)
+        self.blur_kernel = blur_kernel
+        self.img_scratch = ops.image_scratch(H, W, blur_kernel or 0, dev)
+        self.upd_scratch = ops.update_scratch(self.p.numel(), dev)
+        self.workspaces = [torch.empty(pl.workspace_floats, dtype=torch.float32, device=dev) for pl in self.plans]
+        self.weights = list(model_weights) if model_weights is not None else [1.0] * len(self.plans)
+        self.opt_kind = {"adamw": L.OPT_ADAMW, "sign": L.OPT_SIGN}[optimizer]
+        self.lr = float(lr)                                     # chained StepLR value (double, like torch)
+        self.step_size, self.gamma = int(scheduler_step_size), float(scheduler_gamma)
+        self.beta1, self.beta2 = float(betas[0]), float(betas[1])
+        self.adam_eps, self.wd = float(adam_eps), float(weight_decay)
+        self.accum = int(grad_accum_steps)
+        self.cross_mode = bool(cross_mode)
+        self.opt_steps = 0
+        self.iteration = 0
+        self.seed = int(seed)
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self.fused = bool(allow_fused and len(self.plans) == 1 and self.plans[0].fused_supported()
+                          and blur_kernel is None)
+        self.fused_scratch = ops.fused_scratch(self.plans[0], dev) if self.fused else None
+        self._last = None
+        for pl in self.plans:
+            pl.upload()
+
+    # ------------------------------------------------------------------ scalars
+    def _opt_scalars(self, apply):
+        o = L.OptScalars()
+        o.kind, o.apply = self.opt_kind, int(apply)
+        t = self.opt_steps + 1
+        lr = self.lr
+        bias1 = 1.0 - self.beta1 ** t
+        bias2 = 1.0 - self.beta2 ** t
+        o.lr = lr
+        o.decay = 1.0 - lr * self.wd
+        o.w1 = 1.0 - self.beta1
+        o.beta2 = self.beta2
+        o.w2 = 1.0 - self.beta2
+        o.bias2_sqrt = bias2 ** 0.5
+        o.eps = self.adam_eps
+        o.neg_step_size = -(lr / bias1)
+        return o
+
+    def _scheduler_step(self):
+        # torch.optim.lr_scheduler.StepLR (chained form): multiply at every step_size-th step
+        self.opt_steps += 1
+        if self.opt_steps % self.step_size == 0:
+            self.lr = self.lr * self.gamma
+
+    def imgfit_scale(self):
+        # single: (CE + img)/accum (attack_model.py:330); cross: img added once per model and
+        # never divided (crossattack_models.py:369).  The DP pre-scale 1/world makes the
+        # SUM all-reduce an average.
+        n = float(len(self.plans)) if self.cross_mode else 1.0 / self.accum
+        return n / self.world
+
+    def loss_scale(self, i=0):
+        """Factor the caller applies to model i's loss before .backward()."""
+        w = self.weights[i] if self.cross_mode else self.weights[i] / self.accum
+        return w / self.world
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, batches, unit_noises=None, blur_sigma=None, crop=None, use_philox=True):
+        if not isinstance(batches, (list, tuple)):
+            batches = [batches] * len(self.plans)
+        if unit_noises is None:
+            unit_noises = [None] * len(self.plans)
+        elif not isinstance(unit_noises, (list, tuple)):
+            unit_noises = [unit_noises]
+        blur = (self.blur_kernel, blur_sigma) if self.blur_kernel is not None else None
+        use_fused = self.fused and crop is None
+        outs = []
+        if use_fused:
+            pl = self.plans[0]
+            ph = None if (unit_noises[0] is not None or not use_philox) else (self.seed, self.iteration)
+            out = ops.fused_fwd(pl, self.p, self.x0, self.eps, batches[0], self.stats, self.fused_scratch,
+                                unit_noise=unit_noises[0], philox=ph, s_out=self.s)
+            outs.append(out.view((batches[0] * pl.out_shape[0],) + pl.out_shape[1:]))
+        else:
+            _, arg = ops.image_fwd(self.p, self.x0, self.eps, self.stats, self.img_scratch, blur=blur, crop=crop,
+                                   s=self.s, argument=self.argument if crop is not None else None)
+            sigma = self.stats[L.STAT_SIGMA:L.STAT_SIGMA + 1]
+            for i, (pl, B, z) in enumerate(zip(self.plans, batches, unit_noises)):
+                ph = None if (z is not None or not use_philox) else (self.seed, self.iteration * len(self.plans) + i)
+                out = ops.emit(pl, arg, B, sigma_dev=sigma, unit_noise=z, philox=ph, workspace=self.workspaces[i])
+                outs.append(out.view((B * pl.out_shape[0],) + pl.out_shape[1:]))
+        self._last = dict(batches=list(batches), blur=blur, crop=crop, fused=use_fused)
+        return outs
+
+    # ----------------------------------------------------------------- backward
+    def backward_update(self, grads):
+        """grads[i] = d(loss)/d(pixel_values_i) as produced by autograd with the loss already
+        multiplied by loss_scale(i)."""
+        if not isinstance(grads, (list, tuple)):
+            grads = [grads]
+        st = self._last
+        if st is None:
+            raise L.AdvxError("backward_update called before forward")
+        take_step = (self.iteration + 1) % self.accum == 0        # attack_model.py:343
+        # accumulate into p.grad across iterations only in the single-model trainer
+        first_of_window = (self.iteration % self.accum == 0)
+        accumulate = (not self.cross_mode) and (not first_of_window)
+        opt = self._opt_scalars(take_step)
+        if st["fused"] and self.world == 1 and not accumulate:
+            ops.fused_bwd(self.plans[0], grads[0], st["batches"][0], self.p, self.x0, self.eps, self.imgfit_scale(),
+                          self.grad, self.fused_scratch, mask=self.mask, m=self.m, v=self.v, opt=opt, stats=self.stats)
+        else:
+            if st["fused"] and not accumulate:
+                ops.fused_bwd(self.plans[0], grads[0], st["batches"][0], self.p, self.x0, self.eps, self.imgfit_scale(),
+                              self.grad, self.fused_scratch)
+            else:
+                for i, (pl, g, B) in enumerate(zip(self.plans, grads, st["batches"])):
+                    ops.collect(pl, g.reshape(B, pl.out_numel), B, grad_argument=self.garg, accumulate=(i > 0),
+                                workspace=self.workspaces[i])
+                ops.image_bwd(self.p, self.s, self.garg, self.eps, self.imgfit_scale(), self.grad, self.img_scratch,
+                              blur=st["blur"], crop=st["crop"], accumulate=accumulate)
+            if self.world > 1 and take_step:
+                # one exchange per optimiser step: the shared image gradient (P_in*4 bytes) over
+                # RCCL/xGMI.  The reduction is linear, so a gradient-accumulation window is
+                # exchanged once, at its end (intermediate grad norms are then rank-local).
+                torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            ops.update(self.p, self.m, self.v, self.grad, self.mask, opt, self.stats, self.upd_scratch)
+        if take_step:
+            self._scheduler_step()
+        self.iteration += 1
+        self._last = None
+        return take_step
+
+    # ------------------------------------------------------------------ readout
+    def stats_dict(self):
+        """Synchronising readout of the device statistics (logging cadence only)."""
+        v = self.stats.tolist()
+        return dict(sigma=v[L.STAT_SIGMA], sigma_next=v[L.STAT_QERR_STD], qerr_mean=v[L.STAT_QERR_MEAN],
+                    qerr_l1=v[L.STAT_QERR_L1], img_loss=v[L.STAT_IMGFIT], x_mean=v[L.STAT_X_MEAN],
+                    x_std=v[L.STAT_X_STD], grad_norm=v[L.STAT_GRAD_NORM])
+
+    def current_lr(self):
+        return self.lr
+
+    def image(self):
+        """x0 + x of the most recent forward (what the reference checkpoints)."""
+        return self.s

@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py - the owned pixel-space hot path of the PGD loop on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): LLaVA-1.5 processor geometry, synthetic 336x336x3
+image, 64-prompt batch PER GPU, tanh-clamp attack, in-kernel Philox noise, masked AdamW.
+One step = fused forward (p -> 64 noisy pixel_values) -> [the VLM is not owned: its
+backward is replaced by a fixed synthetic upstream gradient g ~ N(0,1) resident in HBM]
+-> fused backward (sum over the batch, /std, image-fit term, tanh', mask, AdamW) ->
+quantise-error statistics.  With N > 1 every rank owns 64 prompts (weak scaling) and the
+shared image gradient (1.355 MB) is all-reduced once per step over RCCL.
+
+`value` = prompts * steps / s over all ranks.  The VLM forward/backward (PyTorch-ROCm,
+~1e15 FLOP per 64-prompt step) is NOT inside this number - see DESIGN.md "Measurement".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+H = W = 336
+BATCH = 64
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(seconds_budget=15.0):
+    """The oracle (torch-CPU restatement of the reference's step, 'port') on host cores."""
+    from oracle.pgd import PGDOracle
+    from oracle.processors import LlavaOracle
+    threads = max(1, min(os.cpu_count() or 1, 16))
+    torch.set_num_threads(threads)
+    gen = torch.Generator().manual_seed(0)
+    x0 = torch.rand(3, H, W, generator=gen)
+    g = torch.randn(BATCH, 3, H, W, generator=gen)
+    ora = PGDOracle(x0, [LlavaOracle(H, W)], lr=1e-2)
+
+    def step():
+        z = torch.randn(BATCH, 3, H, W)          # the reference draws randn_like every step
+        ora.forward(BATCH, [z])
+        ora.backward_update([g])
+
+    for _ in range(2):
+        step()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds_budget or n >= 200:
+            break
+    return dict(value=round(n * BATCH / dt, 2), unit="prompt-steps/s", cores=threads, kind="port",
+                sample=f"{n} steps of the same workload (336x336x3, B=64), {dt:.1f} s", steps_per_s=round(n / dt, 3))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused", action="store_true", help="time the generic (unfused) kernel chain instead")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+        pg = torch.distributed.group.WORLD
+
+    from adversarialvlm_amd.build import build_library
+    build_library()
+    from adversarialvlm_amd.pgd import PixelPGD
+    from adversarialvlm_amd.plan import Plan
+
+    gen = torch.Generator().manual_seed(0)
+    x0 = torch.rand(3, H, W, generator=gen).to(dev)
+    g = torch.randn(BATCH, 3, H, W, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+    plan = Plan.llava(H, W)
+    eng = PixelPGD(x0, [plan], epsilon=0.5, lr=1e-2, sigma0=1e-3, seed=1234 + rank, process_group=pg,
+                   allow_fused=not args.no_fused)
+    # every rank pre-scales its share so that the SUM all-reduce is the DP average
+    gs = g * eng.loss_scale(0)
+
+    def step():
+        eng.forward(BATCH)
+        eng.backward_update([gs])
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # per-kernel durations of the two B*P_out movers, HIP events on the launch stream
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(min(args.steps, 200))]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        if k < len(ev):
+            ev[k][0].record()
+            eng.forward(BATCH)
+            ev[k][1].record()
+            eng.backward_update([gs])
+            ev[k][2].record()
+        else:
+            step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    fwd_ms = sorted(e[0].elapsed_time(e[1]) for e in ev)
+    bwd_ms = sorted(e[1].elapsed_time(e[2]) for e in ev)
+    fwd_avg = sum(fwd_ms) / len(fwd_ms)
+    bwd_avg = sum(bwd_ms) / len(bwd_ms)
+
+    n_in = 3 * H * W
+    bytes_fwd = 4 * (BATCH * n_in + 2 * n_in)          # write B*P_out, read p,x0
+    bytes_bwd = 4 * (BATCH * n_in + 8 * n_in)          # read B*P_out; p,x0,mask,m,v in; p,m,v(+grad) out
+    bytes_step = 4 * (2 * BATCH * n_in + 10 * n_in)
+    steps_per_s = args.steps / dt
+    dom_name, dom_bytes, dom_ms = (("k_fused_fwd", bytes_fwd, fwd_avg) if fwd_avg >= bwd_avg
+                                   else ("k_fused_bwd", bytes_bwd, bwd_avg))
+    if args.no_fused:
+        dom_name = "generic chain (" + dom_name.replace("k_fused_", "") + " half)"
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    if rank == 0:
+        line = {
+            "metric": "adversarial PGD steps/sec x prompt-batch, LLaVA-1.5-7B pixel path at 1/2/4/8 MI355X",
+            "value": round(steps_per_s * BATCH * world, 1),
+            "unit": "prompt-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "LLaVA-1.5 tanh-clamp attack, 336x336x3 image, 64-prompt batch per GPU, "
+                                   "owned pixel path isolated (synthetic upstream gradient in HBM; VLM fwd/bwd not included)",
+                       "prompts_per_gpu": BATCH, "global_prompts": BATCH * world, "image": [3, H, W],
+                       "noise": "in-kernel Philox4x32-10", "optimizer": "AdamW", "parallelism": f"dp{world}",
+                       "path": "generic" if args.no_fused else "fused"},
+            "steps_per_s": round(steps_per_s, 1),
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 5),
+                         "fwd_call_ms": round(fwd_avg, 5), "bwd_call_ms": round(bwd_avg, 5),
+                         "step_algorithmic_bytes": bytes_step,
+                         "step_frac_of_hbm_peak": round(bytes_step * steps_per_s / 1e9 / HBM_PEAK_GBS, 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,230 @@
+/* advx.h - C ABI of libadvx_hip.so: the pixel-space hot path of the universal
+ * adversarial-image PGD loop as hand-written CDNA4 (gfx950) HIP kernels.
+ *
+ * The reference (FusionBrainLab/AdversarialVLM) has no FFI of its own: its boundary is the
+ * Python plugin API (src/processors/__init__.py:49-76, abstract_processor.py:91-208) and
+ * everything below it is stock torch.  This header is the boundary a replacement of that
+ * torch arithmetic binds to; each entry point cites the reference lines it replaces.
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every function returns int32: 0 = ok, negative = ADVX_E_*; advx_last_error() gives
+ *    the thread-local message.  Nothing throws across the ABI.
+ *  - all data pointers are CALLER-OWNED DEVICE pointers to contiguous float32 unless
+ *    stated otherwise (tensor.data_ptr()).  The library allocates device memory only
+ *    inside opaque plans (tap/index tables of one geometry).
+ *  - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); launches are
+ *    asynchronous, never synchronise, and are safe to capture in a hipGraph once the plan
+ *    has been uploaded (advx_plan_upload).
+ *  - image tensors are CHW, 3 channels; "stats" is a device float[ADVX_STATS_N].
+ */
+#ifndef ADVX_H
+#define ADVX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADVX_VERSION 100 /* 0.1.0 */
+
+#define ADVX_OK 0
+#define ADVX_E_BADARG (-1)
+#define ADVX_E_SHAPE (-2)
+#define ADVX_E_HIP (-3)
+#define ADVX_E_UNSUPPORTED (-4)
+
+/* processor kinds = the reference's four differentiable processors */
+#define ADVX_KIND_LLAVA 0   /* llavaprocessor.py:134-149   */
+#define ADVX_KIND_MLLAMA 1  /* llama32processor.py:219-405 */
+#define ADVX_KIND_PHI3 2    /* phi3processor.py:107-250    */
+#define ADVX_KIND_QWEN2VL 3 /* qwen2VLprocessor.py:121-272 */
+
+/* resampling modes (ATen F.interpolate semantics) */
+#define ADVX_MODE_AA_BILINEAR 0
+#define ADVX_MODE_BILINEAR 1
+#define ADVX_MODE_BICUBIC 2
+
+/* slots of the device-side stats vector */
+#define ADVX_STAT_SIGMA 0      /* noise sigma used by the NEXT emit (= previous step's QERR_STD) */
+#define ADVX_STAT_QERR_STD 1   /* std_unbiased(|q - s|)   attack_model.py:373 */
+#define ADVX_STAT_QERR_MEAN 2  /* mean(|q - s|)           attack_model.py:389 */
+#define ADVX_STAT_QERR_L1 3    /* sum(|q - s|)            attack_model.py:391 */
+#define ADVX_STAT_IMGFIT 4     /* image_fit_loss          attack_model.py:86-106 */
+#define ADVX_STAT_X_MEAN 5     /* x.mean()                attack_model.py:386 */
+#define ADVX_STAT_X_STD 6      /* x.std()                 attack_model.py:387 */
+#define ADVX_STAT_GRAD_NORM 7  /* ||p.grad * mask||_2     attack_model.py:340 */
+#define ADVX_STATS_N 16
+
+#define ADVX_OPT_ADAMW 0 /* torch.optim.AdamW, attack_model.py:184 */
+#define ADVX_OPT_SIGN 1  /* p -= lr*sign(g): PGD-style variant named by the north star (not in the reference) */
+
+typedef struct advx_plan advx_plan;
+
+typedef struct advx_plan_desc {
+  int32_t kind;     /* ADVX_KIND_* */
+  int32_t in_h;     /* native image height H */
+  int32_t in_w;     /* native image width  W */
+  /* kind-specific integers:
+   *  LLAVA  : a0 = crop_size.height, a1 = crop_size.width
+   *  MLLAMA : a0 = tile size, a1 = max_image_tiles
+   *  PHI3   : a0 = num_crops
+   *  QWEN2VL: a0 = patch_size, a1 = merge_size, a2 = temporal_patch_size,
+   *           a3 = min_pixels, a4 = max_pixels */
+  int64_t a0, a1, a2, a3, a4;
+  float mean[3];    /* image_mean */
+  float std[3];     /* image_std  */
+} advx_plan_desc;
+
+#define ADVX_MAX_STAGES 2
+
+typedef struct advx_stage_info {
+  int32_t mode;           /* ADVX_MODE_* */
+  int32_t src;            /* 0 = input image, k>0 = canvas of stage k-1 */
+  int32_t src_h, src_w;   /* source size */
+  int32_t res_h, res_w;   /* resized size */
+  int32_t can_h, can_w;   /* canvas (padded) size */
+  int32_t off_y, off_x;   /* position of the resized image inside the canvas */
+  float pad_value;        /* constant written outside the resized image (before normalise) */
+  int32_t normalise;      /* 1: (v-mean)/std applied after padding */
+  int32_t inner_axis_h;   /* 1: the inner (first) 1-D pass runs along H (phi3 transposed frame) */
+} advx_stage_info;
+
+typedef struct advx_plan_info {
+  int32_t kind, in_h, in_w;
+  int32_t out_rank;
+  int64_t out_shape[6];     /* shape of ONE sample's pixel_values as the reference returns it */
+  int64_t out_numel;        /* product of out_shape */
+  int32_t n_stage;
+  advx_stage_info stage[ADVX_MAX_STAGES];
+  int32_t tiles_h, tiles_w; /* MLLAMA / PHI3 local tile arrangement */
+  int32_t num_tiles;        /* MLLAMA: real tiles; PHI3: 1 + local tiles; QWEN: grid_h*grid_w */
+  int32_t grid_h, grid_w;   /* QWEN patch grid */
+  int32_t image_h, image_w; /* PHI3 image_sizes[0] */
+  int32_t num_img_tokens;   /* PHI3 (phi3processor.py:244) */
+  int32_t aspect_ratio_id;  /* MLLAMA (1-based id of the tile arrangement) */
+  int64_t workspace_floats; /* floats of scratch advx_emit / advx_collect need */
+} advx_plan_info;
+
+/* ---------------------------------------------------------------- library */
+int32_t advx_version(void);
+const char* advx_last_error(void);
+
+/* ------------------------------------------------------------------ plans
+ * A plan holds the integer geometry and the float32 tap tables of one
+ * (H, W) -> processor layout, computed on the HOST exactly as ATen / the reference do
+ * (llama32processor.py:255-279, qwen2VLprocessor.py:176-197, phi3processor.py:173-216).
+ * Creation needs no GPU; advx_plan_upload copies the tables to the current device. */
+int32_t advx_plan_create(const advx_plan_desc* desc, advx_plan** out);
+int32_t advx_plan_destroy(advx_plan* plan);
+int32_t advx_plan_describe(const advx_plan* plan, advx_plan_info* info);
+int32_t advx_plan_upload(advx_plan* plan, void* stream);
+/* Host copy of one tap table (tests). transposed=0: per OUTPUT index the taps into the
+ * source; transposed=1: per SOURCE index the taps into the output (backward gather).
+ * Call with start=NULL to query n / stride only. axis: 0 = H, 1 = W. */
+int32_t advx_plan_taps(const advx_plan* plan, int32_t stage, int32_t axis, int32_t transposed,
+                       int32_t* n, int32_t* stride, int32_t* start, int32_t* count, float* weight);
+/* Host evaluation of the layout map (tests): flat output indices that canvas element
+ * (c, y, x) of `stage` is written to; returns how many (0, 1 or 2) in *n_idx. */
+int32_t advx_plan_out_index(const advx_plan* plan, int32_t stage, int32_t c, int32_t y, int32_t x,
+                            int32_t* n_idx, int64_t idx[2]);
+/* Host tap computation for an arbitrary 1-D resize (tests; also the crop window's tables). */
+int32_t advx_taps_compute(int32_t mode, int32_t in_size, int32_t out_size, int32_t transposed,
+                          int32_t* n, int32_t* stride, int32_t* start, int32_t* count, float* weight);
+
+/* ------------------------------------------------ processor level (plugin API)
+ * advx_emit  = Differentiable*ImageProcessor.process() + `repeat(B,..)` + `randn*sigma`
+ *              (attack_model.py:314-321): argument [3,H,W] -> out [B, out_numel].
+ *   unit_noise : optional N(0,1) tensor [B, out_numel] (parity mode); if NULL and
+ *                use_philox != 0 the noise is generated in-kernel (Philox4x32-10 +
+ *                Box-Muller, keyed by seed/offset); if both are off no noise is added.
+ *   sigma_dev  : device pointer to the noise sigma (stats + ADVX_STAT_SIGMA), may be NULL
+ *                when no noise is requested.
+ * advx_collect = backward of the above: grad_out [B, out_numel] -> grad_argument [3,H,W]
+ *              (sum over B, un-tile, /std, drop padding, transposed resize).
+ *   accumulate != 0 adds into grad_argument instead of overwriting. */
+int32_t advx_emit(advx_plan* plan, const float* argument, int32_t batch, const float* sigma_dev,
+                  const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset,
+                  float* out, float* workspace, int64_t workspace_floats, void* stream);
+int32_t advx_collect(advx_plan* plan, const float* grad_out, int32_t batch, float* grad_argument,
+                     int32_t accumulate, float* workspace, int64_t workspace_floats, void* stream);
+
+/* ---------------------------------------------------- image level (trainer)
+ * advx_image_fwd : attack_model.py:300-312,329,366-373,386-391
+ *     x = eps*tanh(p) ; optional Gaussian blur (kernel k, sigma) ; s = x0 + x ;
+ *     optional random-resized-crop window (i,j,h,w) resized back to (H,W) -> argument.
+ *     Also reduces image_fit_loss, the quantise-error statistics and x mean/std into
+ *     `stats`, and rotates stats[SIGMA] <- old stats[QERR_STD] before overwriting it.
+ *     blur_k = 0 disables blur; crop = NULL disables the crop (then argument may alias s).
+ *   scratch: float[advx_image_scratch_floats(H,W,blur_k)].
+ * advx_image_bwd : the autograd of the above (attack_model.py:332): grad_argument ->
+ *     grad wrt p, plus imgfit_scale * d(image_fit_loss)/dp; written (or accumulated)
+ *     into grad_p UNMASKED (the mask is applied by advx_update, attack_model.py:336). */
+int64_t advx_image_scratch_floats(int32_t H, int32_t W, int32_t blur_k);
+int32_t advx_image_fwd(const float* p, const float* x0, int32_t H, int32_t W, float epsilon,
+                       int32_t blur_k, float blur_sigma, const int32_t* crop_ijhw,
+                       float* s, float* argument, float* stats, float* scratch, void* stream);
+int32_t advx_image_bwd(const float* p, const float* s, const float* grad_argument, int32_t H, int32_t W,
+                       float epsilon, int32_t blur_k, float blur_sigma, const int32_t* crop_ijhw,
+                       float imgfit_scale, float* grad_p, int32_t accumulate,
+                       float* scratch, void* stream);
+
+/* advx_update : attack_model.py:335-346 : g = grad_p * mask ; ||g|| -> stats ; optimiser.
+ *   ADAMW follows torch.optim.AdamW's single-tensor arithmetic with the scalars the host
+ *   derives in double exactly like torch (decay = 1-lr*wd, step_size = lr/(1-b1^t), ...).
+ *   apply = 0 only masks + measures the norm (gradient-accumulation iterations). */
+typedef struct advx_opt_scalars {
+  int32_t kind;         /* ADVX_OPT_* */
+  int32_t apply;        /* 1 = take the optimiser step */
+  float lr;             /* SIGN: step length */
+  float decay;          /* ADAMW: 1 - lr*weight_decay */
+  float w1;             /* ADAMW: 1 - beta1 (lerp weight) */
+  float beta2;          /* ADAMW */
+  float w2;             /* ADAMW: 1 - beta2 */
+  float bias2_sqrt;     /* ADAMW: sqrt(1 - beta2^t) */
+  float eps;            /* ADAMW */
+  float neg_step_size;  /* ADAMW: -(lr / (1 - beta1^t)) */
+} advx_opt_scalars;
+int32_t advx_update(float* p, float* m, float* v, float* grad_p, const float* mask, int64_t n,
+                    const advx_opt_scalars* opt, float* stats, float* scratch, void* stream);
+int64_t advx_update_scratch_floats(int64_t n);
+
+/* ------------------------------------------- fused fast path (headline config)
+ * One call = the whole owned step of attack_model.py:300-346,366-373 for a plan whose
+ * resize is the identity (LLaVA at native 336x336), no blur, no crop:
+ *   advx_fused_fwd : p,x0 -> out[B, 3*H*W] = (x0+eps*tanh(p)-mean)/std + sigma*noise ; stats
+ *   advx_fused_bwd : grad_out[B,3*H*W] -> sum_b, /std, +imgfit', tanh', (mask, AdamW | grad only)
+ * With world_size > 1 call advx_fused_bwd with opt = NULL (writes grad_p only), all-reduce
+ * grad_p, then advx_update. */
+int32_t advx_fused_supported(const advx_plan* plan);
+int32_t advx_fused_fwd(advx_plan* plan, const float* p, const float* x0, float epsilon, int32_t batch,
+                       const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset,
+                       float* out, float* s_out /* nullable: x0+eps*tanh(p), [3,H,W] */, float* stats,
+                       float* scratch, void* stream);
+int32_t advx_fused_bwd(advx_plan* plan, const float* grad_out, int32_t batch, float* p, const float* x0,
+                       float epsilon, float imgfit_scale, const float* mask, float* m, float* v,
+                       float* grad_p, const advx_opt_scalars* opt, float* stats, float* scratch,
+                       void* stream);
+int64_t advx_fused_scratch_floats(const advx_plan* plan);
+
+/* ------------------------------------------------- single ops (unit tests)
+ * Same kernels the calls above launch, exposed one by one. */
+int32_t advx_tanh_fwd(const float* p, float epsilon, float* x, int64_t n, void* stream);
+int32_t advx_tanh_bwd(const float* p, const float* grad_x, float epsilon, float* grad_p, int64_t n, void* stream);
+int32_t advx_blur_fwd(const float* x, int32_t H, int32_t W, int32_t k, float sigma, float* y, void* stream);
+int32_t advx_blur_bwd(const float* grad_y, int32_t H, int32_t W, int32_t k, float sigma, float* grad_x,
+                      float* scratch /* float[3*(H+2r)*(W+2r)] */, void* stream);
+int32_t advx_crop_resize_fwd(const float* src, int32_t H, int32_t W, const int32_t* crop_ijhw, float* dst,
+                             float* scratch, void* stream);
+int32_t advx_crop_resize_bwd(const float* grad_dst, int32_t H, int32_t W, const int32_t* crop_ijhw,
+                             float* grad_src, float* scratch, void* stream);
+int64_t advx_crop_scratch_floats(int32_t H, int32_t W);
+int32_t advx_batch_reduce(const float* g, int32_t batch, int64_t n, float* out, void* stream);
+int32_t advx_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADVX_H */

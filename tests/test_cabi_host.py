@@ -1,0 +1,174 @@
+"""CPU tier: the C-ABI library loads without a GPU, exports every symbol include/advx.h
+declares, and its HOST logic (integer geometry, tap tables, layout index maps) is
+bit-exact against the oracle and the fixtures.  No compute entry point is called here."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st
+
+from conftest import ROOT, load_golden
+from oracle import geometry as G
+from oracle import resample as R
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from adversarialvlm_amd.build import build_library
+    build_library()
+    from adversarialvlm_amd import _lib
+    return _lib.load()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "advx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(advx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(lib):
+    from adversarialvlm_amd import _lib
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (advx_[a-z0-9_]+)", out))
+    assert set(declared) <= exported, sorted(set(declared) - exported)
+    assert set(declared) == set(_lib.SIGNATURES), "ctypes table and header disagree"
+    assert lib.advx_version() >= 100
+
+
+def test_product_path_has_no_cpu_fallback():
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd._lib import AdvxError
+    with pytest.raises(AdvxError):
+        ops.tanh_fwd(torch.zeros(3, 4, 4), 0.5)          # CPU tensor: must fail loudly
+    # and nothing under the package imports the oracle
+    pkg = os.path.join(ROOT, "adversarialvlm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_error_reporting(lib):
+    from adversarialvlm_amd._lib import AdvxError
+    from adversarialvlm_amd.plan import Plan
+    with pytest.raises(AdvxError, match="unknown kind"):
+        Plan(99, 10, 10)
+    with pytest.raises(AdvxError, match="size out of range"):
+        Plan.llava(0, 10)
+    with pytest.raises(AdvxError):
+        Plan.qwen2vl(336, 336, patch=0)
+
+
+def test_mllama_geometry_bit_exact(lib):
+    from adversarialvlm_amd.plan import Plan
+    g = load_golden("mllama_helpers.npz")
+    for h, w, mt, ts, ch, cw, nh, nw in g["geometry"]:
+        p = Plan.mllama(int(h), int(w), tile=int(ts), max_tiles=int(mt))
+        s = p.stage(0)
+        assert (s.can_h, s.can_w, s.res_h, s.res_w) == (int(ch), int(cw), int(nh), int(nw))
+        assert p.info.aspect_ratio_id == G.mllama_aspect_ratio_id(int(ch) // int(ts), int(cw) // int(ts), int(mt))
+        assert p.out_shape == (1, 1, int(mt), 3, int(ts), int(ts))
+
+
+def test_qwen_geometry_bit_exact(lib):
+    from adversarialvlm_amd.plan import Plan
+    g = load_golden("qwen2vl_reference.npz")
+    for h, w, hb, wb in g["geometry"]:
+        p = Plan.qwen2vl(int(h), int(w))
+        assert (p.stage(0).res_h, p.stage(0).res_w) == (int(hb), int(wb))
+        assert p.out_shape == ((int(hb) // 14) * (int(wb) // 14), 1176)
+        assert p.info.num_tiles == (int(hb) // 14) * (int(wb) // 14)
+
+
+def test_phi3_geometry_bit_exact(lib):
+    from adversarialvlm_amd.plan import Plan
+    g = load_golden("phi3_reference.npz")
+    for h, w, oh, ow, ntok in g["geometry"]:
+        p = Plan.phi3(int(h), int(w))
+        assert (p.info.image_h, p.info.image_w, p.info.num_img_tokens) == (int(oh), int(ow), int(ntok))
+        assert p.out_shape == (1, 7, 3, 336, 336)
+
+
+@settings(max_examples=150, deadline=None)
+@given(h=st.integers(8, 2400), w=st.integers(8, 2400))
+def test_geometry_property_vs_oracle(lib, h, w):
+    from adversarialvlm_amd.plan import Plan
+    nh, nw, th, tw = G.mllama_geometry(h, w)
+    s = Plan.mllama(h, w).stage(0)
+    assert (s.res_h, s.res_w, s.can_h // 560, s.can_w // 560) == (nh, nw, th, tw)
+    q = Plan.qwen2vl(h, w).stage(0)
+    assert (q.res_h, q.res_w) == G.qwen_smart_resize(h, w)
+    g = G.phi3_hd_geometry(h, w, 6)
+    if g["out_h"] % 336 == 0 and g["out_w"] % 336 == 0 and 1 <= (g["out_h"] // 336) * (g["out_w"] // 336) <= 6:
+        f = Plan.phi3(h, w)
+        assert (f.info.image_h, f.info.image_w) == (g["out_h"], g["out_w"])
+        assert f.info.num_img_tokens == G.phi3_num_img_tokens(g["out_h"], g["out_w"])
+        a = f.stage(0)
+        if g["trans"]:
+            assert (a.res_h, a.res_w, a.off_y, a.off_x) == (g["new_w"], g["new_h"], 0, g["pad_top"])
+        else:
+            assert (a.res_h, a.res_w, a.off_y, a.off_x) == (g["new_h"], g["new_w"], g["pad_top"], 0)
+
+
+ORACLE_TAPS = {0: R.aa_bilinear_taps, 1: R.bilinear_taps, 2: R.bicubic_taps}
+
+
+@settings(max_examples=120, deadline=None)
+@given(mode=st.integers(0, 2), n=st.integers(2, 700), m=st.integers(2, 700))
+def test_tap_tables_bit_exact_vs_oracle(lib, mode, n, m):
+    """fp32 tap tables computed by the library's host code == the oracle's restatement of
+    ATen (which tests/test_oracle_resample.py pins to F.interpolate), bit for bit."""
+    from adversarialvlm_amd.plan import taps_compute
+    s, c, w = taps_compute(mode, n, m)
+    so, co, wo = ORACLE_TAPS[mode](n, m)
+    k = min(w.shape[1], wo.shape[1])
+    assert np.array_equal(s, so) and np.array_equal(c, co)
+    assert np.array_equal(w[:, :k], wo[:, :k])
+    assert not w[:, k:].any() and not wo[:, k:].any()
+    ts, tc, tw = taps_compute(mode, n, m, transposed=True)
+    assert np.array_equal(R.taps_to_matrix((ts, tc, tw), m), R.taps_to_matrix((s, c, w), n).T)
+
+
+def test_layout_index_maps_vs_reference_permutes(lib):
+    """Tile / patch index maps are integer-exact against the reshape-permute-reshape of the
+    reference (llama32processor.py:326-332, phi3processor.py:227, qwen2VLprocessor.py:249-267)."""
+    from adversarialvlm_amd.plan import Plan
+    rng = np.random.default_rng(0)
+    # qwen
+    p = Plan.qwen2vl(60, 90, min_pixels=28 * 28 * 4, max_pixels=28 * 28 * 64)
+    sg = p.stage(0)
+    for _ in range(300):
+        c, y, x = int(rng.integers(3)), int(rng.integers(sg.can_h)), int(rng.integers(sg.can_w))
+        idx = p.out_index(0, c, y, x)
+        want = []
+        for t in range(2):
+            r, col = G.qwen_patch_index(c, t, y, x, p.info.grid_w)
+            want.append(r * 1176 + col)
+        assert idx == want
+    # mllama tiles: emulate split_to_tiles on an index canvas
+    p = Plan.mllama(1352, 1988)
+    sg = p.stage(0)
+    th, tw = sg.can_h // 560, sg.can_w // 560
+    canvas = torch.arange(3 * sg.can_h * sg.can_w).reshape(3, sg.can_h, sg.can_w)
+    tiles = canvas.reshape(3, th, 560, tw, 560).permute(1, 3, 0, 2, 4).reshape(-1)
+    for _ in range(300):
+        c, y, x = int(rng.integers(3)), int(rng.integers(sg.can_h)), int(rng.integers(sg.can_w))
+        (i,) = p.out_index(0, c, y, x)
+        assert int(tiles[i]) == int(canvas[c, y, x])
+    # phi3: global view is tile 0 (stage 1), local tiles follow (stage 0)
+    p = Plan.phi3(300, 500)
+    sg = p.stage(0)
+    canvas = torch.arange(3 * sg.can_h * sg.can_w).reshape(3, sg.can_h, sg.can_w)
+    local = canvas.reshape(1, 3, sg.can_h // 336, 336, sg.can_w // 336, 336).permute(0, 2, 4, 1, 3, 5).reshape(-1)
+    T = 3 * 336 * 336
+    for _ in range(300):
+        c, y, x = int(rng.integers(3)), int(rng.integers(sg.can_h)), int(rng.integers(sg.can_w))
+        (i,) = p.out_index(0, c, y, x)
+        assert i >= T and int(local[i - T]) == int(canvas[c, y, x])
+    assert p.out_index(1, 2, 335, 335) == [T - 1]

@@ -1,0 +1,145 @@
+"""GPU tier: multi-step PGD trajectories of the HIP engine (PixelPGD, through the C ABI)
+against the CPU oracle (oracle/pgd.py) on identical inputs: noise, blur sigma and crop
+window are passed to both.  Bar: p, grad, sigma within 1e-4 relative (north star)."""
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import pixel_ops as P
+from oracle.pgd import PGDOracle
+from oracle.processors import LlavaOracle, MllamaOracle, Phi3Oracle, Qwen2VLOracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _plans():
+    from adversarialvlm_amd.plan import Plan
+    return Plan
+
+
+def _trajectory(dev, x0, oracles, plans, batches, steps, blur_kernel=None, crop_fn=None, blur_sigma_fn=None,
+                mask=None, accum=1, weights=None, cross=False, optimizer="adamw", fused=True, gamma=1.0, step_size=100,
+                lr=1e-2):
+    from adversarialvlm_amd.pgd import PixelPGD
+    ora = PGDOracle(x0, oracles, lr=lr, mask=mask, grad_accum_steps=accum, blur_kernel=blur_kernel, model_weights=weights,
+                    cross_mode=cross, optimizer=optimizer, scheduler_gamma=gamma, scheduler_step_size=step_size)
+    eng = PixelPGD(x0.to(dev), plans, lr=lr, mask=None if mask is None else mask.to(dev), grad_accum_steps=accum,
+                   blur_kernel=blur_kernel, model_weights=weights, cross_mode=cross, optimizer=optimizer,
+                   allow_fused=fused, scheduler_gamma=gamma, scheduler_step_size=step_size)
+    worst = {}
+
+    def upd(k, v):
+        worst[k] = max(worst.get(k, 0.0), v)
+
+    gen = torch.Generator().manual_seed(11)
+    for t in range(steps):
+        crop = crop_fn(t) if crop_fn else None
+        bs = blur_sigma_fn(t) if blur_sigma_fn else None
+        # shapes of the per-model pixel_values
+        shapes = [(B * pl.out_shape[0],) + pl.out_shape[1:] for pl, B in zip(plans, batches)]
+        zs = [torch.randn(s, generator=gen) for s in shapes]
+        gs = [torch.randn(s, generator=gen) * 0.01 for s in shapes]
+        pv_ref = ora.forward(batches, zs, blur_sigma=bs, crop=crop)
+        pv = eng.forward(batches, [z.to(dev) for z in zs], blur_sigma=bs, crop=crop)
+        for a, b in zip(pv, pv_ref):
+            assert tuple(a.shape) == tuple(b.shape)
+            upd("pixel_values", rel_err(a.cpu(), b))
+        # the oracle differentiates weight_i * <pv_i, g_i> (/accum in single mode); the engine
+        # receives what autograd would hand over: g_i * loss_scale(i)
+        ref = ora.backward_update(gs)
+        eng.backward_update([g.to(dev) * eng.loss_scale(i) for i, g in enumerate(gs)])
+        st = eng.stats_dict()
+        upd("grad", rel_err(eng.grad.cpu(), ref["grad"]))
+        upd("p", rel_err(eng.p.cpu(), ora.p.detach()) if ora.p.detach().abs().max() > 0 else 0.0)
+        upd("sigma", abs(st["sigma_next"] - ref["sigma_next"]) / max(ref["sigma_next"], 1e-12))
+        upd("imgfit", abs(st["img_loss"] - ref["img_loss"]) / max(ref["img_loss"], 1e-12))
+        upd("grad_norm", abs(st["grad_norm"] - ref["grad_norm"]) / max(ref["grad_norm"], 1e-12))
+        upd("qerr_mean", abs(st["qerr_mean"] - ref["qerr_mean"]) / max(ref["qerr_mean"], 1e-12))
+        upd("x_std", abs(st["x_std"] - ref["x_std"]) / max(ref["x_std"], 1e-12) if ref["x_std"] > 0 else 0.0)
+        assert eng.current_lr() == pytest.approx(ora.current_lr(), rel=1e-12)
+        upd("s", rel_err(eng.image().cpu(), ref["s"]))
+    for k, v in worst.items():
+        assert v < TOL, (k, v, worst)
+    return worst
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_llava_identity_headline_small(dev, fused):
+    Plan = _plans()
+    torch.manual_seed(0)
+    x0 = torch.rand(3, 64, 64) * 1.2 - 0.1
+    _trajectory(dev, x0, [LlavaOracle(64, 64)], [Plan.llava(64, 64, 64, 64)], [4], 5, fused=fused)
+
+
+def test_llava_336_batch64_baseline_config(dev):
+    """BASELINE config 2 geometry: 336x336x3, 64-prompt batch, fused path."""
+    Plan = _plans()
+    torch.manual_seed(1)
+    x0 = torch.rand(3, 336, 336)
+    _trajectory(dev, x0, [LlavaOracle()], [Plan.llava(336, 336)], [64], 3)
+
+
+def test_llava_downsample_blur_crop_mask_accum(dev):
+    Plan = _plans()
+    torch.manual_seed(2)
+    H, W = 96, 80
+    x0 = torch.rand(3, H, W)
+    mask = P.create_mask("corner", 40, (3, H, W))
+    crops = [(3, 5, 70, 60), (0, 0, 96, 80), (10, 2, 64, 70), (20, 20, 60, 50)]
+    _trajectory(dev, x0, [LlavaOracle(48, 48)], [Plan.llava(H, W, 48, 48)], [3], 4, blur_kernel=5,
+                blur_sigma_fn=lambda t: 7.0, crop_fn=lambda t: crops[t], mask=mask, accum=2, gamma=0.5, step_size=1)
+
+
+def test_mllama_localized_patch(dev):
+    """BASELINE config 3 shape in miniature: tiling plugin + bottom_lines mask."""
+    Plan = _plans()
+    torch.manual_seed(3)
+    H, W = 70, 100
+    x0 = torch.rand(3, H, W)
+    mask = P.create_mask("bottom_lines", 20, (3, H, W))
+    _trajectory(dev, x0, [MllamaOracle(tile=32)], [Plan.mllama(H, W, tile=32)], [4], 3, mask=mask)
+
+
+def test_cross_model_sum_with_blur(dev):
+    """BASELINE configs 4/5 in miniature: Phi-3.5 + Qwen2-VL + Mllama on one image, weighted
+    sum of gradients, image_fit counted once per model, per-step random blur sigma."""
+    Plan = _plans()
+    torch.manual_seed(4)
+    H, W = 60, 90
+    x0 = torch.rand(3, H, W)
+    oracles = [Phi3Oracle(), Qwen2VLOracle(min_pixels=28 * 28 * 4, max_pixels=28 * 28 * 64), MllamaOracle(tile=32)]
+    plans = [Plan.phi3(H, W), Plan.qwen2vl(H, W, min_pixels=28 * 28 * 4, max_pixels=28 * 28 * 64),
+             Plan.mllama(H, W, tile=32)]
+    sig = [0.7, 1.9, 0.15]
+    _trajectory(dev, x0, oracles, plans, [2, 2, 2], 3, blur_kernel=5, blur_sigma_fn=lambda t: sig[t],
+                weights=[0.2, 0.8, 1.6], cross=True, gamma=0.9, step_size=2)
+
+
+def test_sign_optimizer(dev):
+    Plan = _plans()
+    torch.manual_seed(5)
+    x0 = torch.rand(3, 32, 32)
+    _trajectory(dev, x0, [LlavaOracle(32, 32)], [Plan.llava(32, 32, 32, 32)], [2], 4, optimizer="sign", lr=1e-3)
+
+
+def test_determinism_bitwise(dev):
+    """Two runs from the same seeds give bitwise identical p after N steps (fixed-order
+    reductions, counter-based noise)."""
+    from adversarialvlm_amd.pgd import PixelPGD
+    Plan = _plans()
+    x0 = torch.rand(3, 336, 336, generator=torch.Generator().manual_seed(9)).to(dev)
+    g = torch.randn(16, 3, 336, 336, generator=torch.Generator().manual_seed(10)).to(dev)
+    ps = []
+    for _ in range(2):
+        eng = PixelPGD(x0, [Plan.llava(336, 336)], seed=42)
+        for _ in range(4):
+            eng.forward(16)
+            eng.backward_update([g])
+        ps.append(eng.p.clone())
+    assert torch.equal(ps[0], ps[1])

@@ -1,0 +1,181 @@
+"""GPU tier: advx_emit / advx_collect (the four differentiable processors) against the CPU
+oracle and against the fixtures captured from the imported reference classes."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, lcg_tensor, rel_err
+from oracle.processors import LlavaOracle, MllamaOracle, Phi3Oracle, Qwen2VLOracle
+
+pytestmark = pytest.mark.gpu
+TIGHT = 5e-6
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _run(plan, img, up, dev):
+    from adversarialvlm_amd import ops
+    x = img.detach().to(dev).requires_grad_(True)
+    pv = ops.ProcessFunction.apply(x, plan)
+    pv.backward(up.to(dev).view(pv.shape))
+    return pv.detach().cpu(), x.grad.cpu()
+
+
+@pytest.mark.parametrize("name", ["down", "mixed", "ident", "up"])
+def test_llava_reference_capture(dev, name):
+    from adversarialvlm_amd.plan import Plan
+    g = load_golden("llava_reference.npz")
+    ch, cw = (int(v) for v in g[f"{name}_crop"])
+    img = torch.tensor(g[f"{name}_image"])
+    plan = Plan.llava(img.shape[1], img.shape[2], ch, cw)
+    pv, grad = _run(plan, img, lcg_tensor((1, 3, ch, cw), int(g[f"{name}_salt"])), dev)
+    assert tuple(pv.shape) == g[f"{name}_pixel_values"].shape
+    assert rel_err(pv, g[f"{name}_pixel_values"]) < TIGHT
+    assert rel_err(grad, g[f"{name}_image_grad"]) < TIGHT
+    if name == "ident":   # identity resize is a bit-exact passthrough before normalisation
+        ref = LlavaOracle(ch, cw).process(img)["pixel_values"]
+        assert torch.equal(pv, ref)
+
+
+def test_llava_full_size_512_to_336(dev):
+    from adversarialvlm_amd.plan import Plan
+    g = load_golden("llava_reference.npz")
+    img = lcg_tensor((3, 512, 512), int(g["full_salt_image"])) + 0.5
+    plan = Plan.llava(512, 512)
+    pv, grad = _run(plan, img, lcg_tensor((1, 3, 336, 336), int(g["full_salt_up"])), dev)
+    assert abs(float(pv.double().sum()) - float(g["full_pv_sum"])) < 1e-5 * abs(float(g["full_pv_sum"]))
+    assert rel_err(pv.flatten()[g["full_pv_idx"]], g["full_pv_val"]) < TIGHT
+    assert rel_err(grad.flatten()[g["full_grad_idx"]], g["full_grad_val"]) < TIGHT
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_qwen_reference_capture(dev, name):
+    from adversarialvlm_amd.plan import Plan
+    g = load_golden("qwen2vl_reference.npz")
+    minp, maxp = (int(v) for v in g[f"{name}_minmax"])
+    img = torch.tensor(g[f"{name}_image"])
+    plan = Plan.qwen2vl(img.shape[1], img.shape[2], min_pixels=minp, max_pixels=maxp)
+    assert plan.info.num_tiles == int(g[f"{name}_num_tiles"][0])
+    assert (plan.stage(0).res_h, plan.stage(0).res_w) == tuple(int(v) for v in g[f"{name}_optimal_size"])
+    ref = g[f"{name}_pixel_values"]
+    pv, grad = _run(plan, img, lcg_tensor(ref.shape, int(g[f"{name}_salt"])), dev)
+    assert tuple(pv.shape) == ref.shape
+    assert rel_err(pv, ref) < TIGHT
+    assert rel_err(grad, g[f"{name}_image_grad"]) < TIGHT
+
+
+@pytest.mark.parametrize("name", ["wide", "tall", "square"])
+def test_phi3_reference_capture(dev, name):
+    from adversarialvlm_amd.plan import Plan
+    g = load_golden("phi3_reference.npz")
+    img = torch.tensor(g[f"{name}_image"])
+    plan = Plan.phi3(img.shape[1], img.shape[2])
+    assert [[plan.info.image_h, plan.info.image_w]] == g[f"{name}_image_sizes"].tolist()
+    assert [plan.info.num_img_tokens] == g[f"{name}_num_img_tokens"].tolist()
+    pv, grad = _run(plan, img, lcg_tensor((1, 7, 3, 336, 336), int(g[f"{name}_salt"])), dev)
+    flat = pv.reshape(7, -1).double()
+    np.testing.assert_allclose(flat.sum(1).numpy(), g[f"{name}_tile_sum"], rtol=2e-6, atol=2e-3)
+    np.testing.assert_allclose((flat ** 2).sum(1).numpy(), g[f"{name}_tile_sumsq"], rtol=2e-6, atol=2e-3)
+    assert rel_err(pv.flatten()[g[f"{name}_pv_idx"]], g[f"{name}_pv_val"]) < TIGHT
+    assert rel_err(grad, g[f"{name}_image_grad"]) < 2e-5
+    n_real = plan.info.num_tiles
+    assert torch.count_nonzero(pv[0, n_real:]) == 0            # padding tiles are exact zeros
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_mllama_restated_fixture(dev, name):
+    from adversarialvlm_amd.plan import Plan
+    g = load_golden("mllama_restated.npz")
+    img = torch.tensor(g[f"{name}_image"])
+    tile = int(g[f"{name}_tile"])
+    plan = Plan.mllama(img.shape[1], img.shape[2], tile=tile, max_tiles=4)
+    assert plan.info.num_tiles == int(g[f"{name}_num_tiles"])
+    ref = g[f"{name}_pixel_values"]
+    pv, grad = _run(plan, img, lcg_tensor(ref.shape, int(g[f"{name}_salt"])), dev)
+    assert rel_err(pv, ref) < TIGHT
+    assert rel_err(grad, g[f"{name}_image_grad"]) < TIGHT
+    assert torch.count_nonzero(pv[0, 0, plan.info.num_tiles:]) == 0
+
+
+@pytest.mark.parametrize("kind,H,W", [("llava", 336, 336), ("llava", 512, 512), ("mllama", 336, 336), ("mllama", 700, 420),
+                                       ("phi3", 336, 336), ("phi3", 300, 500), ("qwen", 336, 336), ("qwen", 512, 512)])
+def test_full_size_against_oracle(dev, kind, H, W):
+    """BASELINE-size geometries live against the oracle (torch CPU), forward and backward."""
+    from adversarialvlm_amd.plan import Plan
+    torch.manual_seed(5)
+    img = torch.rand(3, H, W)
+    plan, ora = {"llava": (Plan.llava, LlavaOracle), "mllama": (Plan.mllama, MllamaOracle),
+                 "phi3": (Plan.phi3, Phi3Oracle), "qwen": (Plan.qwen2vl, Qwen2VLOracle)}[kind]
+    plan = plan(H, W)
+    x = img.clone().requires_grad_(True)
+    ref = ora().process(x)["pixel_values"]
+    up = torch.randn(ref.shape)
+    ref.backward(up)
+    pv, grad = _run(plan, img, up, dev)
+    assert tuple(pv.shape) == tuple(ref.shape)
+    assert rel_err(pv, ref.detach()) < TIGHT
+    assert rel_err(grad, x.grad) < 2e-5
+
+
+def test_emit_broadcast_noise_and_collect_sum(dev):
+    """repeat(B) + randn*sigma (attack_model.py:316-321) with the noise supplied, and the
+    batch-sum backward, on the Mllama layout (tiles + zero tiles)."""
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan
+    torch.manual_seed(6)
+    B, H, W, tile = 5, 50, 90, 32
+    img = torch.rand(3, H, W, requires_grad=True)
+    z = torch.randn(B, 1, 4, 3, tile, tile)
+    sigma = 0.0123
+    ref1 = MllamaOracle(tile=tile).process(img)["pixel_values"]
+    ref = ref1.repeat(B, 1, 1, 1, 1, 1) + z * sigma
+    up = torch.randn_like(ref)
+    ref.backward(up)
+    plan = Plan.mllama(H, W, tile=tile)
+    sig = torch.tensor([sigma], device=dev)
+    out = ops.emit(plan, img.detach().to(dev), B, sigma_dev=sig, unit_noise=z.to(dev))
+    assert rel_err(out.cpu().view(ref.shape), ref.detach()) < TIGHT
+    g = ops.collect(plan, up.to(dev).view(B, -1), B)
+    assert rel_err(g.cpu(), img.grad) < TIGHT
+    # accumulate flag adds instead of overwriting
+    g2 = ops.collect(plan, up.to(dev).view(B, -1), B, grad_argument=g.clone(), accumulate=True)
+    assert rel_err(g2.cpu(), 2 * img.grad) < TIGHT
+
+
+def test_emit_philox_noise_statistics(dev):
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan
+    plan = Plan.llava(64, 64, 64, 64)
+    img = torch.rand(3, 64, 64, device=dev)
+    sig = torch.tensor([0.05], device=dev)
+    clean = ops.emit(plan, img, 16)
+    noisy = ops.emit(plan, img, 16, sigma_dev=sig, philox=(7, 3))
+    d = (noisy - clean).cpu().numpy() / 0.05
+    assert abs(d.mean()) < 1e-2 and abs(d.std() - 1.0) < 1e-2
+    assert abs(np.corrcoef(d[0], d[1])[0, 1]) < 3e-2        # batch rows get independent draws
+    again = ops.emit(plan, img, 16, sigma_dev=sig, philox=(7, 3))
+    assert torch.equal(noisy, again)                          # counter-based: reproducible
+
+
+def test_layout_index_map_matches_device(dev):
+    """advx_plan_out_index (host) vs what the device wrote: integer layout bit-exact."""
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan
+    for plan in (Plan.qwen2vl(60, 90, min_pixels=28 * 28 * 4, max_pixels=28 * 28 * 64), Plan.mllama(90, 50, tile=32)):
+        st = plan.stage(0)
+        # an image whose canvas values are all distinct: use mean 0 / std 1 via a fresh plan
+        p2 = type(plan)(plan.kind, plan.in_h, plan.in_w, (plan.desc.a0, plan.desc.a1, plan.desc.a2, plan.desc.a3, plan.desc.a4),
+                        mean=(0, 0, 0), std=(1, 1, 1))
+        img = torch.rand(3, plan.in_h, plan.in_w, device=dev)
+        out = ops.emit(p2, img, 1).cpu().flatten()
+        ws = torch.empty(p2.workspace_floats, device=dev)
+        ops.emit(p2, img, 1, workspace=ws)
+        canvas = ws[:3 * st.can_h * st.can_w].cpu().view(3, st.can_h, st.can_w)
+        rng = np.random.default_rng(0)
+        for _ in range(300):
+            c, y, x = int(rng.integers(3)), int(rng.integers(st.can_h)), int(rng.integers(st.can_w))
+            for idx in p2.out_index(0, c, y, x):
+                assert out[idx].item() == canvas[c, y, x].item()
