@@ -99,7 +99,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise AdvxError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch must load ITS HIP runtime first: libadvx_hip.so then binds to the same
+    # libamdhip64 (same soname), so torch's streams and device pointers are valid inside the
+    # library.  Loading in the other order maps a second runtime that sees no device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
+    with open("/proc/self/maps") as f:
+        runtimes = {ln.split()[-1] for ln in f if "libamdhip64" in ln}
+    if len(runtimes) > 1:
+        raise AdvxError(f"two HIP runtimes mapped ({sorted(runtimes)}): import torch before loading libadvx_hip.so")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError here = header/library mismatch
         fn.restype = res
