@@ -470,6 +470,7 @@ static void emit_slices(long long n4, int batch, int* gx, int* slices, int* b_pe
   if (bx < 1) bx = 1;
   int want = (int)std::max<long long>(1, (2048 + bx - 1) / bx);
   int sl = std::min(batch, want);
+  while (sl < batch && batch % sl != 0) ++sl;  // equal slices: no straggler slice
   int bps = (batch + sl - 1) / sl;
   sl = (batch + bps - 1) / bps;
   *gx = (int)bx;
@@ -768,75 +769,114 @@ extern "C" int32_t advx_fused_supported(const advx_plan* p) {
   return (p->info.kind == ADVX_KIND_LLAVA && s.src_h == s.res_h && s.src_w == s.res_w && ((s.src_h * s.src_w) % 4 == 0)) ? 1 : 0;
 }
 
+// scratch of the fused pair: [FusedHeader][image partials: fwd_blocks x 6 doubles][norm partials]
+namespace {
+struct FusedScratch {
+  FusedHeader* hdr;
+  double* img_partials;
+  double* norm_partials;
+  int fwd_blocks, bwd_blocks;
+};
+FusedScratch carve_fused(const advx_plan* p, float* scratch) {
+  FusedScratch f;
+  long long n4 = (3LL * p->info.in_h * p->info.in_w) >> 2;
+  f.fwd_blocks = (int)((n4 + kBlock - 1) / kBlock);
+  f.bwd_blocks = (int)((n4 + kWave - 1) / kWave);
+  f.hdr = reinterpret_cast<FusedHeader*>(scratch);
+  f.img_partials = reinterpret_cast<double*>(scratch + sizeof(FusedHeader) / sizeof(float));
+  f.norm_partials = f.img_partials + (size_t)kStatSlots * f.bwd_blocks;  // image rows: one per 256 pixels
+  return f;
+}
+}  // namespace
+
 extern "C" int64_t advx_fused_scratch_floats(const advx_plan* p) {
   if (!p) return 0;
-  long long n = 3LL * p->info.in_h * p->info.in_w;
-  long long fwd_blocks = (n / 4 + kBlock - 1) / kBlock;
-  long long bwd_blocks = (n / 4 + kWave - 1) / kWave;
-  return 2 * kStatSlots * fwd_blocks + 2 * bwd_blocks + 256;
+  long long n4 = (3LL * p->info.in_h * p->info.in_w) >> 2;
+  long long fwd_blocks = (n4 + kBlock - 1) / kBlock;
+  long long bwd_blocks = (n4 + kWave - 1) / kWave;
+  (void)fwd_blocks;
+  return (long long)(sizeof(FusedHeader) / sizeof(float)) + 2 * kStatSlots * bwd_blocks + 2 * bwd_blocks + 256;
+}
+
+static FusedGeom fused_geom(const advx_plan* p) {
+  FusedGeom g;
+  g.plane = p->info.in_h * p->info.in_w;
+  for (int c = 0; c < 3; ++c) {
+    g.mean[c] = p->desc.mean[c];
+    g.stdv[c] = p->desc.std[c];
+  }
+  return g;
 }
 
 extern "C" int32_t advx_fused_fwd(advx_plan* p, const float* pp, const float* x0, float eps, int32_t batch,
                                   const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset, float* out,
-                                  float* s_out, float* stats, float* scratch, void* stream) {
-  REQUIRE(p && pp && x0 && out && stats && scratch, ADVX_E_BADARG, "advx_fused_fwd: null argument");
+                                  float* s_buf, float* v_buf, int32_t prepared, float* stats, float* scratch, void* stream) {
+  REQUIRE(p && pp && x0 && out && stats && scratch && s_buf && v_buf, ADVX_E_BADARG, "advx_fused_fwd: null argument");
   REQUIRE(advx_fused_supported(p), ADVX_E_UNSUPPORTED, "advx_fused_fwd: plan is not an identity LLaVA plan");
   REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_fused_fwd: batch out of range");
-  REQUIRE(aligned16(pp) && aligned16(x0) && aligned16(out) && (!unit_noise || aligned16(unit_noise)) &&
-              (!s_out || aligned16(s_out)), ADVX_E_BADARG,
+  REQUIRE(aligned16(out) && aligned16(scratch) && aligned16(v_buf) && aligned16(s_buf) && aligned16(x0) &&
+              (!unit_noise || aligned16(unit_noise)), ADVX_E_BADARG,
           "advx_fused_fwd: pointers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const int plane = p->info.in_h * p->info.in_w;
-  const long long n = 3LL * plane, n4 = n >> 2;
+  const long long n = 3LL * p->info.in_h * p->info.in_w, n4 = n >> 2;
+  FusedScratch f = carve_fused(p, scratch);
+  if (!prepared) {
+    // first step, or p was changed outside the fused pair: prepare s, v and the statistics partials
+    hipLaunchKernelGGL(k_fused_prep, dim3(grid_for(n, 1 << 20)), dim3(kBlock), 0, st, pp, x0, eps, fused_geom(p), s_buf,
+                       v_buf);
+    LAUNCH_CHECK();
+  }
   int gx, slices, bps;
   emit_slices(n4, batch, &gx, &slices, &bps);
-  double* partials = reinterpret_cast<double*>(scratch);
-  const float* m = p->desc.mean;
-  const float* sd = p->desc.std;
   dim3 grid(gx, slices);
   int noise = unit_noise ? 1 : (use_philox ? 2 : 0);
-#define ADVX_FF(N)                                                                                              \
-  hipLaunchKernelGGL(k_fused_fwd<N>, grid, dim3(kBlock), 0, st, pp, x0, eps, plane, m[0], m[1], m[2], sd[0], sd[1], \
-                     sd[2], batch, bps, stats, unit_noise, seed, offset, out, s_out, partials)
+#define ADVX_FF(N)                                                                                               \
+  hipLaunchKernelGGL(k_fused_fwd<N>, grid, dim3(kBlock), 0, st, (const float*)v_buf, (const float*)s_buf, x0, n, batch, \
+                     bps, stats, unit_noise, seed, offset, out, f.hdr, f.img_partials, (const double*)f.norm_partials)
   if (noise == 0) ADVX_FF(0); else if (noise == 1) ADVX_FF(1); else ADVX_FF(2);
 #undef ADVX_FF
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_finalize_image, dim3(1), dim3(kBlock), 0, st, partials, gx, n, stats);
   LAUNCH_CHECK();
   return ADVX_OK;
 }
 
 extern "C" int32_t advx_fused_bwd(advx_plan* p, const float* g, int32_t batch, float* pp, const float* x0, float eps,
                                   float imgfit_scale, const float* mask, float* m, float* v, float* grad_p,
-                                  const advx_opt_scalars* opt, float* stats, float* scratch, void* stream) {
-  REQUIRE(p && g && pp && x0 && grad_p && scratch, ADVX_E_BADARG, "advx_fused_bwd: null argument");
+                                  const advx_opt_scalars* opt, float* s_next, float* v_buf, float* stats, float* scratch,
+                                  void* stream) {
+  REQUIRE(p && g && pp && x0 && grad_p && scratch && stats, ADVX_E_BADARG, "advx_fused_bwd: null argument");
   REQUIRE(advx_fused_supported(p), ADVX_E_UNSUPPORTED, "advx_fused_bwd: plan is not an identity LLaVA plan");
   REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_fused_bwd: batch out of range");
-  REQUIRE(aligned16(g), ADVX_E_BADARG, "advx_fused_bwd: grad_out must be 16-byte aligned");
+  REQUIRE(aligned16(g) && aligned16(scratch), ADVX_E_BADARG, "advx_fused_bwd: grad_out/scratch must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const int plane = p->info.in_h * p->info.in_w;
-  const long long n = 3LL * plane, n4 = n >> 2;
+  const long long n = 3LL * p->info.in_h * p->info.in_w;
   const float c_fit = imgfit_scale / (float)n;
-  const float* sd = p->desc.std;
-  int blocks = (int)((n4 + kWave - 1) / kWave);
-  long long fwd_blocks = (n4 + kBlock - 1) / kBlock;
-  double* partials = reinterpret_cast<double*>(scratch) + kStatSlots * fwd_blocks;
+  FusedScratch f = carve_fused(p, scratch);
   if (opt) {
-    REQUIRE(mask && stats, ADVX_E_BADARG, "advx_fused_bwd: update needs mask and stats");
+    REQUIRE(mask && s_next && v_buf, ADVX_E_BADARG, "advx_fused_bwd: update needs mask, s_next and v_buf");
+    REQUIRE(opt->apply, ADVX_E_UNSUPPORTED, "advx_fused_bwd: the fused update always steps (use the generic path to accumulate)");
     int32_t rc = check_opt(opt, m, v);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_fused_bwd<true>, dim3(blocks), dim3(kBlock), 0, st, g, batch, pp, x0, eps, plane, sd[0], sd[1],
-                       sd[2], c_fit, mask, m, v, grad_p, to_dev(opt), partials);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_finalize_norm, dim3(1), dim3(kBlock), 0, st, partials, blocks, stats);
-    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_fused_bwd<true>, dim3(f.bwd_blocks), dim3(kBlock), 0, st, g, batch, pp, x0, eps, fused_geom(p), c_fit,
+                       mask, m, v, grad_p, to_dev(opt), s_next, v_buf, f.norm_partials, stats, f.hdr,
+                       (const double*)f.img_partials);
   } else {
     OptScalars none;
     std::memset(&none, 0, sizeof(none));
-    hipLaunchKernelGGL(k_fused_bwd<false>, dim3(blocks), dim3(kBlock), 0, st, g, batch, pp, x0, eps, plane, sd[0], sd[1],
-                       sd[2], c_fit, mask, m, v, grad_p, none, partials);
-    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_fused_bwd<false>, dim3(f.bwd_blocks), dim3(kBlock), 0, st, g, batch, pp, x0, eps, fused_geom(p), c_fit,
+                       mask, m, v, grad_p, none, s_next, v_buf, f.norm_partials, stats, f.hdr,
+                       (const double*)f.img_partials);
   }
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_fused_flush(advx_plan* p, float* stats, float* scratch, int32_t image_too, void* stream) {
+  REQUIRE(p && stats && scratch, ADVX_E_BADARG, "advx_fused_flush: null argument");
+  REQUIRE(advx_fused_supported(p), ADVX_E_UNSUPPORTED, "advx_fused_flush: plan is not an identity LLaVA plan");
+  FusedScratch f = carve_fused(p, scratch);
+  hipLaunchKernelGGL(k_fused_flush, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, f.hdr, (const double*)f.img_partials,
+                     (const double*)f.norm_partials, 3LL * p->info.in_h * p->info.in_w, (int)image_too, stats);
+  LAUNCH_CHECK();
   return ADVX_OK;
 }
 

@@ -161,6 +161,7 @@ __device__ inline void block_sum_store(const double (&acc)[NS], double* dst) {
       dst[k] = t;
     }
   }
+  __syncthreads();  // `red` may be reused by a following call
 }
 
 // ----------------------------------------------------------------------- Philox noise
@@ -170,8 +171,11 @@ struct Philox {
 __device__ inline uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    // one 32x32->64 multiply (v_mad_u64_u32) per word instead of a mul_hi + mul_lo pair
+    unsigned long long p0 = (unsigned long long)0xD2511F53u * (unsigned long long)c.x;
+    unsigned long long p1 = (unsigned long long)0xCD9E8D57u * (unsigned long long)c.z;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;

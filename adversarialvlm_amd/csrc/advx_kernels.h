@@ -47,28 +47,64 @@ __global__ void __launch_bounds__(kBlock) k_prep(const float* __restrict__ p, co
   if (WRITE_S) block_sum_store<kStatSlots>(acc, partials + (size_t)blockIdx.x * kStatSlots);
 }
 
-// single block: reduce the per-block partials, rotate SIGMA <- QERR_STD, write stats
-__global__ void __launch_bounds__(kBlock) k_finalize_image(const double* __restrict__ partials, int nblk,
-                                                           long long n, float* __restrict__ stats) {
+// one whole block: reduce the per-block partials, [rotate SIGMA <- QERR_STD], write stats
+template <bool ROTATE>
+__device__ inline void finalize_image_block(const double* __restrict__ partials, int nblk, long long n,
+                                            float* __restrict__ stats) {
   double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
   for (int b = threadIdx.x; b < nblk; b += blockDim.x)
     for (int k = 0; k < kStatSlots; ++k) acc[k] += partials[(size_t)b * kStatSlots + k];
   __shared__ double tot[kStatSlots];
   block_sum_store<kStatSlots>(acc, tot);
-  __syncthreads();
   if (threadIdx.x == 0) {
     double N = (double)n;
     double mean_d = tot[0] / N;
     double var_d = (n > 1) ? (tot[1] - tot[0] * tot[0] / N) / (N - 1.0) : 0.0;
     double mean_x = tot[3] / N;
     double var_x = (n > 1) ? (tot[4] - tot[3] * tot[3] / N) / (N - 1.0) : 0.0;
-    stats[0] = stats[1];  // ADVX_STAT_SIGMA <- previous step's QERR_STD
+    if (ROTATE) stats[0] = stats[1];  // ADVX_STAT_SIGMA <- previous step's QERR_STD
     stats[1] = (float)sqrt(var_d > 0.0 ? var_d : 0.0);
     stats[2] = (float)mean_d;
     stats[3] = (float)tot[0];
     stats[4] = (float)(tot[2] / N);
     stats[5] = (float)mean_x;
     stats[6] = (float)sqrt(var_x > 0.0 ? var_x : 0.0);
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_finalize_image(const double* __restrict__ partials, int nblk,
+                                                           long long n, float* __restrict__ stats) {
+  finalize_image_block<true>(partials, nblk, n, stats);
+}
+
+// one whole block: ||g||_2 from per-block sums of squares -> stats[GRAD_NORM]
+__device__ inline void finalize_norm_block(const double* __restrict__ partials, int nblk, float* __restrict__ stats) {
+  double acc[1] = {0.0};
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) acc[0] += partials[b];
+  __shared__ double tot1[1];
+  block_sum_store<1>(acc, tot1);
+  if (threadIdx.x == 0) stats[7] = (float)sqrt(tot1[0]);
+}
+
+// Header of the fused pair's scratch: which partial sets still wait for their reduction.
+// The reductions ride in block (0,0) of the next k_fused_fwd (kernel boundaries give the
+// ordering and visibility), so a fused step is two launches instead of four.
+struct FusedHeader {
+  int norm_blocks;   // > 0: k_fused_bwd<true> left that many sum-of-squares partials
+  int image_blocks;  // > 0: k_fused_fwd left that many statistics partial rows
+  int pad[14];
+};
+
+// explicit flush (host reads stats / a non-fused kernel follows)
+__global__ void __launch_bounds__(kBlock) k_fused_flush(FusedHeader* __restrict__ hdr, const double* __restrict__ img_partials,
+                                                        const double* __restrict__ norm_partials, long long n,
+                                                        int image_too, float* __restrict__ stats) {
+  int ib = image_too ? hdr->image_blocks : 0, nb = hdr->norm_blocks;
+  __syncthreads();
+  if (ib > 0) finalize_image_block<true>(img_partials, ib, n, stats);
+  if (nb > 0) finalize_norm_block(norm_partials, nb, stats);
+  if (threadIdx.x == 0) {
+    if (image_too) hdr->image_blocks = 0;
+    hdr->norm_blocks = 0;
   }
 }
 
@@ -458,7 +494,14 @@ __device__ inline float4 batch_column_sum(const float* __restrict__ g, int batch
                                           int wid, int nw) {
   float4 a = make_float4(0, 0, 0, 0);
   int b = wid;
-  // 4 loads in flight per iteration
+  // 8, then 4 independent 16-byte loads in flight per lane (1 KiB per wave-instruction)
+  for (; b + 7 * nw < batch; b += 8 * nw) {
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(g + (size_t)(b + k * nw) * n + i0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a = f4add(a, v[k]);
+  }
   for (; b + 3 * nw < batch; b += 4 * nw) {
     float4 v0 = *reinterpret_cast<const float4*>(g + (size_t)b * n + i0);
     float4 v1 = *reinterpret_cast<const float4*>(g + (size_t)(b + nw) * n + i0);
@@ -548,117 +591,174 @@ __global__ void __launch_bounds__(kBlock) k_update(float* __restrict__ p, float*
 
 __global__ void __launch_bounds__(kBlock) k_finalize_norm(const double* __restrict__ partials, int nblk,
                                                           float* __restrict__ stats) {
-  double acc[1] = {0.0};
-  for (int b = threadIdx.x; b < nblk; b += blockDim.x) acc[0] += partials[b];
-  __shared__ double tot[1];
-  block_sum_store<1>(acc, tot);
-  __syncthreads();
-  if (threadIdx.x == 0) stats[7] = (float)sqrt(tot[0]);
+  finalize_norm_block(partials, nblk, stats);
 }
 
 // ================================================================= fused (identity plan)
-// LLaVA at native resolution: process() is (s - mean)/std, so the whole forward is one
-// streaming kernel: out[b,i] = (x0[i] + eps*tanh(p[i]) - mean_c)/std_c + sigma*z.
-// blockIdx.y slices the batch; slice 0 also produces the statistics partials.
-template <int NOISE>
-__global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ p, const float* __restrict__ x0,
-                                                      float eps, int plane, float m0, float m1, float m2, float s0,
-                                                      float s1, float s2, int batch, int b_per_slice,
-                                                      const float* __restrict__ stats, const float* __restrict__ unit_noise,
-                                                      unsigned long long seed, unsigned long long offset,
-                                                      float* __restrict__ out, float* __restrict__ s_out,
-                                                      double* __restrict__ partials) {
-  const long long n = 3LL * plane;
-  const long long n4 = n >> 2;  // host guarantees plane % 4 == 0
-  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
-  if (q < n4) {
-    const long long i0 = q << 2;
-    const int c = (int)(i0 / plane);
-    const float mean = (c == 0) ? m0 : ((c == 1) ? m1 : m2);
-    const float sd = (c == 0) ? s0 : ((c == 1) ? s1 : s2);
-    float4 pp = *reinterpret_cast<const float4*>(p + i0);
-    float4 xx = *reinterpret_cast<const float4*>(x0 + i0);
-    float x[4] = {eps * tanhf(pp.x), eps * tanhf(pp.y), eps * tanhf(pp.z), eps * tanhf(pp.w)};
-    float s[4] = {xx.x + x[0], xx.y + x[1], xx.z + x[2], xx.w + x[3]};
-    float v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (s[k] - mean) / sd;
-    if (blockIdx.y == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) stat_accumulate(s[k], x[k], acc);
-      if (s_out != nullptr) *reinterpret_cast<float4*>(s_out + i0) = make_float4(s[0], s[1], s[2], s[3]);
-    }
-    // the sigma of THIS step is the previous step's QERR_STD: k_finalize_image has not run
-    // yet for this step, so read slot QERR_STD (1) directly.
-    const float sigma = (NOISE != 0) ? stats[1] : 0.0f;
-    const int b0 = blockIdx.y * b_per_slice;
-    const int b1 = min(batch, b0 + b_per_slice);
-    for (int b = b0; b < b1; ++b) {
-      float4 o = make_float4(v[0], v[1], v[2], v[3]);
-      if (NOISE == 1) {
-        float4 z = *reinterpret_cast<const float4*>(unit_noise + (size_t)b * n + i0);
-        o = make_float4(v[0] + z.x * sigma, v[1] + z.y * sigma, v[2] + z.z * sigma, v[3] + z.w * sigma);
-      } else if (NOISE == 2) {
-        float4 z = philox_normal4((unsigned long long)b * (unsigned long long)n4 + (unsigned long long)q, offset, seed);
-        o = make_float4(v[0] + z.x * sigma, v[1] + z.y * sigma, v[2] + z.z * sigma, v[3] + z.w * sigma);
-      }
-      *reinterpret_cast<float4*>(out + (size_t)b * n + i0) = o;
-    }
+// LLaVA at native resolution: process() is (s - mean)/std with s = x0 + eps*tanh(p).
+// The step is software-pipelined over two launches:
+//   k_fused_fwd(t) : stream out[b,i] = v_t[i] + sigma_t * N(0,1) from the PREPARED v_t.  The
+//                    blocks of batch-slice 0 also read s_t, x0 and leave the statistics
+//                    partials of s_t; block (0,0) reduces ||g|| of step t-1 (slot 7).
+//                    sigma_t is slot QERR_STD, i.e. the quantise error of s_{t-1}.
+//   k_fused_bwd(t) : reads the B gradients once, /std, image-fit term, tanh', mask, ||g||,
+//                    optimiser, and - same thread, same registers - prepares step t+1 from
+//                    the UPDATED p: s_{t+1}, v_{t+1}.  Block 0 reduces the statistics of s_t
+//                    (rotating SIGMA <- old QERR_STD first), beside the other blocks' stream.
+// k_fused_prep does the preparation alone (first step, or after p changed elsewhere).
+struct FusedGeom {
+  int plane;        // H*W, multiple of 4
+  float mean[3];
+  float stdv[3];
+};
+
+__global__ void __launch_bounds__(kBlock) k_fused_prep(const float* __restrict__ p, const float* __restrict__ x0,
+                                                       float eps, FusedGeom geo, float* __restrict__ s_buf,
+                                                       float* __restrict__ v_buf) {
+  const long long n = 3LL * geo.plane;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int c = (int)(i / geo.plane);
+    float s = x0[i] + eps * tanhf(p[i]);
+    s_buf[i] = s;
+    v_buf[i] = (s - geo.mean[c]) / geo.stdv[c];
   }
-  if (blockIdx.y == 0) block_sum_store<kStatSlots>(acc, partials + (size_t)blockIdx.x * kStatSlots);
 }
 
-// backward + update in one pass over grad_out: block = 64 float4 columns (256 pixels);
-// waves split the batch, LDS combines, then thread t owns pixel t of the block:
-// /std, + imgfit', tanh', [mask, ||g||, AdamW | store grad].
+// NOISE: 0 none, 1 unit-noise tensor supplied, 2 in-kernel Philox
+template <int NOISE>
+__global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ v_buf, const float* __restrict__ s_buf,
+                                                      const float* __restrict__ x0, long long n, int batch,
+                                                      int b_per_slice, float* stats, const float* __restrict__ unit_noise,
+                                                      unsigned long long seed, unsigned long long offset,
+                                                      float* __restrict__ out, FusedHeader* __restrict__ hdr,
+                                                      double* __restrict__ img_partials,
+                                                      const double* __restrict__ norm_partials) {
+  const long long n4 = n >> 2;
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // sigma of THIS step = quantise error of the previous image = slot QERR_STD (1); it is
+  // only rewritten by the next k_fused_bwd.  Block (0,0) below writes slot 7 only.
+  const float sigma = (NOISE != 0) ? stats[1] : 0.0f;
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    int nb = hdr->norm_blocks;
+    __syncthreads();  // every thread has read the header before thread 0 rewrites it
+    if (nb > 0) finalize_norm_block(norm_partials, nb, stats);
+    if (threadIdx.x == 0) {
+      hdr->norm_blocks = 0;
+      hdr->image_blocks = gridDim.x;
+    }
+  }
+  const long long i0 = q << 2;
+  if (blockIdx.y == 0) {
+    double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
+    if (q < n4) {
+      float4 sv = *reinterpret_cast<const float4*>(s_buf + i0);
+      float4 xv = *reinterpret_cast<const float4*>(x0 + i0);
+      stat_accumulate(sv.x, sv.x - xv.x, acc);
+      stat_accumulate(sv.y, sv.y - xv.y, acc);
+      stat_accumulate(sv.z, sv.z - xv.z, acc);
+      stat_accumulate(sv.w, sv.w - xv.w, acc);
+    }
+    block_sum_store<kStatSlots>(acc, img_partials + (size_t)blockIdx.x * kStatSlots);
+  }
+  if (q >= n4) return;
+  const float4 v = *reinterpret_cast<const float4*>(v_buf + i0);
+  const int b0 = blockIdx.y * b_per_slice;
+  const int b1 = min(batch, b0 + b_per_slice);
+  for (int b = b0; b < b1; ++b) {
+    float4 o = v;
+    if (NOISE == 1) {
+      float4 z = *reinterpret_cast<const float4*>(unit_noise + (size_t)b * n + i0);
+      o = make_float4(v.x + z.x * sigma, v.y + z.y * sigma, v.z + z.z * sigma, v.w + z.w * sigma);
+    } else if (NOISE == 2) {
+      float4 z = philox_normal4((unsigned long long)b * (unsigned long long)n4 + (unsigned long long)q, offset, seed);
+      o = make_float4(v.x + z.x * sigma, v.y + z.y * sigma, v.z + z.z * sigma, v.w + z.w * sigma);
+    }
+    *reinterpret_cast<float4*>(out + (size_t)b * n + i0) = o;
+  }
+}
+
+// backward (+ update + preparation of the next forward) in one pass over grad_out:
+// block = 64 float4 columns (256 pixels); the 4 waves split the batch and meet in LDS; then
+// thread t owns pixel t of the block.  Its per-pixel state is prefetched before the batch
+// loop so that no dependent load sits on the tail.
 template <bool UPDATE>
 __global__ void __launch_bounds__(kBlock) k_fused_bwd(const float* __restrict__ g, int batch, float* __restrict__ p,
-                                                      const float* __restrict__ x0, float eps, int plane, float s0,
-                                                      float s1, float s2, float c_fit, const float* __restrict__ mask,
+                                                      const float* __restrict__ x0, float eps, FusedGeom geo,
+                                                      float c_fit, const float* __restrict__ mask,
                                                       float* __restrict__ m, float* __restrict__ v,
                                                       float* __restrict__ grad_p, OptScalars o,
-                                                      double* __restrict__ partials) {
+                                                      float* __restrict__ s_next, float* __restrict__ v_buf,
+                                                      double* __restrict__ norm_partials, float* __restrict__ stats,
+                                                      FusedHeader* __restrict__ hdr,
+                                                      const double* __restrict__ img_partials) {
   __shared__ float4 part4[kBlock / kWave][kWave];
-  const long long n = 3LL * plane;
+  const long long n = 3LL * geo.plane;
   const long long n4 = n >> 2;
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   const long long q = (long long)blockIdx.x * kWave + lane;
+  const long long i = (long long)blockIdx.x * (kWave * 4) + threadIdx.x;
+  // prefetch this thread's pixel state (latency hides under the batch stream)
+  float pp = 0.f, xv = 0.f, mk = 0.f, mm = 0.f, vv = 0.f;
+  if (i < n) {
+    pp = p[i];
+    xv = x0[i];
+    if (UPDATE) {
+      mk = mask[i];
+      if (o.apply && o.kind == 0) {
+        mm = m[i];
+        vv = v[i];
+      }
+    }
+  }
   float4 a = make_float4(0, 0, 0, 0);
   if (q < n4) a = batch_column_sum(g, batch, n, q << 2, wid, kBlock / kWave);
+  if (blockIdx.x == 0) {
+    // statistics partials left by this step's forward: reduce them here, beside the other
+    // blocks' streaming work (rotates SIGMA <- old QERR_STD, then QERR_STD <- new)
+    int ib = hdr->image_blocks;
+    __syncthreads();
+    if (ib > 0) finalize_image_block<true>(img_partials, ib, n, stats);
+    if (threadIdx.x == 0) {
+      hdr->image_blocks = 0;
+      if (UPDATE) hdr->norm_blocks = gridDim.x;
+    }
+  }
   part4[wid][lane] = a;
   __syncthreads();
   const float(*part)[kWave * 4] = reinterpret_cast<const float(*)[kWave * 4]>(&part4[0][0]);
-  const long long i = (long long)blockIdx.x * (kWave * 4) + threadIdx.x;
-  double acc[1] = {0.0};
+  double nacc[1] = {0.0};
   if (i < n) {
     float gs = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
-    const int c = (int)(i / plane);
-    const float sd = (c == 0) ? s0 : ((c == 1) ? s1 : s2);
-    float pp = p[i];
+    const int c = (int)(i / geo.plane);
+    const float sd = geo.stdv[c];
     float t = tanhf(pp);
-    float s = x0[i] + eps * t;
+    float s = xv + eps * t;
     float gx = gs / sd + imgfit_grad(s, c_fit);
     float gp = (gx * eps) * (1.0f - t * t);
     if (UPDATE) {
-      gp = gp * mask[i];
-      acc[0] = (double)gp * (double)gp;
+      gp = gp * mk;
+      nacc[0] = (double)gp * (double)gp;
       grad_p[i] = gp;
       if (o.apply) {
         if (o.kind == 0) {
-          float mm = m[i], vv = v[i];
           adamw_element(pp, mm, vv, gp, o);
           p[i] = pp; m[i] = mm; v[i] = vv;
         } else {
           float sg = (gp > 0.0f) ? 1.0f : ((gp < 0.0f) ? -1.0f : 0.0f);
-          p[i] = pp - o.lr * sg;
+          pp = pp - o.lr * sg;
+          p[i] = pp;
         }
       }
+      // prepare the next forward from the UPDATED p
+      float sn = xv + eps * tanhf(pp);
+      s_next[i] = sn;
+      v_buf[i] = (sn - geo.mean[c]) / sd;
     } else {
       grad_p[i] = gp;
     }
   }
-  if (UPDATE) block_sum_store<1>(acc, partials + blockIdx.x);
+  if (UPDATE) block_sum_store<1>(nacc, norm_partials + blockIdx.x);
 }
 
 // stats finalisation for the fused pair: image statistics + (optionally) the gradient norm

@@ -137,27 +137,34 @@ def update_scratch(n, device):
 
 # ----------------------------------------------------------------------------- fused
 def fused_scratch(plan, device):
-    return torch.empty(int(L.load().advx_fused_scratch_floats(plan.handle)), dtype=torch.float32, device=device)
+    # zero-initialised: the header says "nothing pending"
+    return torch.zeros(int(L.load().advx_fused_scratch_floats(plan.handle)), dtype=torch.float32, device=device)
 
 
-def fused_fwd(plan, p, x0, epsilon, batch, stats, scratch, unit_noise=None, philox=None, out=None, s_out=None):
-    _require_cuda(p, x0, stats, scratch)
+def fused_flush(plan, stats, scratch, image_too=False):
+    """Run the reductions the fused pair deferred (before reading stats on the host)."""
+    L.check(L.load().advx_fused_flush(plan.handle, L.ptr(stats), L.ptr(scratch), int(image_too), _stream(stats)),
+            "advx_fused_flush")
+
+
+def fused_fwd(plan, p, x0, epsilon, batch, stats, scratch, s_buf, v_buf, prepared, unit_noise=None, philox=None, out=None):
+    _require_cuda(p, x0, stats, scratch, s_buf, v_buf)
     if out is None:
         out = torch.empty((batch, plan.out_numel), dtype=torch.float32, device=p.device)
     seed, offset = (philox if philox is not None else (0, 0))
     L.check(L.load().advx_fused_fwd(plan.handle, L.ptr(p), L.ptr(x0), float(epsilon), int(batch), L.ptr(unit_noise),
-                                    int(philox is not None), int(seed), int(offset), L.ptr(out), L.ptr(s_out),
-                                    L.ptr(stats), L.ptr(scratch), _stream(p)), "advx_fused_fwd")
+                                    int(philox is not None), int(seed), int(offset), L.ptr(out), L.ptr(s_buf), L.ptr(v_buf),
+                                    int(bool(prepared)), L.ptr(stats), L.ptr(scratch), _stream(p)), "advx_fused_fwd")
     return out
 
 
-def fused_bwd(plan, grad_out, batch, p, x0, epsilon, imgfit_scale, grad_p, scratch, mask=None, m=None, v=None,
-              opt=None, stats=None):
-    _require_cuda(grad_out, p, x0, grad_p, scratch)
+def fused_bwd(plan, grad_out, batch, p, x0, epsilon, imgfit_scale, grad_p, stats, scratch, mask=None, m=None, v=None,
+              opt=None, s_next=None, v_buf=None):
+    _require_cuda(grad_out, p, x0, grad_p, scratch, stats)
     L.check(L.load().advx_fused_bwd(plan.handle, L.ptr(_f32c(grad_out)), int(batch), L.ptr(p), L.ptr(x0), float(epsilon),
                                     float(imgfit_scale), L.ptr(mask), L.ptr(m), L.ptr(v), L.ptr(grad_p),
-                                    C.byref(opt) if opt is not None else None, L.ptr(stats), L.ptr(scratch),
-                                    _stream(p)), "advx_fused_bwd")
+                                    C.byref(opt) if opt is not None else None, L.ptr(s_next), L.ptr(v_buf), L.ptr(stats),
+                                    L.ptr(scratch), _stream(p)), "advx_fused_bwd")
 
 
 # ------------------------------------------------------------------------ single ops

@@ -10,10 +10,13 @@ and `crossattack_models.py:329-406,425-432` (several models):
                        blur^T, tanh' -> grad_p ; [all-reduce over the DP group] ;
                        mask, ||g||, AdamW|sign, StepLR                   (HIP)
 
+Two kernel chains implement this:
+  * generic  - any plan(s), blur, crop, gradient accumulation (advx_image_* / advx_emit /
+               advx_collect / advx_update);
+  * fused    - one identity-resize LLaVA plan without blur/crop/accumulation: two launches
+               per step (advx_fused_fwd / advx_fused_bwd), chosen at construction.
 All statistics stay on the device (`self.stats`); nothing here synchronises the stream.
 """
-import math
-
 import torch
 
 from . import _lib as L
@@ -22,8 +25,8 @@ from . import ops
 
 class PixelPGD:
     def __init__(self, x0, plans, epsilon=0.5, lr=1e-2, sigma0=1e-3, mask=None, scheduler_step_size=100,
-                 scheduler_gamma=1.0, grad_accum_steps=1, blur_kernel=None, model_weights=None, optimizer="adamw",
-                 cross_mode=False, betas=(0.9, 0.999), adam_eps=1e-8, weight_decay=1e-2, seed=0,
+                 scheduler_gamma=1.0, grad_accum_steps=1, blur_kernel=None, use_crop=False, model_weights=None,
+                 optimizer="adamw", cross_mode=False, betas=(0.9, 0.999), adam_eps=1e-8, weight_decay=1e-2, seed=0,
                  process_group=None, allow_fused=True):
         if not x0.is_cuda:
             raise L.AdvxError("PixelPGD needs x0 on a ROCm device (there is no CPU fallback)")
@@ -44,14 +47,8 @@ class PixelPGD:
         self.grad = torch.zeros_like(self.x0)
         self.mask = (torch.ones_like(self.x0) if mask is None else mask.to(dev).float().contiguous())
         self.stats = torch.zeros(L.STATS_N, dtype=torch.float32, device=dev)
-        self.stats[L.STAT_QERR_STD] = float(sigma0)             # resave_error_std, attack_model.py:261
-        self.s = torch.empty_like(self.x0)
-        self.argument = torch.empty_like(self.x0)
-        self.garg = torch.empty_like(self.x0)
         self.blur_kernel = blur_kernel
-        self.img_scratch = ops.image_scratch(H, W, blur_kernel or 0, dev)
-        self.upd_scratch = ops.update_scratch(self.p.numel(), dev)
-        self.workspaces = [torch.empty(pl.workspace_floats, dtype=torch.float32, device=dev) for pl in self.plans]
+        self.use_crop = bool(use_crop)
         self.weights = list(model_weights) if model_weights is not None else [1.0] * len(self.plans)
         self.opt_kind = {"adamw": L.OPT_ADAMW, "sign": L.OPT_SIGN}[optimizer]
         self.lr = float(lr)                                     # chained StepLR value (double, like torch)
@@ -68,8 +65,24 @@ class PixelPGD:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
         self.fused = bool(allow_fused and len(self.plans) == 1 and self.plans[0].fused_supported()
-                          and blur_kernel is None)
-        self.fused_scratch = ops.fused_scratch(self.plans[0], dev) if self.fused else None
+                          and blur_kernel is None and not self.use_crop and self.accum == 1)
+        self.upd_scratch = ops.update_scratch(self.p.numel(), dev)
+        if self.fused:
+            # the forward reads its sigma from slot QERR_STD (the previous image's quantise error)
+            self.stats[L.STAT_QERR_STD] = float(sigma0)
+            self.fused_scratch = ops.fused_scratch(self.plans[0], dev)
+            self.s_bufs = [torch.empty_like(self.x0), torch.empty_like(self.x0)]
+            self.s_cur = 0               # s_bufs[s_cur] = image of the prepared / latest forward
+            self.v_buf = torch.empty_like(self.x0)
+            self.prepared = False
+            self.s = self.s_bufs[0]
+        else:
+            self.stats[L.STAT_QERR_STD] = float(sigma0)         # resave_error_std, attack_model.py:261
+            self.s = torch.empty_like(self.x0)
+            self.argument = torch.empty_like(self.x0)
+            self.garg = torch.empty_like(self.x0)
+            self.img_scratch = ops.image_scratch(H, W, blur_kernel or 0, dev)
+            self.workspaces = [torch.empty(pl.workspace_floats, dtype=torch.float32, device=dev) for pl in self.plans]
         self._last = None
         for pl in self.plans:
             pl.upload()
@@ -118,24 +131,28 @@ class PixelPGD:
             unit_noises = [None] * len(self.plans)
         elif not isinstance(unit_noises, (list, tuple)):
             unit_noises = [unit_noises]
-        blur = (self.blur_kernel, blur_sigma) if self.blur_kernel is not None else None
-        use_fused = self.fused and crop is None
         outs = []
-        if use_fused:
+        if self.fused:
+            if crop is not None:
+                raise L.AdvxError("this engine was built for the fused chain: construct with use_crop=True to crop")
             pl = self.plans[0]
             ph = None if (unit_noises[0] is not None or not use_philox) else (self.seed, self.iteration)
             out = ops.fused_fwd(pl, self.p, self.x0, self.eps, batches[0], self.stats, self.fused_scratch,
-                                unit_noise=unit_noises[0], philox=ph, s_out=self.s)
+                                self.s_bufs[self.s_cur], self.v_buf, self.prepared, unit_noise=unit_noises[0], philox=ph)
+            self.prepared = True
+            self.s = self.s_bufs[self.s_cur]
             outs.append(out.view((batches[0] * pl.out_shape[0],) + pl.out_shape[1:]))
-        else:
-            _, arg = ops.image_fwd(self.p, self.x0, self.eps, self.stats, self.img_scratch, blur=blur, crop=crop,
-                                   s=self.s, argument=self.argument if crop is not None else None)
-            sigma = self.stats[L.STAT_SIGMA:L.STAT_SIGMA + 1]
-            for i, (pl, B, z) in enumerate(zip(self.plans, batches, unit_noises)):
-                ph = None if (z is not None or not use_philox) else (self.seed, self.iteration * len(self.plans) + i)
-                out = ops.emit(pl, arg, B, sigma_dev=sigma, unit_noise=z, philox=ph, workspace=self.workspaces[i])
-                outs.append(out.view((B * pl.out_shape[0],) + pl.out_shape[1:]))
-        self._last = dict(batches=list(batches), blur=blur, crop=crop, fused=use_fused)
+            self._last = dict(batches=list(batches))
+            return outs
+        blur = (self.blur_kernel, blur_sigma) if self.blur_kernel is not None else None
+        _, arg = ops.image_fwd(self.p, self.x0, self.eps, self.stats, self.img_scratch, blur=blur, crop=crop,
+                               s=self.s, argument=self.argument if crop is not None else None)
+        sigma = self.stats[L.STAT_SIGMA:L.STAT_SIGMA + 1]
+        for i, (pl, B, z) in enumerate(zip(self.plans, batches, unit_noises)):
+            ph = None if (z is not None or not use_philox) else (self.seed, self.iteration * len(self.plans) + i)
+            out = ops.emit(pl, arg, B, sigma_dev=sigma, unit_noise=z, philox=ph, workspace=self.workspaces[i])
+            outs.append(out.view((B * pl.out_shape[0],) + pl.out_shape[1:]))
+        self._last = dict(batches=list(batches), blur=blur, crop=crop)
         return outs
 
     # ----------------------------------------------------------------- backward
@@ -152,23 +169,30 @@ class PixelPGD:
         first_of_window = (self.iteration % self.accum == 0)
         accumulate = (not self.cross_mode) and (not first_of_window)
         opt = self._opt_scalars(take_step)
-        if st["fused"] and self.world == 1 and not accumulate:
-            ops.fused_bwd(self.plans[0], grads[0], st["batches"][0], self.p, self.x0, self.eps, self.imgfit_scale(),
-                          self.grad, self.fused_scratch, mask=self.mask, m=self.m, v=self.v, opt=opt, stats=self.stats)
-        else:
-            if st["fused"] and not accumulate:
-                ops.fused_bwd(self.plans[0], grads[0], st["batches"][0], self.p, self.x0, self.eps, self.imgfit_scale(),
-                              self.grad, self.fused_scratch)
+        if self.fused:
+            pl, B = self.plans[0], st["batches"][0]
+            nxt = 1 - self.s_cur
+            if self.world == 1:
+                ops.fused_bwd(pl, grads[0], B, self.p, self.x0, self.eps, self.imgfit_scale(), self.grad, self.stats,
+                              self.fused_scratch, mask=self.mask, m=self.m, v=self.v, opt=opt,
+                              s_next=self.s_bufs[nxt], v_buf=self.v_buf)
             else:
-                for i, (pl, g, B) in enumerate(zip(self.plans, grads, st["batches"])):
-                    ops.collect(pl, g.reshape(B, pl.out_numel), B, grad_argument=self.garg, accumulate=(i > 0),
-                                workspace=self.workspaces[i])
-                ops.image_bwd(self.p, self.s, self.garg, self.eps, self.imgfit_scale(), self.grad, self.img_scratch,
-                              blur=st["blur"], crop=st["crop"], accumulate=accumulate)
+                ops.fused_bwd(pl, grads[0], B, self.p, self.x0, self.eps, self.imgfit_scale(), self.grad, self.stats,
+                              self.fused_scratch)
+                # one exchange per step: the shared image gradient (P_in*4 bytes) over RCCL/xGMI
+                torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                ops.update(self.p, self.m, self.v, self.grad, self.mask, opt, self.stats, self.upd_scratch)
+                self.prepared = False
+            self.s_cur = nxt          # the next forward's image goes to the other buffer: image() stays valid
+        else:
+            for i, (pl, g, B) in enumerate(zip(self.plans, grads, st["batches"])):
+                ops.collect(pl, g.reshape(B, pl.out_numel), B, grad_argument=self.garg, accumulate=(i > 0),
+                            workspace=self.workspaces[i])
+            ops.image_bwd(self.p, self.s, self.garg, self.eps, self.imgfit_scale(), self.grad, self.img_scratch,
+                          blur=st["blur"], crop=st["crop"], accumulate=accumulate)
             if self.world > 1 and take_step:
-                # one exchange per optimiser step: the shared image gradient (P_in*4 bytes) over
-                # RCCL/xGMI.  The reduction is linear, so a gradient-accumulation window is
-                # exchanged once, at its end (intermediate grad norms are then rank-local).
+                # The reduction is linear, so a gradient-accumulation window is exchanged once,
+                # at its end (intermediate grad norms are then rank-local).
                 torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
             ops.update(self.p, self.m, self.v, self.grad, self.mask, opt, self.stats, self.upd_scratch)
         if take_step:
@@ -179,7 +203,15 @@ class PixelPGD:
 
     # ------------------------------------------------------------------ readout
     def stats_dict(self):
-        """Synchronising readout of the device statistics (logging cadence only)."""
+        """Synchronising readout of the device statistics (logging cadence only).
+
+        After backward_update() of step t every entry refers to step t (image statistics of
+        s_t, sigma_next = the noise sigma step t+1 will use, ||grad_t||), like the values the
+        reference logs at the end of an iteration.  In the fused chain only the pending
+        gradient-norm reduction is flushed; the statistics of the already prepared NEXT image
+        stay pending until its forward."""
+        if self.fused:
+            ops.fused_flush(self.plans[0], self.stats, self.fused_scratch)
         v = self.stats.tolist()
         return dict(sigma=v[L.STAT_SIGMA], sigma_next=v[L.STAT_QERR_STD], qerr_mean=v[L.STAT_QERR_MEAN],
                     qerr_l1=v[L.STAT_QERR_L1], img_loss=v[L.STAT_IMGFIT], x_mean=v[L.STAT_X_MEAN],

@@ -192,22 +192,36 @@ int32_t advx_update(float* p, float* m, float* v, float* grad_p, const float* ma
 int64_t advx_update_scratch_floats(int64_t n);
 
 /* ------------------------------------------- fused fast path (headline config)
- * One call = the whole owned step of attack_model.py:300-346,366-373 for a plan whose
- * resize is the identity (LLaVA at native 336x336), no blur, no crop:
- *   advx_fused_fwd : p,x0 -> out[B, 3*H*W] = (x0+eps*tanh(p)-mean)/std + sigma*noise ; stats
- *   advx_fused_bwd : grad_out[B,3*H*W] -> sum_b, /std, +imgfit', tanh', (mask, AdamW | grad only)
- * With world_size > 1 call advx_fused_bwd with opt = NULL (writes grad_p only), all-reduce
- * grad_p, then advx_update. */
+ * The whole owned step of attack_model.py:300-346,366-373 for a plan whose resize is the
+ * identity (LLaVA at native 336x336), no blur, no crop, no gradient accumulation, as a
+ * software-pipelined pair of launches:
+ *   advx_fused_fwd : out[B, 3*H*W] = v + sigma * N(0,1), v = (x0+eps*tanh(p)-mean)/std and
+ *                    sigma = stats[QERR_STD] (quantise error of the PREVIOUS image, as in
+ *                    attack_model.py:320,373).  v (v_buf) and s = x0+eps*tanh(p) (s_buf) are
+ *                    PREPARED data: written by the previous advx_fused_bwd, or by this call
+ *                    itself when prepared == 0 (first step / p changed elsewhere; one extra
+ *                    small launch).  Leaves the statistics partials of s.
+ *   advx_fused_bwd : reduces those partials (SIGMA <- old QERR_STD, QERR_STD <- new, slots 2..6),
+ *                    then grad_out[B,3*H*W] -> sum_b, /std, +imgfit', tanh', mask, ||g||,
+ *                    optimiser, and from the UPDATED p the next step's s (s_next) and v (v_buf).
+ *                    opt == NULL: gradient only (world_size > 1: all-reduce grad_p, then
+ *                    advx_update; the next advx_fused_fwd must then pass prepared = 0).
+ * The gradient-norm reduction rides in block (0,0) of the next advx_fused_fwd, so a step is
+ * two launches; slot 7 lags until then or until advx_fused_flush.  After advx_fused_bwd of
+ * step t every other slot refers to step t.  `scratch` must be ZERO-INITIALISED once and kept
+ * for the life of the loop.  advx_fused_flush reduces the pending gradient norm and, with
+ * image_too != 0 (only meaningful between a fused_fwd and its fused_bwd), the image statistics. */
 int32_t advx_fused_supported(const advx_plan* plan);
 int32_t advx_fused_fwd(advx_plan* plan, const float* p, const float* x0, float epsilon, int32_t batch,
                        const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset,
-                       float* out, float* s_out /* nullable: x0+eps*tanh(p), [3,H,W] */, float* stats,
+                       float* out, float* s_buf, float* v_buf, int32_t prepared, float* stats,
                        float* scratch, void* stream);
 int32_t advx_fused_bwd(advx_plan* plan, const float* grad_out, int32_t batch, float* p, const float* x0,
                        float epsilon, float imgfit_scale, const float* mask, float* m, float* v,
-                       float* grad_p, const advx_opt_scalars* opt, float* stats, float* scratch,
-                       void* stream);
+                       float* grad_p, const advx_opt_scalars* opt, float* s_next, float* v_buf,
+                       float* stats, float* scratch, void* stream);
 int64_t advx_fused_scratch_floats(const advx_plan* plan);
+int32_t advx_fused_flush(advx_plan* plan, float* stats, float* scratch, int32_t image_too, void* stream);
 
 /* ------------------------------------------------- single ops (unit tests)
  * Same kernels the calls above launch, exposed one by one. */
