@@ -74,10 +74,14 @@ SIGNATURES = {
     "advx_update": (_I32, [_P, _P, _P, _P, _P, _I64, C.POINTER(OptScalars), _P, _P, _P]),
     "advx_update_scratch_floats": (_I64, [_I64]),
     "advx_fused_supported": (_I32, [_P]),
-    "advx_fused_fwd": (_I32, [_P, _P, _P, _F, _I32, _P, _I32, _U64, _U64, _P, _P, _P, _I32, _P, _P, _P]),
+    "advx_fused_fwd": (_I32, [_P, _P, _P, _F, _I32, _P, _I32, _U64, _U64, _P, _P, _P, _I32, _I32, _P, _P, _P]),
     "advx_fused_bwd": (_I32, [_P, _P, _I32, _P, _P, _F, _F, _P, _P, _P, _P, C.POINTER(OptScalars), _P, _P, _P, _P, _P]),
     "advx_fused_scratch_floats": (_I64, [_P]),
     "advx_fused_flush": (_I32, [_P, _P, _P, _I32, _P]),
+    "advx_fused_step": (_I32, [_P, _P, _I32, _P, _P, _F, _F, _P, _P, _P, _P, C.POINTER(OptScalars), _P, _I32, _U64, _U64,
+                               _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
+    "advx_fused_step_rows": (_I32, [_P, _PI32, _PI32]),
+    "advx_fused_step_flush": (_I32, [_P, _I32, _I32, _P, _P, _P]),
     "advx_tanh_fwd": (_I32, [_P, _F, _P, _I64, _P]),
     "advx_tanh_bwd": (_I32, [_P, _P, _F, _P, _I64, _P]),
     "advx_blur_fwd": (_I32, [_P, _I32, _I32, _I32, _F, _P, _P]),

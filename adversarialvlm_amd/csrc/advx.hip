@@ -769,12 +769,17 @@ extern "C" int32_t advx_fused_supported(const advx_plan* p) {
   return (p->info.kind == ADVX_KIND_LLAVA && s.src_h == s.res_h && s.src_w == s.res_w && ((s.src_h * s.src_w) % 4 == 0)) ? 1 : 0;
 }
 
-// scratch of the fused pair: [FusedHeader][image partials: fwd_blocks x 6 doubles][norm partials]
+// scratch of the fused kernels:
+//   [FusedHeader][image rows 0][image rows 1][norm rows 0][norm rows 1]
+// each row set has one row per 256 pixels; the two-launch pair uses set 0 only, the
+// one-launch step ping-pongs between the sets.
 namespace {
 struct FusedScratch {
   FusedHeader* hdr;
-  double* img_partials;
-  double* norm_partials;
+  double* img_partials;   // = img_rows[0]
+  double* norm_partials;  // = norm_rows[0]
+  double* img_rows[2];
+  double* norm_rows[2];
   int fwd_blocks, bwd_blocks;
 };
 FusedScratch carve_fused(const advx_plan* p, float* scratch) {
@@ -783,8 +788,13 @@ FusedScratch carve_fused(const advx_plan* p, float* scratch) {
   f.fwd_blocks = (int)((n4 + kBlock - 1) / kBlock);
   f.bwd_blocks = (int)((n4 + kWave - 1) / kWave);
   f.hdr = reinterpret_cast<FusedHeader*>(scratch);
-  f.img_partials = reinterpret_cast<double*>(scratch + sizeof(FusedHeader) / sizeof(float));
-  f.norm_partials = f.img_partials + (size_t)kStatSlots * f.bwd_blocks;  // image rows: one per 256 pixels
+  double* d = reinterpret_cast<double*>(scratch + sizeof(FusedHeader) / sizeof(float));
+  f.img_rows[0] = d;
+  f.img_rows[1] = f.img_rows[0] + (size_t)kStatSlots * f.bwd_blocks;
+  f.norm_rows[0] = f.img_rows[1] + (size_t)kStatSlots * f.bwd_blocks;
+  f.norm_rows[1] = f.norm_rows[0] + f.bwd_blocks;
+  f.img_partials = f.img_rows[0];
+  f.norm_partials = f.norm_rows[0];
   return f;
 }
 }  // namespace
@@ -792,10 +802,8 @@ FusedScratch carve_fused(const advx_plan* p, float* scratch) {
 extern "C" int64_t advx_fused_scratch_floats(const advx_plan* p) {
   if (!p) return 0;
   long long n4 = (3LL * p->info.in_h * p->info.in_w) >> 2;
-  long long fwd_blocks = (n4 + kBlock - 1) / kBlock;
   long long bwd_blocks = (n4 + kWave - 1) / kWave;
-  (void)fwd_blocks;
-  return (long long)(sizeof(FusedHeader) / sizeof(float)) + 2 * kStatSlots * bwd_blocks + 2 * bwd_blocks + 256;
+  return (long long)(sizeof(FusedHeader) / sizeof(float)) + 2 * (2 * kStatSlots * bwd_blocks) + 2 * (2 * bwd_blocks) + 256;
 }
 
 static FusedGeom fused_geom(const advx_plan* p) {
@@ -810,8 +818,10 @@ static FusedGeom fused_geom(const advx_plan* p) {
 
 extern "C" int32_t advx_fused_fwd(advx_plan* p, const float* pp, const float* x0, float eps, int32_t batch,
                                   const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset, float* out,
-                                  float* s_buf, float* v_buf, int32_t prepared, float* stats, float* scratch, void* stream) {
+                                  float* s_buf, float* v_buf, int32_t prepared, int32_t parity, float* stats,
+                                  float* scratch, void* stream) {
   REQUIRE(p && pp && x0 && out && stats && scratch && s_buf && v_buf, ADVX_E_BADARG, "advx_fused_fwd: null argument");
+  REQUIRE(parity == 0 || parity == 1, ADVX_E_BADARG, "advx_fused_fwd: parity must be 0 or 1");
   REQUIRE(advx_fused_supported(p), ADVX_E_UNSUPPORTED, "advx_fused_fwd: plan is not an identity LLaVA plan");
   REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_fused_fwd: batch out of range");
   REQUIRE(aligned16(out) && aligned16(scratch) && aligned16(v_buf) && aligned16(s_buf) && aligned16(x0) &&
@@ -832,7 +842,7 @@ extern "C" int32_t advx_fused_fwd(advx_plan* p, const float* pp, const float* x0
   int noise = unit_noise ? 1 : (use_philox ? 2 : 0);
 #define ADVX_FF(N)                                                                                               \
   hipLaunchKernelGGL(k_fused_fwd<N>, grid, dim3(kBlock), 0, st, (const float*)v_buf, (const float*)s_buf, x0, n, batch, \
-                     bps, stats, unit_noise, seed, offset, out, f.hdr, f.img_partials, (const double*)f.norm_partials)
+                     bps, stats, unit_noise, seed, offset, out, f.hdr, f.img_rows[parity], (const double*)f.norm_partials)
   if (noise == 0) ADVX_FF(0); else if (noise == 1) ADVX_FF(1); else ADVX_FF(2);
 #undef ADVX_FF
   LAUNCH_CHECK();
@@ -866,6 +876,64 @@ extern "C" int32_t advx_fused_bwd(advx_plan* p, const float* g, int32_t batch, f
                        mask, m, v, grad_p, none, s_next, v_buf, f.norm_partials, stats, f.hdr,
                        (const double*)f.img_partials);
   }
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_fused_step(advx_plan* p, const float* g, int32_t batch, float* pp, const float* x0, float eps,
+                                   float imgfit_scale, const float* mask, float* m, float* v, float* grad_p,
+                                   const advx_opt_scalars* opt, const float* unit_noise_next, int32_t use_philox,
+                                   uint64_t seed, uint64_t offset_next, float* out_next, float* s_next, float* v_buf,
+                                   int32_t parity, int32_t image_rows_in, int32_t norm_rows_in, float* stats,
+                                   float* scratch, void* stream) {
+  REQUIRE(p && g && pp && x0 && mask && grad_p && opt && out_next && s_next && v_buf && stats && scratch, ADVX_E_BADARG,
+          "advx_fused_step: null argument");
+  REQUIRE(advx_fused_supported(p), ADVX_E_UNSUPPORTED, "advx_fused_step: plan is not an identity LLaVA plan");
+  REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_fused_step: batch out of range");
+  REQUIRE(parity == 0 || parity == 1, ADVX_E_BADARG, "advx_fused_step: parity must be 0 or 1");
+  REQUIRE(opt->apply, ADVX_E_UNSUPPORTED, "advx_fused_step always takes the optimiser step");
+  REQUIRE(aligned16(g) && aligned16(out_next) && aligned16(scratch) && (!unit_noise_next || aligned16(unit_noise_next)),
+          ADVX_E_BADARG, "advx_fused_step: pointers must be 16-byte aligned");
+  int32_t rc = check_opt(opt, m, v);
+  if (rc) return rc;
+  FusedScratch f = carve_fused(p, scratch);
+  REQUIRE(image_rows_in >= 1 && image_rows_in <= f.bwd_blocks && norm_rows_in >= 0 && norm_rows_in <= f.bwd_blocks,
+          ADVX_E_BADARG, "advx_fused_step: row counts out of range");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = 3LL * p->info.in_h * p->info.in_w;
+  const float c_fit = imgfit_scale / (float)n;
+  StepRows rows;
+  rows.img_in = f.img_rows[parity];
+  rows.img_rows_in = image_rows_in;
+  rows.img_out = f.img_rows[1 - parity];
+  rows.norm_in = f.norm_rows[parity];
+  rows.norm_rows_in = norm_rows_in;
+  rows.norm_out = f.norm_rows[1 - parity];
+  int noise = unit_noise_next ? 1 : (use_philox ? 2 : 0);
+#define ADVX_FS(N)                                                                                                   \
+  hipLaunchKernelGGL(k_fused_step<N>, dim3(f.bwd_blocks), dim3(kBlock), 0, st, g, batch, pp, x0, eps, fused_geom(p), c_fit, \
+                     mask, m, v, grad_p, to_dev(opt), s_next, v_buf, unit_noise_next, seed, offset_next, out_next, rows, stats)
+  if (noise == 0) ADVX_FS(0); else if (noise == 1) ADVX_FS(1); else ADVX_FS(2);
+#undef ADVX_FS
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_fused_step_rows(const advx_plan* p, int32_t* rows_after_fwd, int32_t* rows_after_step) {
+  REQUIRE(p && rows_after_fwd && rows_after_step, ADVX_E_BADARG, "advx_fused_step_rows: null argument");
+  long long n4 = (3LL * p->info.in_h * p->info.in_w) >> 2;
+  *rows_after_fwd = (int32_t)((n4 + kBlock - 1) / kBlock);
+  *rows_after_step = (int32_t)((n4 + kWave - 1) / kWave);
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_fused_step_flush(advx_plan* p, int32_t parity, int32_t norm_rows, float* stats, float* scratch,
+                                         void* stream) {
+  REQUIRE(p && stats && scratch && (parity == 0 || parity == 1), ADVX_E_BADARG, "advx_fused_step_flush: bad argument");
+  FusedScratch f = carve_fused(p, scratch);
+  REQUIRE(norm_rows >= 0 && norm_rows <= f.bwd_blocks, ADVX_E_BADARG, "advx_fused_step_flush: row count out of range");
+  hipLaunchKernelGGL(k_step_flush, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, (const double*)f.norm_rows[parity], norm_rows,
+                     stats);
   LAUNCH_CHECK();
   return ADVX_OK;
 }

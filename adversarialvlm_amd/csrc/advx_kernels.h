@@ -761,6 +761,138 @@ __global__ void __launch_bounds__(kBlock) k_fused_bwd(const float* __restrict__ 
   if (UPDATE) block_sum_store<1>(nacc, norm_partials + blockIdx.x);
 }
 
+// ------------------------------------------------------------------- one launch per step
+// k_fused_step = k_fused_bwd(t) + k_fused_fwd(t+1) for the same 256 pixels, in one block:
+//   A  stream-read g_t[:, block] (the 4 waves split the batch), reduce in LDS
+//   B  per pixel: /std, image-fit term, tanh', mask, ||g||, optimiser -> p_{t+1};
+//      s_{t+1}, v_{t+1}; statistics partials of s_{t+1}
+//   C  stream-write out_{t+1}[:, block] = v_{t+1} + sigma_{t+1} * N(0,1) (waves split the batch)
+// sigma_{t+1} = std(|q(s_t) - s_t|) needs a global reduction over s_t: its partial rows were
+// left by the PREVIOUS launch (kernel boundary = visibility), and every block re-reduces
+// the two columns it needs in the same fixed order - redundant L2 reads instead of a grid
+// barrier.  Partial rows are double-buffered (`rows_in` / `rows_out`) because early blocks of
+// this launch write the next rows while late blocks still read the current ones.  Block 0
+// also publishes the statistics of s_t and ||g_{t-1}|| to `stats`.
+// With ~5 blocks resident per CU and phases A (memory) and C (VALU + stores) alternating,
+// the load stream of one block overlaps the noise generation of another.
+struct StepRows {
+  const double* img_in;    // [img_rows_in][kStatSlots]  statistics partials of s_t
+  int img_rows_in;
+  double* img_out;         // [gridDim.x][kStatSlots]    statistics partials of s_{t+1}
+  const double* norm_in;   // [norm_rows_in]             sum-of-squares partials of step t-1 (0 rows: none)
+  int norm_rows_in;
+  double* norm_out;        // [gridDim.x]
+};
+
+template <int NOISE>
+__global__ void __launch_bounds__(kBlock) k_fused_step(const float* __restrict__ g, int batch, float* __restrict__ p,
+                                                       const float* __restrict__ x0, float eps, FusedGeom geo,
+                                                       float c_fit, const float* __restrict__ mask,
+                                                       float* __restrict__ m, float* __restrict__ v,
+                                                       float* __restrict__ grad_p, OptScalars o,
+                                                       float* __restrict__ s_next, float* __restrict__ v_buf,
+                                                       const float* __restrict__ unit_noise, unsigned long long seed,
+                                                       unsigned long long offset, float* __restrict__ out,
+                                                       StepRows rows, float* __restrict__ stats) {
+  __shared__ float4 part4[kBlock / kWave][kWave];
+  __shared__ float4 vsh4[kWave];
+  __shared__ double sig2[2];
+  const long long n = 3LL * geo.plane;
+  const long long n4 = n >> 2;
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  const long long q = (long long)blockIdx.x * kWave + lane;
+  const long long i = (long long)blockIdx.x * (kWave * 4) + threadIdx.x;
+  // ---- prefetch this thread's pixel state
+  float pp = 0.f, xv = 0.f, mk = 0.f, mm = 0.f, vv = 0.f;
+  if (i < n) {
+    pp = p[i];
+    xv = x0[i];
+    mk = mask[i];
+    if (o.kind == 0) {
+      mm = m[i];
+      vv = v[i];
+    }
+  }
+  // ---- sigma_{t+1}: fixed-order reduction of columns 0,1 of the current partial rows
+  {
+    double acc[2] = {0.0, 0.0};
+    for (int r = threadIdx.x; r < rows.img_rows_in; r += kBlock) {
+      acc[0] += rows.img_in[(size_t)r * kStatSlots + 0];
+      acc[1] += rows.img_in[(size_t)r * kStatSlots + 1];
+    }
+    block_sum_store<2>(acc, sig2);
+  }
+  double N = (double)n;
+  double var_d = (n > 1) ? (sig2[1] - sig2[0] * sig2[0] / N) / (N - 1.0) : 0.0;
+  const float sigma = (float)sqrt(var_d > 0.0 ? var_d : 0.0);
+  if (blockIdx.x == 0) {
+    // publish the statistics of s_t (rotating SIGMA) and the previous step's gradient norm
+    finalize_image_block<true>(rows.img_in, rows.img_rows_in, n, stats);
+    if (rows.norm_rows_in > 0) finalize_norm_block(rows.norm_in, rows.norm_rows_in, stats);
+  }
+  // ---- A: batch reduction
+  float4 a = make_float4(0, 0, 0, 0);
+  if (q < n4) a = batch_column_sum(g, batch, n, q << 2, wid, kBlock / kWave);
+  part4[wid][lane] = a;
+  __syncthreads();
+  const float(*part)[kWave * 4] = reinterpret_cast<const float(*)[kWave * 4]>(&part4[0][0]);
+  float* vsh = reinterpret_cast<float*>(&vsh4[0]);
+  // ---- B: per-pixel update and preparation
+  double nacc[1] = {0.0};
+  double sacc[kStatSlots] = {0, 0, 0, 0, 0, 0};
+  float vn = 0.0f;
+  if (i < n) {
+    float gs = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+    const int c = (int)(i / geo.plane);
+    const float sd = geo.stdv[c];
+    float t = tanhf(pp);
+    float s = xv + eps * t;
+    float gx = gs / sd + imgfit_grad(s, c_fit);
+    float gp = ((gx * eps) * (1.0f - t * t)) * mk;
+    nacc[0] = (double)gp * (double)gp;
+    grad_p[i] = gp;
+    if (o.kind == 0) {
+      adamw_element(pp, mm, vv, gp, o);
+      p[i] = pp; m[i] = mm; v[i] = vv;
+    } else {
+      float sg = (gp > 0.0f) ? 1.0f : ((gp < 0.0f) ? -1.0f : 0.0f);
+      pp = pp - o.lr * sg;
+      p[i] = pp;
+    }
+    float xn = eps * tanhf(pp);
+    float sn = xv + xn;
+    vn = (sn - geo.mean[c]) / sd;
+    s_next[i] = sn;
+    v_buf[i] = vn;
+    stat_accumulate(sn, xn, sacc);
+  }
+  vsh[threadIdx.x] = vn;
+  block_sum_store<1>(nacc, rows.norm_out + blockIdx.x);
+  block_sum_store<kStatSlots>(sacc, rows.img_out + (size_t)blockIdx.x * kStatSlots);  // ends with a barrier: vsh visible
+  // ---- C: emit the next forward's rows of this block
+  if (q < n4) {
+    const float4 v4 = vsh4[lane];
+    const long long i0 = q << 2;
+    for (int b = wid; b < batch; b += kBlock / kWave) {
+      float4 ov = v4;
+      if (NOISE == 1) {
+        float4 z = *reinterpret_cast<const float4*>(unit_noise + (size_t)b * n + i0);
+        ov = make_float4(v4.x + z.x * sigma, v4.y + z.y * sigma, v4.z + z.z * sigma, v4.w + z.w * sigma);
+      } else if (NOISE == 2) {
+        float4 z = philox_normal4((unsigned long long)b * (unsigned long long)n4 + (unsigned long long)q, offset, seed);
+        ov = make_float4(v4.x + z.x * sigma, v4.y + z.y * sigma, v4.z + z.z * sigma, v4.w + z.w * sigma);
+      }
+      *reinterpret_cast<float4*>(out + (size_t)b * n + i0) = ov;
+    }
+  }
+}
+
+// finalise pending rows on demand (host reads stats)
+__global__ void __launch_bounds__(kBlock) k_step_flush(const double* __restrict__ norm_rows, int n_norm,
+                                                       float* __restrict__ stats) {
+  if (n_norm > 0) finalize_norm_block(norm_rows, n_norm, stats);
+}
+
 // stats finalisation for the fused pair: image statistics + (optionally) the gradient norm
 __global__ void __launch_bounds__(kBlock) k_philox_normal(float* __restrict__ out, long long n,
                                                           unsigned long long seed, unsigned long long offset) {

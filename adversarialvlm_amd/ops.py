@@ -147,14 +147,16 @@ def fused_flush(plan, stats, scratch, image_too=False):
             "advx_fused_flush")
 
 
-def fused_fwd(plan, p, x0, epsilon, batch, stats, scratch, s_buf, v_buf, prepared, unit_noise=None, philox=None, out=None):
+def fused_fwd(plan, p, x0, epsilon, batch, stats, scratch, s_buf, v_buf, prepared, unit_noise=None, philox=None, out=None,
+              parity=0):
     _require_cuda(p, x0, stats, scratch, s_buf, v_buf)
     if out is None:
         out = torch.empty((batch, plan.out_numel), dtype=torch.float32, device=p.device)
     seed, offset = (philox if philox is not None else (0, 0))
     L.check(L.load().advx_fused_fwd(plan.handle, L.ptr(p), L.ptr(x0), float(epsilon), int(batch), L.ptr(unit_noise),
                                     int(philox is not None), int(seed), int(offset), L.ptr(out), L.ptr(s_buf), L.ptr(v_buf),
-                                    int(bool(prepared)), L.ptr(stats), L.ptr(scratch), _stream(p)), "advx_fused_fwd")
+                                    int(bool(prepared)), int(parity), L.ptr(stats), L.ptr(scratch), _stream(p)),
+            "advx_fused_fwd")
     return out
 
 
@@ -165,6 +167,29 @@ def fused_bwd(plan, grad_out, batch, p, x0, epsilon, imgfit_scale, grad_p, stats
                                     float(imgfit_scale), L.ptr(mask), L.ptr(m), L.ptr(v), L.ptr(grad_p),
                                     C.byref(opt) if opt is not None else None, L.ptr(s_next), L.ptr(v_buf), L.ptr(stats),
                                     L.ptr(scratch), _stream(p)), "advx_fused_bwd")
+
+
+def fused_step_rows(plan):
+    a, b = C.c_int32(), C.c_int32()
+    L.check(L.load().advx_fused_step_rows(plan.handle, C.byref(a), C.byref(b)), "advx_fused_step_rows")
+    return a.value, b.value
+
+
+def fused_step(plan, grad_out, batch, p, x0, epsilon, imgfit_scale, mask, m, v, grad_p, opt, out_next, s_next, v_buf,
+               parity, image_rows_in, norm_rows_in, stats, scratch, unit_noise_next=None, philox=None):
+    """bwd(t) + fwd(t+1) in one launch: grad_out of step t in, pixel_values of step t+1 out."""
+    _require_cuda(grad_out, p, x0, grad_p, out_next, stats, scratch)
+    seed, offset = (philox if philox is not None else (0, 0))
+    L.check(L.load().advx_fused_step(plan.handle, L.ptr(_f32c(grad_out)), int(batch), L.ptr(p), L.ptr(x0), float(epsilon),
+                                     float(imgfit_scale), L.ptr(mask), L.ptr(m), L.ptr(v), L.ptr(grad_p), C.byref(opt),
+                                     L.ptr(unit_noise_next), int(philox is not None), int(seed), int(offset),
+                                     L.ptr(out_next), L.ptr(s_next), L.ptr(v_buf), int(parity), int(image_rows_in),
+                                     int(norm_rows_in), L.ptr(stats), L.ptr(scratch), _stream(p)), "advx_fused_step")
+
+
+def fused_step_flush(plan, parity, norm_rows, stats, scratch):
+    L.check(L.load().advx_fused_step_flush(plan.handle, int(parity), int(norm_rows), L.ptr(stats), L.ptr(scratch),
+                                           _stream(stats)), "advx_fused_step_flush")
 
 
 # ------------------------------------------------------------------------ single ops

@@ -10,11 +10,15 @@ and `crossattack_models.py:329-406,425-432` (several models):
                        blur^T, tanh' -> grad_p ; [all-reduce over the DP group] ;
                        mask, ||g||, AdamW|sign, StepLR                   (HIP)
 
-Two kernel chains implement this:
+Three kernel chains implement this, chosen at construction (`self.mode`):
   * generic  - any plan(s), blur, crop, gradient accumulation (advx_image_* / advx_emit /
                advx_collect / advx_update);
-  * fused    - one identity-resize LLaVA plan without blur/crop/accumulation: two launches
-               per step (advx_fused_fwd / advx_fused_bwd), chosen at construction.
+  * pair     - one identity-resize LLaVA plan without blur/crop/accumulation: two launches
+               per step (advx_fused_fwd / advx_fused_bwd); the form data parallelism uses,
+               with the gradient all-reduce between the backward and advx_update;
+  * step     - same plans on one GPU: ONE launch per step (advx_fused_step): the backward of
+               step t and the forward of step t+1 run in the same kernel, so forward() of
+               step t+1 only hands out the tensor that backward_update() of step t produced.
 All statistics stay on the device (`self.stats`); nothing here synchronises the stream.
 """
 import torch
@@ -27,7 +31,7 @@ class PixelPGD:
     def __init__(self, x0, plans, epsilon=0.5, lr=1e-2, sigma0=1e-3, mask=None, scheduler_step_size=100,
                  scheduler_gamma=1.0, grad_accum_steps=1, blur_kernel=None, use_crop=False, model_weights=None,
                  optimizer="adamw", cross_mode=False, betas=(0.9, 0.999), adam_eps=1e-8, weight_decay=1e-2, seed=0,
-                 process_group=None, allow_fused=True):
+                 process_group=None, allow_fused=True, fused_mode="auto"):
         if not x0.is_cuda:
             raise L.AdvxError("PixelPGD needs x0 on a ROCm device (there is no CPU fallback)")
         if not isinstance(plans, (list, tuple)):
@@ -67,9 +71,24 @@ class PixelPGD:
         self.fused = bool(allow_fused and len(self.plans) == 1 and self.plans[0].fused_supported()
                           and blur_kernel is None and not self.use_crop and self.accum == 1)
         self.upd_scratch = ops.update_scratch(self.p.numel(), dev)
+        if fused_mode not in ("auto", "pair", "step"):
+            raise ValueError("fused_mode must be auto, pair or step")
+        if not self.fused:
+            self.mode = "generic"
+        elif fused_mode == "auto":
+            self.mode = "step" if self.world == 1 else "pair"
+        else:
+            if fused_mode == "step" and self.world > 1:
+                raise L.AdvxError("the one-launch step cannot host the gradient all-reduce: use fused_mode='pair'")
+            self.mode = fused_mode
         if self.fused:
             # the forward reads its sigma from slot QERR_STD (the previous image's quantise error)
             self.stats[L.STAT_QERR_STD] = float(sigma0)
+            self.par = 0                  # row set holding the statistics rows of the current image
+            self.rows_fwd, self.rows_step = ops.fused_step_rows(self.plans[0])
+            self.img_rows = 0
+            self.norm_rows = 0
+            self._out_next = None
             self.fused_scratch = ops.fused_scratch(self.plans[0], dev)
             self.s_bufs = [torch.empty_like(self.x0), torch.empty_like(self.x0)]
             self.s_cur = 0               # s_bufs[s_cur] = image of the prepared / latest forward
@@ -136,12 +155,22 @@ class PixelPGD:
             if crop is not None:
                 raise L.AdvxError("this engine was built for the fused chain: construct with use_crop=True to crop")
             pl = self.plans[0]
-            ph = None if (unit_noises[0] is not None or not use_philox) else (self.seed, self.iteration)
-            out = ops.fused_fwd(pl, self.p, self.x0, self.eps, batches[0], self.stats, self.fused_scratch,
-                                self.s_bufs[self.s_cur], self.v_buf, self.prepared, unit_noise=unit_noises[0], philox=ph)
-            self.prepared = True
+            B = batches[0]
+            shape = (B * pl.out_shape[0],) + pl.out_shape[1:]
+            if (self.mode == "step" and self._out_next is not None and unit_noises[0] is None
+                    and self._out_next.shape[0] == B and (use_philox or self._out_kind != "philox")):
+                # already emitted by the previous backward_update (same launch as its update)
+                out, self._out_next = self._out_next, None
+            else:
+                ph = None if (unit_noises[0] is not None or not use_philox) else (self.seed, self.iteration)
+                out = ops.fused_fwd(pl, self.p, self.x0, self.eps, B, self.stats, self.fused_scratch,
+                                    self.s_bufs[self.s_cur], self.v_buf, self.prepared, unit_noise=unit_noises[0],
+                                    philox=ph, parity=self.par if self.mode == "step" else 0)
+                self.prepared = True
+                self.img_rows = self.rows_fwd
+                self._out_next = None
             self.s = self.s_bufs[self.s_cur]
-            outs.append(out.view((batches[0] * pl.out_shape[0],) + pl.out_shape[1:]))
+            outs.append(out.view(shape))
             self._last = dict(batches=list(batches))
             return outs
         blur = (self.blur_kernel, blur_sigma) if self.blur_kernel is not None else None
@@ -156,9 +185,11 @@ class PixelPGD:
         return outs
 
     # ----------------------------------------------------------------- backward
-    def backward_update(self, grads):
+    def backward_update(self, grads, next_unit_noise=None, next_batch=None, use_philox=True):
         """grads[i] = d(loss)/d(pixel_values_i) as produced by autograd with the loss already
-        multiplied by loss_scale(i)."""
+        multiplied by loss_scale(i).  In the one-launch `step` chain the same kernel emits the
+        pixel_values of the NEXT step: `next_unit_noise` (parity mode) / Philox noise and
+        `next_batch` (default: same batch) describe that emission."""
         if not isinstance(grads, (list, tuple)):
             grads = [grads]
         st = self._last
@@ -172,7 +203,21 @@ class PixelPGD:
         if self.fused:
             pl, B = self.plans[0], st["batches"][0]
             nxt = 1 - self.s_cur
-            if self.world == 1:
+            if self.mode == "step":
+                Bn = int(next_batch) if next_batch is not None else B
+                if Bn != B:
+                    raise L.AdvxError("the one-launch step emits the next batch with the size of the current one")
+                out_next = torch.empty((B, pl.out_numel), dtype=torch.float32, device=self.p.device)
+                ph = None if (next_unit_noise is not None or not use_philox) else (self.seed, self.iteration + 1)
+                ops.fused_step(pl, grads[0], B, self.p, self.x0, self.eps, self.imgfit_scale(), self.mask, self.m, self.v,
+                               self.grad, opt, out_next, self.s_bufs[nxt], self.v_buf, self.par, self.img_rows,
+                               self.norm_rows, self.stats, self.fused_scratch, unit_noise_next=next_unit_noise, philox=ph)
+                self.par = 1 - self.par
+                self.img_rows = self.rows_step
+                self.norm_rows = self.rows_step
+                self._out_next = out_next
+                self._out_kind = "given" if next_unit_noise is not None else ("philox" if use_philox else "none")
+            elif self.world == 1:
                 ops.fused_bwd(pl, grads[0], B, self.p, self.x0, self.eps, self.imgfit_scale(), self.grad, self.stats,
                               self.fused_scratch, mask=self.mask, m=self.m, v=self.v, opt=opt,
                               s_next=self.s_bufs[nxt], v_buf=self.v_buf)
@@ -210,7 +255,9 @@ class PixelPGD:
         reference logs at the end of an iteration.  In the fused chain only the pending
         gradient-norm reduction is flushed; the statistics of the already prepared NEXT image
         stay pending until its forward."""
-        if self.fused:
+        if self.mode == "step":
+            ops.fused_step_flush(self.plans[0], self.par, self.norm_rows, self.stats, self.fused_scratch)
+        elif self.mode == "pair":
             ops.fused_flush(self.plans[0], self.stats, self.fused_scratch)
         v = self.stats.tolist()
         return dict(sigma=v[L.STAT_SIGMA], sigma_next=v[L.STAT_QERR_STD], qerr_mean=v[L.STAT_QERR_MEAN],

@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="time the generic (unfused) kernel chain instead")
+    ap.add_argument("--chain", default="auto", choices=["auto", "pair", "step"],
+                    help="fused chain: step = one launch per step (single GPU), pair = two launches")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,7 +98,7 @@ def main():
     g = torch.randn(BATCH, 3, H, W, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     plan = Plan.llava(H, W)
     eng = PixelPGD(x0, [plan], epsilon=0.5, lr=1e-2, sigma0=1e-3, seed=1234 + rank, process_group=pg,
-                   allow_fused=not args.no_fused)
+                   allow_fused=not args.no_fused, fused_mode=args.chain)
     # every rank pre-scales its share so that the SUM all-reduce is the DP average
     gs = g * eng.loss_scale(0)
 
@@ -140,9 +142,13 @@ def main():
     bytes_bwd = 4 * (BATCH * n_in + 8 * n_in)          # read B*P_out; p,x0,mask,m,v in; p,m,v(+grad) out
     bytes_step = 4 * (2 * BATCH * n_in + 10 * n_in)
     steps_per_s = args.steps / dt
-    dom_name, dom_bytes, dom_ms = (("k_fused_fwd", bytes_fwd, fwd_avg) if fwd_avg >= bwd_avg
-                                   else ("k_fused_bwd", bytes_bwd, bwd_avg))
-    if args.no_fused:
+    if eng.mode == "step":
+        # one launch per step: backward of step t + forward of step t+1 in the same kernel
+        dom_name, dom_bytes, dom_ms = "k_fused_step", bytes_step, fwd_avg + bwd_avg
+    else:
+        dom_name, dom_bytes, dom_ms = (("k_fused_fwd", bytes_fwd, fwd_avg) if fwd_avg >= bwd_avg
+                                       else ("k_fused_bwd", bytes_bwd, bwd_avg))
+    if eng.mode == "generic":
         dom_name = "generic chain (" + dom_name.replace("k_fused_", "") + " half)"
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     if rank == 0:
@@ -158,7 +164,7 @@ def main():
                                    "owned pixel path isolated (synthetic upstream gradient in HBM; VLM fwd/bwd not included)",
                        "prompts_per_gpu": BATCH, "global_prompts": BATCH * world, "image": [3, H, W],
                        "noise": "in-kernel Philox4x32-10", "optimizer": "AdamW", "parallelism": f"dp{world}",
-                       "path": "generic" if args.no_fused else "fused"},
+                       "path": eng.mode},
             "steps_per_s": round(steps_per_s, 1),
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,

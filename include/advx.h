@@ -214,14 +214,36 @@ int64_t advx_update_scratch_floats(int64_t n);
 int32_t advx_fused_supported(const advx_plan* plan);
 int32_t advx_fused_fwd(advx_plan* plan, const float* p, const float* x0, float epsilon, int32_t batch,
                        const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset,
-                       float* out, float* s_buf, float* v_buf, int32_t prepared, float* stats,
-                       float* scratch, void* stream);
+                       float* out, float* s_buf, float* v_buf, int32_t prepared,
+                       int32_t parity /* row set that receives the statistics rows: 0 for the pair */,
+                       float* stats, float* scratch, void* stream);
 int32_t advx_fused_bwd(advx_plan* plan, const float* grad_out, int32_t batch, float* p, const float* x0,
                        float epsilon, float imgfit_scale, const float* mask, float* m, float* v,
                        float* grad_p, const advx_opt_scalars* opt, float* s_next, float* v_buf,
                        float* stats, float* scratch, void* stream);
 int64_t advx_fused_scratch_floats(const advx_plan* plan);
 int32_t advx_fused_flush(advx_plan* plan, float* stats, float* scratch, int32_t image_too, void* stream);
+
+/* One launch per step (single GPU): advx_fused_step = advx_fused_bwd(step t) followed by
+ * advx_fused_fwd(step t+1) for the same pixels inside one kernel - grad_out of step t in,
+ * pixel_values of step t+1 out - so that the gradient stream of one workgroup overlaps the
+ * noise generation and store stream of another.  The loop is
+ *     advx_fused_fwd (step 0)  ->  VLM  ->  advx_fused_step  ->  VLM  ->  advx_fused_step ...
+ * Partial-reduction rows are double-buffered in `scratch`: `parity` names the set that holds
+ * the statistics rows of the CURRENT image (0 after advx_fused_fwd; flips after every step),
+ * image_rows_in / norm_rows_in their counts (advx_fused_step_rows; norm_rows_in = 0 on the
+ * first step).  The noise of step t+1 uses offset_next.  After the call `stats` describes
+ * step t except slot 7, which holds ||g_{t-1}|| until the next step or advx_fused_step_flush
+ * (parity / norm_rows = the values to be passed to the NEXT advx_fused_step). */
+int32_t advx_fused_step(advx_plan* plan, const float* grad_out, int32_t batch, float* p, const float* x0,
+                        float epsilon, float imgfit_scale, const float* mask, float* m, float* v,
+                        float* grad_p, const advx_opt_scalars* opt, const float* unit_noise_next,
+                        int32_t use_philox, uint64_t seed, uint64_t offset_next, float* out_next,
+                        float* s_next, float* v_buf, int32_t parity, int32_t image_rows_in,
+                        int32_t norm_rows_in, float* stats, float* scratch, void* stream);
+int32_t advx_fused_step_rows(const advx_plan* plan, int32_t* rows_after_fwd, int32_t* rows_after_step);
+int32_t advx_fused_step_flush(advx_plan* plan, int32_t parity, int32_t norm_rows, float* stats,
+                              float* scratch, void* stream);
 
 /* ------------------------------------------------- single ops (unit tests)
  * Same kernels the calls above launch, exposed one by one. */

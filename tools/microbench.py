@@ -54,13 +54,23 @@ def main():
         t2 = timeit(lambda: ops.fused_fwd(plan, p, x0, 0.5, B, stats, scr, s, vb, True, philox=(1, 2), out=out))
         t3 = timeit(lambda: ops.fused_bwd(plan, g, B, p, x0, 0.5, 1.0, gp, stats, scr, mask=mask, m=m, v=v, opt=o, s_next=s, v_buf=vb))
         t4 = timeit(lambda: ops.fused_bwd(plan, g, B, p, x0, 0.5, 1.0, gp, stats, scr))
+        rf, rs = ops.fused_step_rows(plan)
+        ops.fused_fwd(plan, p, x0, 0.5, B, stats, scr, s, vb, False, out=out, parity=0)
+        st = dict(par=0, img=rf, nrm=0)
+
+        def step(noise):
+            ops.fused_step(plan, g, B, p, x0, 0.5, 1.0, mask, m, v, gp, o, out, s, vb, st["par"], st["img"], st["nrm"], stats,
+                           scr, philox=(1, 2) if noise else None)
+            st.update(par=1 - st["par"], img=rs, nrm=rs)
+        t8 = timeit(lambda: step(True))
+        t9 = timeit(lambda: step(False))
         t5 = timeit(lambda: ops.batch_reduce(g))
         ws = torch.empty(plan.workspace_floats, device=dev)
         t6 = timeit(lambda: ops.emit(plan, x0, B, sigma_dev=stats[:1], philox=(1, 2), workspace=ws, out=out))
         t7 = timeit(lambda: out.copy_(g))
         print(f"B={B:3d} ({mb:6.1f} MB): fused_fwd none {t0:6.1f}us  given-noise {t1:6.1f}us  philox {t2:6.1f}us | "
               f"fused_bwd+adamw {t3:6.1f}us  grad-only {t4:6.1f}us | batch_reduce {t5:6.1f}us | emit(philox) {t6:6.1f}us | "
-              f"torch copy {t7:6.1f}us ({2 * mb / t7:.2f} TB/s r+w)", flush=True)
+              f"torch copy {t7:6.1f}us ({2 * mb / t7:.2f} TB/s r+w) | fused_step philox {t8:6.1f}us  no-noise {t9:6.1f}us", flush=True)
 
 
 if __name__ == "__main__":
