@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -468,7 +469,12 @@ extern "C" int32_t advx_plan_upload(advx_plan* p, void* stream) {
 static void emit_slices(long long n4, int batch, int* gx, int* slices, int* b_per_slice) {
   long long bx = (n4 + kBlock - 1) / kBlock;
   if (bx < 1) bx = 1;
-  int want = (int)std::max<long long>(1, (2048 + bx - 1) / bx);
+  static int target = -1;
+  if (target < 0) {
+    const char* e = std::getenv("ADVX_EMIT_TARGET_BLOCKS");
+    target = e ? std::max(256, std::atoi(e)) : 2048;
+  }
+  int want = (int)std::max<long long>(1, (target + bx - 1) / bx);
   int sl = std::min(batch, want);
   while (sl < batch && batch % sl != 0) ++sl;  // equal slices: no straggler slice
   int bps = (batch + sl - 1) / sl;
@@ -880,6 +886,20 @@ extern "C" int32_t advx_fused_bwd(advx_plan* p, const float* g, int32_t batch, f
   return ADVX_OK;
 }
 
+// persistent grid of the wave-specialised step: a fixed number of 512-thread workgroups per CU
+static int step_grid(int n_groups) {
+  static int per_cu = -1, cus = 0;
+  if (per_cu < 0) {
+    const char* e = std::getenv("ADVX_STEP_BLOCKS_PER_CU");
+    per_cu = e ? std::max(1, std::min(4, std::atoi(e))) : 2;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    if (cus <= 0) cus = 256;
+  }
+  return std::max(1, std::min(n_groups, per_cu * cus));
+}
+
 extern "C" int32_t advx_fused_step(advx_plan* p, const float* g, int32_t batch, float* pp, const float* x0, float eps,
                                    float imgfit_scale, const float* mask, float* m, float* v, float* grad_p,
                                    const advx_opt_scalars* opt, const float* unit_noise_next, int32_t use_philox,
@@ -910,9 +930,11 @@ extern "C" int32_t advx_fused_step(advx_plan* p, const float* g, int32_t batch, 
   rows.norm_rows_in = norm_rows_in;
   rows.norm_out = f.norm_rows[1 - parity];
   int noise = unit_noise_next ? 1 : (use_philox ? 2 : 0);
-#define ADVX_FS(N)                                                                                                   \
-  hipLaunchKernelGGL(k_fused_step<N>, dim3(f.bwd_blocks), dim3(kBlock), 0, st, g, batch, pp, x0, eps, fused_geom(p), c_fit, \
-                     mask, m, v, grad_p, to_dev(opt), s_next, v_buf, unit_noise_next, seed, offset_next, out_next, rows, stats)
+  const int grid = step_grid(f.bwd_blocks);
+#define ADVX_FS(N)                                                                                                      \
+  hipLaunchKernelGGL(k_fused_step_ws<N>, dim3(grid), dim3(kStepThreads), 0, st, g, batch, pp, x0, eps, fused_geom(p), c_fit, \
+                     mask, m, v, grad_p, to_dev(opt), s_next, v_buf, unit_noise_next, seed, offset_next, out_next, rows,  \
+                     stats, f.bwd_blocks)
   if (noise == 0) ADVX_FS(0); else if (noise == 1) ADVX_FS(1); else ADVX_FS(2);
 #undef ADVX_FS
   LAUNCH_CHECK();
@@ -923,7 +945,7 @@ extern "C" int32_t advx_fused_step_rows(const advx_plan* p, int32_t* rows_after_
   REQUIRE(p && rows_after_fwd && rows_after_step, ADVX_E_BADARG, "advx_fused_step_rows: null argument");
   long long n4 = (3LL * p->info.in_h * p->info.in_w) >> 2;
   *rows_after_fwd = (int32_t)((n4 + kBlock - 1) / kBlock);
-  *rows_after_step = (int32_t)((n4 + kWave - 1) / kWave);
+  *rows_after_step = (int32_t)step_grid((int)((n4 + kWave - 1) / kWave));
   return ADVX_OK;
 }
 

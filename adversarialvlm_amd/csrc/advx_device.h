@@ -145,7 +145,7 @@ __device__ inline float wave_sum(float v) {
 // Block-wide sum of NS doubles per thread; thread 0 writes the NS totals to dst.
 template <int NS>
 __device__ inline void block_sum_store(const double (&acc)[NS], double* dst) {
-  __shared__ double red[kBlock / kWave][NS];
+  __shared__ double red[16][NS];  // up to 1024 threads
   int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
@@ -168,9 +168,12 @@ __device__ inline void block_sum_store(const double (&acc)[NS], double* dst) {
 struct Philox {
   uint32_t k0, k1;
 };
+#ifndef ADVX_PHILOX_ROUNDS
+#define ADVX_PHILOX_ROUNDS 10
+#endif
 __device__ inline uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < ADVX_PHILOX_ROUNDS; ++r) {
     // one 32x32->64 multiply (v_mad_u64_u32) per word instead of a mul_hi + mul_lo pair
     unsigned long long p0 = (unsigned long long)0xD2511F53u * (unsigned long long)c.x;
     unsigned long long p1 = (unsigned long long)0xCD9E8D57u * (unsigned long long)c.z;

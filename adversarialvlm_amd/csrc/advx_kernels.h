@@ -887,6 +887,158 @@ __global__ void __launch_bounds__(kBlock) k_fused_step(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------- one launch per step, wave-specialised
+// Same contract as k_fused_step, but built so that the gradient stream and the noise
+// generation really overlap: a persistent 512-thread workgroup whose waves 0-3 (R) reduce and
+// update pixel group j while waves 4-7 (E) emit group j-1, handing v over through a 2-slot
+// LDS ring.  The memory-bound role and the VALU-bound role share every SIMD of the CU at
+// the same time, from the second slot on.  CDNA has one hardware barrier per workgroup, so
+// both roles meet at the same two barriers per slot (E simply splits its batch in two).
+constexpr int kStepThreads = 512;
+
+template <int NOISE>
+__global__ void __launch_bounds__(kStepThreads) k_fused_step_ws(const float* __restrict__ g, int batch,
+                                                                float* __restrict__ p, const float* __restrict__ x0,
+                                                                float eps, FusedGeom geo, float c_fit,
+                                                                const float* __restrict__ mask, float* __restrict__ m,
+                                                                float* __restrict__ v, float* __restrict__ grad_p,
+                                                                OptScalars o, float* __restrict__ s_next,
+                                                                float* __restrict__ v_buf,
+                                                                const float* __restrict__ unit_noise,
+                                                                unsigned long long seed, unsigned long long offset,
+                                                                float* __restrict__ out, StepRows rows,
+                                                                float* __restrict__ stats, int n_groups) {
+  __shared__ float4 part4[4][kWave];
+  __shared__ float4 vring[2][kWave];
+  __shared__ double sig2[2];
+  const long long n = 3LL * geo.plane;
+  const long long n4 = n >> 2;
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  const bool is_r = wid < 4;
+  const int rw = wid & 3;                 // wave index inside its role
+  const int rtid = threadIdx.x & 255;     // thread index inside its role
+  // ---- sigma_{t+1}: every block reduces columns 0,1 of the current rows in the same order
+  {
+    double acc[2] = {0.0, 0.0};
+    for (int r = threadIdx.x; r < rows.img_rows_in; r += kStepThreads) {
+      acc[0] += rows.img_in[(size_t)r * kStatSlots + 0];
+      acc[1] += rows.img_in[(size_t)r * kStatSlots + 1];
+    }
+    block_sum_store<2>(acc, sig2);
+  }
+  const double N = (double)n;
+  const double var_d = (n > 1) ? (sig2[1] - sig2[0] * sig2[0] / N) / (N - 1.0) : 0.0;
+  const float sigma = (float)sqrt(var_d > 0.0 ? var_d : 0.0);
+  if (blockIdx.x == 0) {
+    finalize_image_block<true>(rows.img_in, rows.img_rows_in, n, stats);
+    if (rows.norm_rows_in > 0) finalize_norm_block(rows.norm_in, rows.norm_rows_in, stats);
+  }
+  const int G = (n_groups > (int)blockIdx.x) ? (n_groups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int per_wave = (batch + 3) >> 2;      // emission iterations of one E wave
+  const int half = (per_wave + 1) >> 1;
+  double nacc[1] = {0.0};
+  double sacc[kStatSlots] = {0, 0, 0, 0, 0, 0};
+  float pp = 0.f, xv = 0.f, mk = 0.f, mm = 0.f, vv = 0.f;
+  for (int j = 0; j <= G; ++j) {
+    const int grp_r = (int)blockIdx.x + j * (int)gridDim.x;          // group the R waves work on
+    const int grp_e = (int)blockIdx.x + (j - 1) * (int)gridDim.x;    // group the E waves emit
+    const long long ir = (long long)grp_r * 256 + rtid;              // pixel owned by an R thread
+    float4 v4 = make_float4(0, 0, 0, 0);
+    long long qe = 0;
+    // ------------------------------------------------------------------ first half
+    if (is_r) {
+      if (j < G) {
+        if (ir < n) {
+          pp = p[ir];
+          xv = x0[ir];
+          mk = mask[ir];
+          if (o.kind == 0) {
+            mm = m[ir];
+            vv = v[ir];
+          }
+        }
+        const long long q = (long long)grp_r * kWave + lane;
+        float4 a = make_float4(0, 0, 0, 0);
+        if (q < n4) a = batch_column_sum(g, batch, n, q << 2, rw, 4);
+        part4[rw][lane] = a;
+      }
+    } else if (j >= 1) {
+      qe = (long long)grp_e * kWave + lane;
+      v4 = vring[(j - 1) & 1][lane];
+      if (qe < n4) {
+        for (int t = 0; t < half; ++t) {
+          const int b = rw + 4 * t;
+          if (b < batch) {
+            float4 ov = v4;
+            if (NOISE == 1) {
+              float4 z = *reinterpret_cast<const float4*>(unit_noise + (size_t)b * n + (qe << 2));
+              ov = make_float4(v4.x + z.x * sigma, v4.y + z.y * sigma, v4.z + z.z * sigma, v4.w + z.w * sigma);
+            } else if (NOISE == 2) {
+              float4 z = philox_normal4((unsigned long long)b * (unsigned long long)n4 + (unsigned long long)qe, offset, seed);
+              ov = make_float4(v4.x + z.x * sigma, v4.y + z.y * sigma, v4.z + z.z * sigma, v4.w + z.w * sigma);
+            }
+            *reinterpret_cast<float4*>(out + (size_t)b * n + (qe << 2)) = ov;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ----------------------------------------------------------------- second half
+    if (is_r) {
+      if (j < G) {
+        const float(*part)[kWave * 4] = reinterpret_cast<const float(*)[kWave * 4]>(&part4[0][0]);
+        float vn = 0.0f;
+        if (ir < n) {
+          float gs = ((part[0][rtid] + part[1][rtid]) + part[2][rtid]) + part[3][rtid];
+          const int c = (int)(ir / geo.plane);
+          const float sd = geo.stdv[c];
+          float t = tanhf(pp);
+          float s = xv + eps * t;
+          float gx = gs / sd + imgfit_grad(s, c_fit);
+          float gp = ((gx * eps) * (1.0f - t * t)) * mk;
+          nacc[0] += (double)gp * (double)gp;
+          grad_p[ir] = gp;
+          if (o.kind == 0) {
+            adamw_element(pp, mm, vv, gp, o);
+            p[ir] = pp; m[ir] = mm; v[ir] = vv;
+          } else {
+            float sg = (gp > 0.0f) ? 1.0f : ((gp < 0.0f) ? -1.0f : 0.0f);
+            pp = pp - o.lr * sg;
+            p[ir] = pp;
+          }
+          float xn = eps * tanhf(pp);
+          float sn = xv + xn;
+          vn = (sn - geo.mean[c]) / sd;
+          s_next[ir] = sn;
+          v_buf[ir] = vn;
+          stat_accumulate(sn, xn, sacc);
+        }
+        reinterpret_cast<float*>(&vring[j & 1][0])[rtid] = vn;
+      }
+    } else if (j >= 1) {
+      if (qe < n4) {
+        for (int t = half; t < per_wave; ++t) {
+          const int b = rw + 4 * t;
+          if (b < batch) {
+            float4 ov = v4;
+            if (NOISE == 1) {
+              float4 z = *reinterpret_cast<const float4*>(unit_noise + (size_t)b * n + (qe << 2));
+              ov = make_float4(v4.x + z.x * sigma, v4.y + z.y * sigma, v4.z + z.z * sigma, v4.w + z.w * sigma);
+            } else if (NOISE == 2) {
+              float4 z = philox_normal4((unsigned long long)b * (unsigned long long)n4 + (unsigned long long)qe, offset, seed);
+              ov = make_float4(v4.x + z.x * sigma, v4.y + z.y * sigma, v4.z + z.z * sigma, v4.w + z.w * sigma);
+            }
+            *reinterpret_cast<float4*>(out + (size_t)b * n + (qe << 2)) = ov;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  block_sum_store<1>(nacc, rows.norm_out + blockIdx.x);
+  block_sum_store<kStatSlots>(sacc, rows.img_out + (size_t)blockIdx.x * kStatSlots);
+}
+
 // finalise pending rows on demand (host reads stats)
 __global__ void __launch_bounds__(kBlock) k_step_flush(const double* __restrict__ norm_rows, int n_norm,
                                                        float* __restrict__ stats) {

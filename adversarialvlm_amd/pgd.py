@@ -76,7 +76,9 @@ class PixelPGD:
         if not self.fused:
             self.mode = "generic"
         elif fused_mode == "auto":
-            self.mode = "step" if self.world == 1 else "pair"
+            # measured on MI355X (profiles/r01): the two-launch pair is currently the faster
+            # chain; the one-launch step is kept behind fused_mode="step"
+            self.mode = "pair"
         else:
             if fused_mode == "step" and self.world > 1:
                 raise L.AdvxError("the one-launch step cannot host the gradient all-reduce: use fused_mode='pair'")
