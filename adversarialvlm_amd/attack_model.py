@@ -1,0 +1,305 @@
+"""Single-model universal adversarial-image trainer (reference: src/attack_model.py).
+
+Same entry point (`train(...)`, `main()`), flag names and defaults, the
+same per-step order of operations, the same on-disk artefacts
+(`optimized_image_iter_{k}.png` + fp32 CHW `.bin`, `mask.pt`, `mask.png`, `config.json`).
+What is different underneath:
+  * every pixel-space operation between `p` and `pixel_values`, and back, runs in
+    libadvx_hip.so through `PixelPGD` (no torch arithmetic, no autograd on that path);
+  * no per-step PNG -> disk -> PNG round trip: the quantise-error statistics come from a
+    device-side reduction (the round trip equals uint8 truncation because PNG is lossless);
+  * prompts are tokenised once and cached; statistics stay on the device and are read at
+    logging cadence only; model parameters are frozen;
+  * data parallelism: under torch.distributed every rank owns batch_size/world prompts and the
+    image gradient is all-reduced once per step over RCCL (the reference has no DP).
+"""
+import argparse
+import json
+import math
+import os
+import random
+from datetime import datetime
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import prompts as P
+from .pgd import PixelPGD
+from .processors import load_components
+
+
+# ----------------------------------------------------------------------------- helpers
+def setup_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("the trainer needs a ROCm device: the pixel path has no CPU fallback")
+    return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def create_directory(exp_name, base_path="./runs"):
+    path = os.path.join(base_path, exp_name)
+    os.makedirs(path, exist_ok=True)
+    return path
+
+
+def save_checkpoint(image: Image.Image, tensor: torch.Tensor, path: str, iteration):
+    """attack_model.py:33-36: PNG + raw float32 CHW dump of x0 + x."""
+    image.save(os.path.join(path, f"optimized_image_iter_{iteration}.png"))
+    tensor.detach().cpu().numpy().astype(np.float32).tofile(os.path.join(path, f"optimized_image_iter_{iteration}.bin"))
+
+
+def create_mask(mask_type, mask_size, image_shape, device):
+    """attack_model.py:66-84."""
+    C, H, W = image_shape
+    mask = torch.zeros(image_shape, device=device)
+    if mask_type == "corner":
+        mask[:, :mask_size, :mask_size] = 1.0
+    elif mask_type == "bottom_lines":
+        mask[:, -mask_size:, :] = 1.0
+    elif mask_type == "random_square":
+        i = random.randint(0, H - mask_size)
+        j = random.randint(0, W - mask_size)
+        mask[:, i:i + mask_size, j:j + mask_size] = 1.0
+    else:
+        mask = torch.ones(image_shape, device=device)
+    return mask
+
+
+def random_resized_crop_params(height, width, scale, ratio):
+    """torchvision RandomResizedCrop.get_params (attack_model.py:198-202): draws from torch's
+    global CPU generator like the original; restated from the published algorithm."""
+    area = height * width
+    log_ratio = torch.log(torch.tensor(ratio))
+    for _ in range(10):
+        target_area = area * torch.empty(1).uniform_(scale[0], scale[1]).item()
+        aspect = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])).item()
+        w = int(round(math.sqrt(target_area * aspect)))
+        h = int(round(math.sqrt(target_area / aspect)))
+        if 0 < w <= width and 0 < h <= height:
+            i = torch.randint(0, height - h + 1, size=(1,)).item()
+            j = torch.randint(0, width - w + 1, size=(1,)).item()
+            return i, j, h, w
+    in_ratio = float(width) / float(height)
+    if in_ratio < min(ratio):
+        w = width
+        h = int(round(w / min(ratio)))
+    elif in_ratio > max(ratio):
+        h = height
+        w = int(round(h * max(ratio)))
+    else:
+        w, h = width, height
+    return (height - h) // 2, (width - w) // 2, h, w
+
+
+class JsonlLogger:
+    """Default metrics sink (the reference logs ~20 scalars per step to wandb,
+    attack_model.py:382-407); wandb is used instead when importable and requested."""
+
+    def __init__(self, path, use_wandb=False, config=None, name=None):
+        self.f = open(path, "a")
+        self.wandb = None
+        if use_wandb:
+            try:
+                import wandb
+                wandb.init(project="image_attack_optimization", name=name, config=config)
+                self.wandb = wandb
+            except Exception as e:  # pragma: no cover - wandb absent in the build container
+                print(f"wandb unavailable ({e}); logging to {path}")
+
+    def log(self, data):
+        self.f.write(json.dumps({k: (float(v) if isinstance(v, (int, float)) else v) for k, v in data.items()}) + "\n")
+        self.f.flush()
+        if self.wandb is not None:
+            self.wandb.log(data)
+
+    def close(self):
+        self.f.close()
+        if self.wandb is not None:
+            self.wandb.finish()
+
+
+# ------------------------------------------------------------------------------- train
+def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iterations, save_steps, batch_size,
+          grad_accum_steps, scheduler_step_size, scheduler_gamma, restart_num, mask_type, mask_size, clamp_method,
+          epsilon, sigma, start_from_white, target_text_random, DPO_flag=False, refuse_prob=0.1,
+          use_gaussian_blur=False, gblur_kernel_size=5, gblur_sigma=7, use_local_crop=False, crop_scale_min=0.6,
+          crop_scale_max=1.0, crop_ratio_min=0.75, crop_ratio_max=1.33,
+          # --- additions of this framework (defaults reproduce the reference behaviour)
+          questions_file=None, test_questions_file=None, answers_file=None, optimizer="adamw", log_every=1,
+          use_wandb=False, seed=0, base_path="./runs", components=None, return_engine=False):
+    if clamp_method != "tanh":
+        raise NotImplementedError("Clamping method except tanh are not implemented")       # attack_model.py:186
+    if DPO_flag:
+        raise NotImplementedError("DPO flag is not implemented")                           # attack_model.py:278-279
+    if mask_type == "random_square":
+        raise NotImplementedError("random_square needs a per-step mask move the reference raises on (:295-296)")
+    questions = P.load_pool(questions_file, P.DEFAULT_QUESTIONS)
+    test_questions = P.load_pool(test_questions_file, P.DEFAULT_TEST_QUESTIONS)
+    if target_text_random:
+        target_text = P.load_pool(answers_file, P.DEFAULT_ANSWERS)                         # :147-148
+    if prompt != "list":
+        questions = [prompt]                                                               # :150-151
+
+    device = setup_device()
+    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+    if batch_size % world != 0:
+        raise ValueError("batch_size must be divisible by the number of ranks")
+    local_batch = batch_size // world
+    exp_path = create_directory(exp_name, base_path)
+
+    load_model_and_processor, AdvInputs, DiffProc = components or load_components(model_name)
+    model, processor = load_model_and_processor(model_name, device)
+    model.requires_grad_(False)                                                            # Q6: output-neutral
+    adv_processor = DiffProc(processor.image_processor, device)
+
+    if isinstance(img_orig, Image.Image):
+        original_image = img_orig.convert("RGB")
+    elif os.path.exists(img_orig):
+        original_image = Image.open(img_orig).convert("RGB")
+    elif os.path.exists(os.path.join("./images", img_orig)):
+        original_image = Image.open(os.path.join("./images", img_orig)).convert("RGB")
+    else:
+        raise FileNotFoundError(f"Cannot find {img_orig}")
+    x_0 = adv_processor.pil_to_tensor(original_image, resize=False).to(device)
+    if start_from_white:
+        x_0 = torch.ones_like(x_0)
+    _, H, W = x_0.shape
+
+    if mask_type is not None and mask_size is not None:
+        mask = create_mask(mask_type, mask_size, x_0.shape, device)
+    else:
+        mask = (x_0 != 0).float()                                                          # :208
+    if rank == 0:
+        torch.save(mask.cpu(), os.path.join(exp_path, "mask.pt"))
+        Image.fromarray((mask.permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8)).save(os.path.join(exp_path, "mask.png"))
+
+    plan = adv_processor.plan_for(H, W)
+    engine = PixelPGD(x_0, [plan], epsilon=epsilon, lr=lr, sigma0=sigma, mask=mask,
+                      scheduler_step_size=scheduler_step_size, scheduler_gamma=scheduler_gamma,
+                      grad_accum_steps=grad_accum_steps, blur_kernel=gblur_kernel_size if use_gaussian_blur else None,
+                      use_crop=use_local_crop, optimizer=optimizer, seed=seed + 7919 * rank,
+                      process_group=torch.distributed.group.WORLD if world > 1 else None)
+
+    # shared draws (target text, crop window) come from the global generators, which every
+    # rank seeds identically; prompt sampling uses a rank-local stream
+    random.seed(seed)
+    torch.manual_seed(seed)
+    inputs_processor = AdvInputs(questions=questions, test_questions=test_questions, batch_size=local_batch,
+                                 original_image=original_image, processor=processor, device=device,
+                                 target_text=target_text,
+                                 rng=random.Random(seed * 1000003 + rank) if world > 1 else None)
+    logger = JsonlLogger(os.path.join(exp_path, "metrics.jsonl"), use_wandb and rank == 0,
+                         config=dict(learning_rate=lr, batch_size=batch_size, epsilon=epsilon, sigma=sigma), name=exp_name) \
+        if rank == 0 else None
+
+    global_iteration = 0
+    accumulated_loss = 0.0
+    refuse_flag = False
+    history = []
+    for iteration in range(num_iterations):
+        if target_text_random:
+            inputs_processor.set_target_text(random.choice(inputs_processor.target_texts))  # :283-290
+        inputs = inputs_processor.get_inputs_train()                                        # :292
+        crop = None
+        if use_local_crop:
+            crop = random_resized_crop_params(H, W, (crop_scale_min, crop_scale_max), (crop_ratio_min, crop_ratio_max))
+        pixel_values = engine.forward(local_batch, blur_sigma=float(gblur_sigma) if use_gaussian_blur else None,
+                                      crop=crop)[0]                                         # :300-321 (HIP)
+        pixel_values.requires_grad_(True)
+        inputs["pixel_values"] = pixel_values
+        outputs = model(**inputs)                                                           # :324 (PyTorch-ROCm)
+        logits = outputs.logits[:, :-1, :]
+        loss = inputs_processor.get_loss(logits)                                            # :327
+        loss = -loss if refuse_flag else loss
+        (loss * engine.loss_scale(0)).backward()                                            # :330-332
+        stepped = engine.backward_update([pixel_values.grad])                               # :335-346, 366-373 (HIP)
+        loss_value = loss.detach()
+        if stepped:
+            global_iteration += 1
+        if rank == 0 and (iteration % log_every == 0 or iteration == num_iterations - 1):
+            st = engine.stats_dict()
+            ce = float(loss_value)
+            total = (ce + st["img_loss"]) / grad_accum_steps
+            accumulated_loss += total
+            rec = {"iteration": iteration, "global_iteration": global_iteration, "loss": total, "ce_loss": ce,
+                   "image_loss": st["img_loss"], "grad norm": st["grad_norm"], "lr": engine.current_lr(),
+                   "resave_error_std": st["sigma_next"], "resave_error_mean": st["qerr_mean"],
+                   "resave_error_l1": st["qerr_l1"], "adversarial_mean": st["x_mean"], "adversarial_std": st["x_std"],
+                   "noise_sigma": st["sigma"], "sigma": sigma}
+            history.append(rec)
+            logger.log(rec)
+        if rank == 0 and (iteration % save_steps == 0 or iteration == num_iterations - 1):  # :410-416 (Q10 naming)
+            img = engine.image()
+            save_checkpoint(adv_processor.tensor2pil(img), img, exp_path, global_iteration)
+        if restart_num > 0 and (iteration + 1) % restart_num == 0 and rank == 0:
+            print("restart_num has no effect on the optimised tensor in the reference (Q5); ignored")
+    if rank == 0:
+        img = engine.image()
+        save_checkpoint(adv_processor.tensor2pil(img), img, exp_path, "final")              # :475-477
+        logger.close()
+    if return_engine:
+        return engine, history
+    return history
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Train image attack model (MI355X-native pixel path).")
+    p.add_argument("--exp_name", type=str, default="advx-run")
+    p.add_argument("--img_orig", type=str, default="gray.png")
+    p.add_argument("--prompt", type=str, default="list", help='"list" = sample from the question pool')
+    p.add_argument("--target_text", type=str, default="sure, here it is!")
+    p.add_argument("--model_name", type=str, default="llava-hf/llava-1.5-7b-hf")
+    p.add_argument("--lr", type=float, default=1e-2)
+    p.add_argument("--num_iterations", type=int, default=1000)
+    p.add_argument("--save_steps", type=int, default=10)
+    p.add_argument("--batch_size", type=int, default=4)
+    p.add_argument("--grad_accum_steps", type=int, default=1)
+    p.add_argument("--scheduler_step_size", type=int, default=100)
+    p.add_argument("--scheduler_gamma", type=float, default=1.0)
+    p.add_argument("--restart_num", type=int, default=0)
+    p.add_argument("--mask_type", type=str, default=None, choices=["corner", "bottom_lines", "random_square"])
+    p.add_argument("--mask_size", type=int, default=None)
+    p.add_argument("--clamp_method", type=str, default="tanh", choices=["clamp", "tanh", "none"])
+    p.add_argument("--start_from_white", action="store_true")
+    p.add_argument("--target_text_random", action="store_true")
+    p.add_argument("--DPO_flag", action="store_true")
+    p.add_argument("--refuse_prob", type=float, default=0.0)
+    p.add_argument("--epsilon", type=float, default=0.5)
+    p.add_argument("--sigma", type=float, default=0.001)
+    p.add_argument("--use_gaussian_blur", action="store_true")
+    p.add_argument("--gblur_kernel_size", type=int, default=5)
+    p.add_argument("--gblur_sigma", type=float, default=7)
+    p.add_argument("--use_local_crop", action="store_true")
+    p.add_argument("--crop_scale_min", type=float, default=0.6)
+    p.add_argument("--crop_scale_max", type=float, default=1.0)
+    p.add_argument("--crop_ratio_min", type=float, default=0.75)
+    p.add_argument("--crop_ratio_max", type=float, default=1.33)
+    # additions
+    p.add_argument("--questions_file", type=str, default=None)
+    p.add_argument("--test_questions_file", type=str, default=None)
+    p.add_argument("--answers_file", type=str, default=None)
+    p.add_argument("--optimizer", type=str, default="adamw", choices=["adamw", "sign"])
+    p.add_argument("--log_every", type=int, default=1)
+    p.add_argument("--use_wandb", action="store_true")
+    p.add_argument("--seed", type=int, default=0)
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not torch.distributed.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.distributed.init_process_group("nccl")
+    name = f"{args.exp_name}_{datetime.now().strftime('%Y%m%d_%H%M%S')}"
+    exp_path = create_directory(name)
+    with open(os.path.join(exp_path, "config.json"), "w") as f:
+        json.dump(vars(args), f, indent=4)
+    kw = vars(args).copy()
+    kw["exp_name"] = name
+    train(**kw)
+
+
+if __name__ == "__main__":
+    main()

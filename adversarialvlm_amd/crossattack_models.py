@@ -1,0 +1,254 @@
+"""Multi-model universal trainer (reference: src/crossattack_models.py).
+
+Per step the shared image x0 + eps*tanh(p) is processed by every model's plugin, each
+model contributes  w_i * CE_i + image_fit_loss  (the image-fit term once PER MODEL,
+crossattack_models.py:369), the gradients wrt p are SUMMED (:391), masked, and AdamW steps.
+
+Placement
+  * one process: all models on the local device, visited serially like the reference
+    (which walks cuda:0..cuda:n-1 inside one process, :352-384);
+  * torch.distributed with world = n_models * k: rank r runs model r mod n_models on its own
+    GPU with batch_size/k prompts; the models run CONCURRENTLY and one RCCL all-reduce(sum)
+    of the image gradient per step replaces the reference's peer copies + stack().sum()
+    (every rank pre-scales by 1/k so that a model's group averages and the groups add up).
+Reference quirks kept: the perturbation scale is `attack_norm` (0.5), not
+`--epsilon` (Q3); the blur sigma is redrawn U(0.1, 2) every step (Q4); gradient accumulation
+only changes the optimiser cadence because p.grad is rebuilt each iteration; DPO_flag swaps
+the target for a refusal string without negating the loss (Q8).
+"""
+import argparse
+import json
+import os
+import random
+from datetime import datetime
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import prompts as P
+from .attack_model import (JsonlLogger, create_directory, create_mask, random_resized_crop_params, save_checkpoint,
+                           setup_device)
+from .pgd import PixelPGD
+from .processors import load_components
+
+
+def pil_to_tensor(image: Image.Image, do_convert_rgb: bool = True, resize: bool = False) -> torch.Tensor:
+    """crossattack_models.py:106-123."""
+    if do_convert_rgb:
+        image = image.convert("RGB")
+    if resize:
+        raise NotImplementedError("Resizing is not universal for models!!!")
+    return torch.tensor(np.array(image).astype(np.float32) / 255).permute(2, 0, 1)
+
+
+def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iterations, save_steps, batch_size,
+          grad_accum_steps, scheduler_step_size, scheduler_gamma, restart_num, mask_type, mask_size, clamp_method,
+          epsilon, sigma, start_from_white, target_text_random, DPO_flag=True, refuse_prob=0.1, model_weights=None,
+          attack_norm=0.5, use_gaussian_blur=False, gblur_kernel_size=5, use_local_crop=False, crop_scale_min=0.6,
+          crop_scale_max=1.0, crop_ratio_min=0.75, crop_ratio_max=1.33,
+          questions_file=None, test_questions_file=None, answers_file=None, log_every=1, use_wandb=False, seed=0,
+          base_path="./runs", return_engine=False):
+    if clamp_method != "tanh":
+        raise NotImplementedError("Clamping method except tanh are not implemented yet.")
+    if mask_type == "random_square":
+        raise NotImplementedError("Dynamic random-square mask updating not implemented.")
+    questions = P.load_pool(questions_file, P.DEFAULT_QUESTIONS)
+    test_questions = P.load_pool(test_questions_file, P.DEFAULT_TEST_QUESTIONS)
+    if target_text_random:
+        target_text = P.load_pool(answers_file, P.DEFAULT_ANSWERS)
+    if prompt != "list":
+        questions = [prompt]
+    n_models = len(model_names)
+    if model_weights is None:
+        model_weights = [1.0] * n_models
+    elif len(model_weights) != n_models:
+        raise ValueError("The length of model_weights must match the number of model_names.")
+
+    device = setup_device()
+    dist_on = torch.distributed.is_initialized()
+    world = torch.distributed.get_world_size() if dist_on else 1
+    rank = torch.distributed.get_rank() if dist_on else 0
+    if world > 1:
+        if world % n_models != 0:
+            raise ValueError("world size must be a multiple of the number of models")
+        group_size = world // n_models
+        if batch_size % group_size != 0:
+            raise ValueError("batch_size must be divisible by the ranks per model")
+        my_models = [rank % n_models]
+        local_batch = batch_size // group_size
+        prescale = 1.0 / group_size
+    else:
+        my_models = list(range(n_models))
+        local_batch = batch_size
+        prescale = 1.0
+    exp_path = create_directory(exp_name, base_path)
+
+    if isinstance(img_orig, Image.Image):
+        original_image = img_orig.convert("RGB")
+    elif os.path.exists(img_orig):
+        original_image = Image.open(img_orig).convert("RGB")
+    elif os.path.exists(os.path.join("./images", img_orig)):
+        original_image = Image.open(os.path.join("./images", img_orig)).convert("RGB")
+    else:
+        raise FileNotFoundError(f"Cannot find {img_orig}")
+
+    models, adv_processors, inputs_processors = [], [], []
+    random.seed(seed)
+    torch.manual_seed(seed)
+    for i in my_models:
+        load_model_and_processor, AdvInputs, DiffProc = load_components(model_names[i])
+        model, processor = load_model_and_processor(model_names[i], device)
+        model.requires_grad_(False)
+        models.append(model)
+        adv_processors.append(DiffProc(processor.image_processor, device))
+        inputs_processors.append(AdvInputs(questions=questions, test_questions=test_questions, batch_size=local_batch,
+                                           original_image=original_image, processor=processor, device=device,
+                                           target_text=target_text,
+                                           rng=random.Random(seed * 1000003 + rank) if world > 1 else None))
+    x_0 = pil_to_tensor(original_image, do_convert_rgb=adv_processors[0].do_convert_rgb).to(device)
+    if start_from_white:
+        x_0 = torch.ones_like(x_0)
+    _, H, W = x_0.shape
+    if mask_type is not None and mask_size is not None:
+        mask = create_mask(mask_type, mask_size, x_0.shape, device)
+    else:
+        mask = (x_0 != 0).float()
+    if rank == 0:
+        torch.save(mask.cpu(), os.path.join(exp_path, "mask.pt"))
+        Image.fromarray((mask.permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8)).save(os.path.join(exp_path, "mask.png"))
+
+    plans = [ap.plan_for(H, W) for ap in adv_processors]
+    engine = PixelPGD(x_0, plans, epsilon=attack_norm, lr=lr, sigma0=0.001, mask=mask,                   # :299 hard-codes 0.001
+                      scheduler_step_size=scheduler_step_size, scheduler_gamma=scheduler_gamma,
+                      grad_accum_steps=grad_accum_steps, blur_kernel=gblur_kernel_size if use_gaussian_blur else None,
+                      use_crop=use_local_crop, model_weights=[model_weights[i] for i in my_models], cross_mode=True,
+                      seed=seed + 7919 * rank, allow_fused=False,
+                      process_group=torch.distributed.group.WORLD if world > 1 else None, grad_prescale=prescale)
+    if world > 1:
+        # every rank sees ONE of the n_models image-fit terms; scaled by 1/group_size the SUM
+        # over all ranks restores "once per model"
+        pass
+    logger = JsonlLogger(os.path.join(exp_path, "metrics.jsonl"), use_wandb and rank == 0, name=exp_name) if rank == 0 else None
+
+    global_iteration = 0
+    history = []
+    for iteration in range(num_iterations):
+        if DPO_flag or target_text_random:                                                  # :303-321
+            coin = random.random()
+            if DPO_flag and coin < refuse_prob:
+                for ip in inputs_processors:
+                    ip.set_target_text(random.choice(ip.refuses))
+            elif target_text_random:
+                text = random.choice(inputs_processors[-1].target_texts)
+                for ip in inputs_processors:
+                    ip.set_target_text(text)
+            else:
+                for ip in inputs_processors:
+                    ip.set_target_text(target_text if isinstance(target_text, str) else target_text[0])
+        blur_sigma = torch.empty(1).uniform_(0.1, 2.0).item() if use_gaussian_blur else None    # Q4
+        crop = None
+        if use_local_crop:
+            crop = random_resized_crop_params(H, W, (crop_scale_min, crop_scale_max), (crop_ratio_min, crop_ratio_max))
+        pvs = engine.forward(local_batch, blur_sigma=blur_sigma, crop=crop)                 # :329-362 (HIP)
+        grads, losses = [], []
+        for k, (model, ip, pv) in enumerate(zip(models, inputs_processors, pvs)):           # :352-384
+            inputs = ip.get_inputs_train()
+            pv.requires_grad_(True)
+            inputs["pixel_values"] = pv
+            logits = model(**inputs).logits[:, :-1, :]
+            model_loss = ip.get_loss(logits)
+            (model_loss * engine.loss_scale(k)).backward()
+            grads.append(pv.grad)
+            losses.append(model_loss.detach())
+        stepped = engine.backward_update(grads)                                             # :391-406 (HIP)
+        if stepped:
+            global_iteration += 1
+        if rank == 0 and (iteration % log_every == 0 or iteration == num_iterations - 1):
+            st = engine.stats_dict()
+            rec = {"iteration": iteration, "global_iteration": global_iteration, "img_loss": st["img_loss"],
+                   "grad_norm": st["grad_norm"], "lr": engine.current_lr(), "resave_error_std": st["sigma_next"],
+                   "adversarial_mean": st["x_mean"], "adversarial_std": st["x_std"]}
+            for k, i in enumerate(my_models):
+                rec[f"loss_{i}_{model_names[i].replace('/', '_')}"] = float(losses[k]) * model_weights[i] + st["img_loss"]
+            rec["loss_per_iteration"] = float(np.mean([v for kk, v in rec.items() if kk.startswith("loss_")]))
+            history.append(rec)
+            logger.log(rec)
+        if rank == 0 and (iteration % save_steps == 0 or iteration == num_iterations - 1):
+            img = engine.image()
+            save_checkpoint(adv_processors[0].tensor2pil(img), img, exp_path, global_iteration)
+    if rank == 0:
+        img = engine.image()
+        save_checkpoint(adv_processors[0].tensor2pil(img), img, exp_path, "final")
+        logger.close()
+    if return_engine:
+        return engine, history
+    return history
+
+
+def parse_model_names(s):
+    return s.split(",")
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Train a universal image against several models.")
+    p.add_argument("--exp_name", type=str, default="advx-cross")
+    p.add_argument("--img_orig", type=str, default="gray.png")
+    p.add_argument("--prompt", type=str, default="list")
+    p.add_argument("--target_text", type=str, default="sure, here it is!")
+    p.add_argument("--model_names", type=parse_model_names,
+                   default="microsoft/Phi-3.5-vision-instruct,Qwen/Qwen2-VL-7B-Instruct,alpindale/Llama-3.2-11B-Vision-Instruct")
+    p.add_argument("--lr", type=float, default=1e-2)
+    p.add_argument("--num_iterations", type=int, default=1000)
+    p.add_argument("--save_steps", type=int, default=10)
+    p.add_argument("--batch_size", type=int, default=4)
+    p.add_argument("--grad_accum_steps", type=int, default=1)
+    p.add_argument("--scheduler_step_size", type=int, default=100)
+    p.add_argument("--scheduler_gamma", type=float, default=0.9)
+    p.add_argument("--restart_num", type=int, default=0)
+    p.add_argument("--mask_type", type=str, default=None, choices=["corner", "bottom_lines", "random_square"])
+    p.add_argument("--mask_size", type=int, default=None)
+    p.add_argument("--clamp_method", type=str, default="tanh", choices=["clamp", "tanh", "none"])
+    p.add_argument("--start_from_white", action="store_true")
+    p.add_argument("--target_text_random", action="store_true")
+    p.add_argument("--DPO_flag", action="store_true")
+    p.add_argument("--refuse_prob", type=float, default=0.1)
+    p.add_argument("--epsilon", type=float, default=0.4, help="logged only by the reference (Q3); use --attack_norm")
+    p.add_argument("--attack_norm", type=float, default=0.5)
+    p.add_argument("--sigma", type=float, default=0.001)
+    p.add_argument("--model_weights", type=float, nargs="+", default=None)
+    p.add_argument("--use_gaussian_blur", action="store_true")
+    p.add_argument("--gblur_kernel_size", type=int, default=5)
+    p.add_argument("--use_local_crop", action="store_true")
+    p.add_argument("--crop_scale_min", type=float, default=0.6)
+    p.add_argument("--crop_scale_max", type=float, default=1.0)
+    p.add_argument("--crop_ratio_min", type=float, default=0.75)
+    p.add_argument("--crop_ratio_max", type=float, default=1.33)
+    p.add_argument("--questions_file", type=str, default=None)
+    p.add_argument("--test_questions_file", type=str, default=None)
+    p.add_argument("--answers_file", type=str, default=None)
+    p.add_argument("--log_every", type=int, default=1)
+    p.add_argument("--use_wandb", action="store_true")
+    p.add_argument("--seed", type=int, default=0)
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if isinstance(args.model_names, str):
+        args.model_names = parse_model_names(args.model_names)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not torch.distributed.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.distributed.init_process_group("nccl")
+    name = f"{args.exp_name}_{datetime.now().strftime('%Y%m%d_%H%M%S')}"
+    exp_path = create_directory(name)
+    with open(os.path.join(exp_path, "config.json"), "w") as f:
+        json.dump(vars(args), f, indent=4)
+    kw = vars(args).copy()
+    kw["exp_name"] = name
+    train(**kw)
+
+
+if __name__ == "__main__":
+    main()

@@ -24,14 +24,14 @@ All statistics stay on the device (`self.stats`); nothing here synchronises the 
 import torch
 
 from . import _lib as L
-from . import ops
+from . import dp, ops
 
 
 class PixelPGD:
     def __init__(self, x0, plans, epsilon=0.5, lr=1e-2, sigma0=1e-3, mask=None, scheduler_step_size=100,
                  scheduler_gamma=1.0, grad_accum_steps=1, blur_kernel=None, use_crop=False, model_weights=None,
                  optimizer="adamw", cross_mode=False, betas=(0.9, 0.999), adam_eps=1e-8, weight_decay=1e-2, seed=0,
-                 process_group=None, allow_fused=True, fused_mode="auto"):
+                 process_group=None, allow_fused=True, fused_mode="auto", grad_prescale=None):
         if not x0.is_cuda:
             raise L.AdvxError("PixelPGD needs x0 on a ROCm device (there is no CPU fallback)")
         if not isinstance(plans, (list, tuple)):
@@ -68,6 +68,11 @@ class PixelPGD:
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+        # factor every rank applies to its contribution before the SUM all-reduce: 1/world gives
+        # the data-parallel average; cross-model groups pass 1/group_size (average inside a
+        # model's group, sum across models - crossattack_models.py:391)
+        self.prescale = (1.0 / self.world) if grad_prescale is None else float(grad_prescale)
+        self.scales = dp.Scales(len(self.plans), self.weights, self.accum, self.cross_mode, self.prescale)
         self.fused = bool(allow_fused and len(self.plans) == 1 and self.plans[0].fused_supported()
                           and blur_kernel is None and not self.use_crop and self.accum == 1)
         self.upd_scratch = ops.update_scratch(self.p.numel(), dev)
@@ -136,13 +141,11 @@ class PixelPGD:
         # single: (CE + img)/accum (attack_model.py:330); cross: img added once per model and
         # never divided (crossattack_models.py:369).  The DP pre-scale 1/world makes the
         # SUM all-reduce an average.
-        n = float(len(self.plans)) if self.cross_mode else 1.0 / self.accum
-        return n / self.world
+        return self.scales.imgfit_scale()
 
     def loss_scale(self, i=0):
         """Factor the caller applies to model i's loss before .backward()."""
-        w = self.weights[i] if self.cross_mode else self.weights[i] / self.accum
-        return w / self.world
+        return self.scales.loss_scale(i)
 
     # ------------------------------------------------------------------ forward
     def forward(self, batches, unit_noises=None, blur_sigma=None, crop=None, use_philox=True):
@@ -227,7 +230,7 @@ class PixelPGD:
                 ops.fused_bwd(pl, grads[0], B, self.p, self.x0, self.eps, self.imgfit_scale(), self.grad, self.stats,
                               self.fused_scratch)
                 # one exchange per step: the shared image gradient (P_in*4 bytes) over RCCL/xGMI
-                torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                dp.allreduce_image_grad_(self.grad, self.pg)
                 ops.update(self.p, self.m, self.v, self.grad, self.mask, opt, self.stats, self.upd_scratch)
                 self.prepared = False
             self.s_cur = nxt          # the next forward's image goes to the other buffer: image() stays valid
@@ -240,7 +243,7 @@ class PixelPGD:
             if self.world > 1 and take_step:
                 # The reduction is linear, so a gradient-accumulation window is exchanged once,
                 # at its end (intermediate grad norms are then rank-local).
-                torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                dp.allreduce_image_grad_(self.grad, self.pg)
             ops.update(self.p, self.m, self.v, self.grad, self.mask, opt, self.stats, self.upd_scratch)
         if take_step:
             self._scheduler_step()

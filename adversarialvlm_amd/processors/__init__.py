@@ -1,0 +1,73 @@
+"""Plugin registry: model name -> (load_model_and_processor, AdvInputs, DifferentiableImageProcessor).
+
+Same map and the same `load_components` contract as the reference's
+`src/processors/__init__.py:5-76` (ValueError for unknown names, processor_class None for the
+evaluation-only judge model), resolved inside this package.
+"""
+import importlib
+from typing import Tuple
+
+MODEL_MAP = {
+    "microsoft/Phi-3.5-vision-instruct": {
+        "module": "adversarialvlm_amd.processors.phi3processor",
+        "input_class": "AdvPhiInputs",
+        "processor_class": "DifferentiablePhi3VImageProcessor",
+    },
+    "Qwen/Qwen2-VL-2B-Instruct": {
+        "module": "adversarialvlm_amd.processors.qwen2VLprocessor",
+        "input_class": "AdvQwen2VLInputs",
+        "processor_class": "DifferentiableQwen2VLImageProcessor",
+    },
+    "Qwen/Qwen2-VL-7B-Instruct": {
+        "module": "adversarialvlm_amd.processors.qwen2VLprocessor",
+        "input_class": "AdvQwen2VLInputs",
+        "processor_class": "DifferentiableQwen2VLImageProcessor",
+    },
+    "alpindale/Llama-3.2-11B-Vision-Instruct": {
+        "module": "adversarialvlm_amd.processors.llama32processor",
+        "input_class": "AdvMllamaInputs",
+        "processor_class": "DifferentiableMllamaImageProcessor",
+    },
+    "alpindale/Llama-3.2-11B-Vision": {
+        "module": "adversarialvlm_amd.processors.llama32processor",
+        "input_class": "AdvMllamaInputs",
+        "processor_class": "DifferentiableMllamaImageProcessor",
+    },
+    "SinclairSchneider/Llama-Guard-3-11B-Vision": {
+        "module": "adversarialvlm_amd.processors.llama32processor",
+        "input_class": "AdvMllamaInputs",
+        "processor_class": "DifferentiableMllamaImageProcessor",
+    },
+    "llava-hf/llava-1.5-7b-hf": {
+        "module": "adversarialvlm_amd.processors.llavaprocessor",
+        "input_class": "AdvLlavaInputs",
+        "processor_class": "DifferentiableLlavaImageProcessor",
+    },
+    # offline, random-init architectures with synthetic token ids (no weights in the container)
+    "synthetic/tiny-llava": {
+        "module": "adversarialvlm_amd.processors.synthetic",
+        "input_class": "AdvLlavaInputs",
+        "processor_class": "DifferentiableLlavaImageProcessor",
+    },
+    "synthetic/llava-1.5-7b": {
+        "module": "adversarialvlm_amd.processors.synthetic",
+        "input_class": "AdvLlavaInputs",
+        "processor_class": "DifferentiableLlavaImageProcessor",
+    },
+}
+
+
+def register(model_name: str, module: str, input_class: str, processor_class):
+    """Add a model (e.g. a local checkpoint path or a tiny test config) to the map."""
+    MODEL_MAP[model_name] = {"module": module, "input_class": input_class, "processor_class": processor_class}
+
+
+def load_components(model_name: str) -> Tuple[object, object, object]:
+    if model_name not in MODEL_MAP:
+        raise ValueError(f"Model {model_name} not found in MODEL_MAP. Please add it to the map.")
+    info = MODEL_MAP[model_name]
+    module = importlib.import_module(info["module"])
+    load_model_and_processor = getattr(module, "load_model_and_processor")
+    adv_inputs = getattr(module, info["input_class"])
+    proc = getattr(module, info["processor_class"]) if info["processor_class"] is not None else None
+    return load_model_and_processor, adv_inputs, proc

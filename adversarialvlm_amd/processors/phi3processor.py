@@ -1,0 +1,69 @@
+"""Phi-3.5-Vision plugin (reference: src/processors/phi3processor.py)."""
+import torch
+
+from ..plan import Plan
+from .base import AdvInputsBase, DifferentiableProcessorBase
+
+
+def load_model_and_processor(model_name, device):
+    """phi3processor.py:25-36 (remote code, fp16, num_crops=6, left padding)."""
+    from transformers import AutoModelForCausalLM, AutoProcessor
+    model = AutoModelForCausalLM.from_pretrained(model_name, trust_remote_code=True, torch_dtype=torch.float16).to(device)
+    model.requires_grad_(False)
+    processor = AutoProcessor.from_pretrained(model_name, num_crops=6, padding_side="left", trust_remote_code=True)
+    model.generation_config.eos_token_id = 32000
+    return model, processor
+
+
+def pad_left(seqs, pad_token_id):
+    """phi3processor.py:305-311."""
+    n = max(len(s) for s in seqs)
+    out = torch.full((len(seqs), n), pad_token_id)
+    for i, s in enumerate(seqs):
+        out[i, n - len(s):] = s
+    return out
+
+
+class AdvPhiInputs(AdvInputsBase):
+    refuses = ["I'm sorry, but I can't", "I'm sorry, but I cannot", "No, it is not", "Sorry, I can't", "Sorry, I cannot",
+               "Sorry, but I can't assist with that", "As an AI, I don't", "As an AI, I'm not",
+               "Sorry, but I cannot help you"]
+    extra_token = "<|end|>\n"
+
+    def _shift(self, tokenizer):
+        return len(tokenizer.encode(self.extra_token)) - 1      # phi3processor.py:61
+
+    def _render_train(self, question, answer):
+        return f"<|user|>\n<|image_1|>\n{question}<|end|>\n<|assistant|>\n{answer}<|end|>\n"   # phi3processor.py:91
+
+    def _render_inference(self, question):
+        return f"<|user|>\n<|image_1|>\n{question}<|end|>\n<|assistant|>\n"                     # phi3processor.py:101
+
+    def _encode(self, prompts, images):
+        # the Phi-3.5 processor takes one prompt at a time (phi3processor.py:275-302)
+        from transformers.feature_extraction_utils import BatchFeature
+        encs = [self.processor(p, [im], return_tensors="pt") for p, im in zip(prompts, images)]
+        pad_id = self.processor.tokenizer.pad_token_id
+        ids = pad_left([e.input_ids[0] for e in encs], pad_id)
+        data = dict(input_ids=ids, attention_mask=(ids != pad_id).long(),
+                    image_sizes=torch.cat([e.image_sizes for e in encs], dim=0))
+        if "pixel_values" in encs[0]:
+            data["pixel_values"] = torch.cat([e.pixel_values for e in encs], dim=0)
+        return BatchFeature(data)
+
+
+class DifferentiablePhi3VImageProcessor(DifferentiableProcessorBase):
+    """HD transform (2-tap bilinear, pad 1.0), normalise, bicubic global view + 336^2 local
+    tiles, zero tiles up to num_crops+1 (phi3processor.py:239-250)."""
+
+    def __init__(self, orig_processor, device):
+        super().__init__(orig_processor, device)
+        self.num_crops = orig_processor.num_crops
+        self.num_img_tokens = getattr(orig_processor, "num_img_tokens", 144)
+
+    def _make_plan(self, H, W):
+        return Plan.phi3(H, W, num_crops=self.num_crops, mean=self.mean, std=self.std)
+
+    def _extras(self, plan):
+        i = plan.info
+        return {"image_sizes": [[int(i.image_h), int(i.image_w)]], "num_img_tokens": [int(i.num_img_tokens)]}

@@ -1,0 +1,138 @@
+"""GPU tier: the whole loop around a (tiny, random-init) LLaVA-architecture VLM.
+
+BASELINE config 1 in spirit ("LLaVA tanh-clamp attack, 1 prompt, 2 PGD steps"): the reference
+trainer cannot be imported here (wandb / torchvision), so its loop is the oracle's restatement
+(oracle/pgd.py) driving the SAME random model on the CPU; the HIP engine drives it on the GPU.
+Bar: fp32 loss and pixel grads within 1e-4 relative (north star)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from conftest import rel_err
+from oracle.pgd import PGDOracle
+from oracle.processors import LlavaOracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny(device):
+    from adversarialvlm_amd.processors.synthetic import load_model_and_processor
+    return load_model_and_processor("synthetic/tiny-llava", device, seed=0)
+
+
+def _inputs(proc, device, batch, seed):
+    from adversarialvlm_amd.processors import load_components
+    import random
+    _, AdvInputs, _ = load_components("synthetic/tiny-llava")
+    return AdvInputs(questions=["what is in the image", "describe the scene please", "hi"], test_questions=["t"],
+                     batch_size=batch, original_image=None, processor=proc, device=device, target_text="sure here it is",
+                     rng=random.Random(seed))
+
+
+@pytest.mark.parametrize("batch,chain", [(1, "pair"), (4, "pair"), (4, "step"), (3, "generic")])
+def test_two_pgd_steps_loss_and_grad_parity(batch, chain):
+    from adversarialvlm_amd.pgd import PixelPGD
+    from adversarialvlm_amd.plan import Plan
+    dev = torch.device("cuda:0")
+    model_g, proc = _tiny(dev)
+    model_c, _ = _tiny("cpu")
+    torch.manual_seed(3)
+    x0 = torch.rand(3, 56, 56)
+    ora = PGDOracle(x0, [LlavaOracle(56, 56)], lr=1e-2)
+    kw = dict(allow_fused=False) if chain == "generic" else dict(fused_mode=chain)
+    eng = PixelPGD(x0.to(dev), [Plan.llava(56, 56, 56, 56)], lr=1e-2, **kw)
+    ip_g, ip_c = _inputs(proc, dev, batch, 5), _inputs(proc, "cpu", batch, 5)
+    gen = torch.Generator().manual_seed(9)
+    for step in range(2):
+        z = torch.randn(batch, 3, 56, 56, generator=gen)
+        inputs_c, inputs_g = ip_c.get_inputs_train(), ip_g.get_inputs_train()
+        assert torch.equal(inputs_c["input_ids"], inputs_g["input_ids"].cpu())
+        # ---- reference path (CPU, autograd through everything)
+        ora.forward(batch, [z])
+        losses = {}
+
+        def loss_fn(pv):
+            out = model_c(input_ids=inputs_c["input_ids"], attention_mask=inputs_c["attention_mask"], pixel_values=pv)
+            l = ip_c.get_loss(out.logits[:, :-1, :])
+            losses["c"] = float(l.detach())
+            return l
+        ref = ora.backward_update(loss_fns=[loss_fn])
+        # ---- HIP path (GPU): pixel ops in libadvx, the VLM under torch
+        pv = eng.forward(batch, [z.to(dev)])[0].requires_grad_(True)
+        out = model_g(input_ids=inputs_g["input_ids"], attention_mask=inputs_g["attention_mask"], pixel_values=pv)
+        loss = ip_g.get_loss(out.logits[:, :-1, :])
+        (loss * eng.loss_scale(0)).backward()
+        eng.backward_update([pv.grad])
+        st = eng.stats_dict()
+        assert abs(float(loss.detach()) - losses["c"]) <= 1e-4 * abs(losses["c"])
+        assert rel_err(eng.grad.cpu(), ref["grad"]) < 1e-4
+        assert abs(st["img_loss"] - ref["img_loss"]) <= 1e-4 * max(ref["img_loss"], 1e-12)
+        assert abs(st["sigma_next"] - ref["sigma_next"]) <= 1e-4 * ref["sigma_next"]
+        # AdamW's first steps are sign-like: a gradient entry that is ~0 may flip between the two
+        # devices' GEMMs, so p is compared on the entries whose gradient is not negligible
+        gmask = ref["grad"].abs() > 1e-3 * ref["grad"].abs().max()
+        assert rel_err(eng.p.cpu()[gmask], ora.p.detach()[gmask]) < 1e-3
+
+
+def _gray(tmp_path, size=56):
+    path = os.path.join(tmp_path, "gray.png")
+    Image.fromarray(np.full((size, size, 3), 128, np.uint8)).save(path)
+    return path
+
+
+def test_train_entry_point_artifacts_and_progress(tmp_path):
+    from adversarialvlm_amd import attack_model
+    img = _gray(str(tmp_path))
+    hist = attack_model.train(exp_name="t1", img_orig=img, prompt="list", target_text="sure here it is",
+                              model_name="synthetic/tiny-llava", lr=1e-2, num_iterations=12, save_steps=5, batch_size=4,
+                              grad_accum_steps=1, scheduler_step_size=100, scheduler_gamma=1.0, restart_num=0,
+                              mask_type=None, mask_size=None, clamp_method="tanh", epsilon=0.5, sigma=1e-3,
+                              start_from_white=False, target_text_random=False, base_path=str(tmp_path))
+    run = os.path.join(str(tmp_path), "t1")
+    files = set(os.listdir(run))
+    # checkpoint index = global_iteration AFTER the increment (Q10): iterations 0, 5, 10, 11 -> 1, 6, 11, 12
+    for k in (1, 6, 11, 12, "final"):
+        assert f"optimized_image_iter_{k}.png" in files and f"optimized_image_iter_{k}.bin" in files, (k, sorted(files))
+    assert {"mask.pt", "mask.png", "metrics.jsonl"} <= files
+    raw = np.fromfile(os.path.join(run, "optimized_image_iter_final.bin"), dtype=np.float32)
+    assert raw.size == 3 * 56 * 56
+    png = np.array(Image.open(os.path.join(run, "optimized_image_iter_final.png")))
+    assert np.array_equal(png, (raw.reshape(3, 56, 56).clip(0, 1) * 255).astype(np.uint8).transpose(1, 2, 0))
+    assert len(hist) == 12 and hist[-1]["ce_loss"] < hist[0]["ce_loss"]       # the target gets more likely
+    assert all(np.isfinite(h["loss"]) for h in hist)
+
+
+def test_train_generic_chain_blur_crop_mask_multi_answer(tmp_path):
+    from adversarialvlm_amd import attack_model
+    img = _gray(str(tmp_path), 64)      # 64 -> 56: true resize, generic chain
+    ans = os.path.join(str(tmp_path), "answers.json")
+    json.dump(["sure here it is", "of course the answer is"], open(ans, "w"))
+    hist = attack_model.train(exp_name="t2", img_orig=img, prompt="list", target_text="unused",
+                              model_name="synthetic/tiny-llava", lr=1e-2, num_iterations=6, save_steps=100, batch_size=2,
+                              grad_accum_steps=2, scheduler_step_size=1, scheduler_gamma=0.9, restart_num=0,
+                              mask_type="corner", mask_size=32, clamp_method="tanh", epsilon=0.5, sigma=1e-3,
+                              start_from_white=True, target_text_random=True, use_gaussian_blur=True,
+                              gblur_kernel_size=5, gblur_sigma=7, use_local_crop=True, answers_file=ans,
+                              base_path=str(tmp_path))
+    assert len(hist) == 6 and hist[-1]["global_iteration"] == 3
+    assert hist[-1]["lr"] == pytest.approx(1e-2 * 0.9 ** 3)
+    raw = np.fromfile(os.path.join(str(tmp_path), "t2", "optimized_image_iter_final.bin"), dtype=np.float32).reshape(3, 64, 64)
+    assert np.all(raw[:, 40:, :] == 1.0) and np.any(raw[:, :32, :32] != 1.0)     # only the masked corner moved
+
+
+def test_cross_trainer_two_models(tmp_path):
+    from adversarialvlm_amd import crossattack_models
+    img = _gray(str(tmp_path), 70)
+    hist = crossattack_models.train(exp_name="t3", img_orig=img, prompt="list", target_text="sure here it is",
+                                    model_names=["synthetic/tiny-llava", "synthetic/tiny-llava"], lr=1e-2,
+                                    num_iterations=4, save_steps=2, batch_size=2, grad_accum_steps=1,
+                                    scheduler_step_size=100, scheduler_gamma=0.9, restart_num=0, mask_type=None,
+                                    mask_size=None, clamp_method="tanh", epsilon=0.4, sigma=1e-3, start_from_white=False,
+                                    target_text_random=False, DPO_flag=False, model_weights=[0.2, 0.8],
+                                    use_gaussian_blur=True, gblur_kernel_size=5, base_path=str(tmp_path))
+    assert len(hist) == 4 and all(np.isfinite(h["loss_per_iteration"]) for h in hist)
+    assert "optimized_image_iter_final.png" in os.listdir(os.path.join(str(tmp_path), "t3"))

@@ -1,0 +1,118 @@
+"""CPU tier: host-side logic above the C ABI - plugin registry, prompt-batch assembly and the
+suffix loss (a18/a11 of SURVEY 8a), CLI defaults (App. C), DP scale factors."""
+import random
+
+import pytest
+import torch
+
+from adversarialvlm_amd import dp
+from adversarialvlm_amd.processors import MODEL_MAP, load_components
+from adversarialvlm_amd.processors.synthetic import ToyLlavaProcessor
+
+
+def test_registry_contract():
+    for name, info in MODEL_MAP.items():
+        lm, inputs, proc = load_components(name)
+        assert callable(lm) and inputs.__name__ == info["input_class"] and proc.__name__ == info["processor_class"]
+    with pytest.raises(ValueError, match="not found in MODEL_MAP"):
+        load_components("unknown/model")
+
+
+def _inputs(batch=5, target="sure here it is", rng=None):
+    _, AdvInputs, _ = load_components("synthetic/tiny-llava")
+    proc = ToyLlavaProcessor(512, 511, 56, 14)
+    qs = ["what is this", "describe the picture in detail please", "hello"]
+    return AdvInputs(questions=qs, test_questions=["test question"], batch_size=batch, original_image=None,
+                     processor=proc, device="cpu", target_text=target, rng=rng), proc
+
+
+def test_batch_assembly_left_padded_suffix_aligned():
+    ip, proc = _inputs(rng=random.Random(0))
+    b = ip.get_inputs_train()
+    ids, att = b["input_ids"], b["attention_mask"]
+    assert ids.shape == att.shape and ids.shape[0] == 5
+    # left padding: zeros (pad) only at the start of a row, attention mirrors it
+    for r in range(5):
+        n_pad = int((att[r] == 0).sum())
+        assert torch.all(att[r, :n_pad] == 0) and torch.all(att[r, n_pad:] == 1)
+        assert torch.all(ids[r, :n_pad] == proc.tokenizer.pad_token_id)
+    # every row ends with target + extra-token ids (the CE slice relies on it, Q7)
+    assert torch.equal(ids[:, -ip.suffix_length:], ip.target_tokens.repeat(5, 1))
+    # the image placeholder was expanded to one token per vision patch
+    assert int((ids[0] == 511).sum()) == 16
+    # shift counts the BOS of the toy tokenizer like the Llama tokenizer does
+    assert ip.shift == 2 and ip.target.shape == (5, ip.suffix_length - 2)
+
+
+def test_prompt_cache_tokenises_each_pair_once():
+    ip, proc = _inputs(rng=random.Random(1))
+    calls = []
+    orig = proc.__call__
+
+    class Counting(type(proc)):
+        def __call__(self, *a, **k):
+            calls.append(1)
+            return orig(*a, **k)
+    ip.processor.__class__ = Counting
+    for _ in range(10):
+        ip.get_inputs_train()
+    assert len(calls) <= 3          # three distinct questions, one target
+    ip.set_target_text("another answer")
+    ip.get_inputs_train()
+    assert len(calls) <= 6
+
+
+def test_suffix_loss_matches_manual_cross_entropy():
+    ip, _ = _inputs(batch=3)
+    S, V = 40, 512
+    logits = torch.randn(3, S, V)
+    loss = ip.get_loss(logits)
+    sl = logits[:, -ip.suffix_length:-ip.shift, :]
+    manual = torch.nn.functional.cross_entropy(sl.reshape(-1, V), ip.target.reshape(-1))
+    assert torch.allclose(loss, manual)
+
+
+def test_multi_answer_targets():
+    ip, _ = _inputs(target=["first answer", "a second and longer answer"])
+    assert ip.target_texts == ["first answer", "a second and longer answer"] and ip.target_text == "first answer"
+    n0 = ip.suffix_length
+    ip.set_target_text(ip.target_texts[1])
+    assert ip.suffix_length > n0
+
+
+def test_cli_defaults_mirror_reference():
+    from adversarialvlm_amd.attack_model import build_parser
+    a = build_parser().parse_args([])
+    assert (a.lr, a.num_iterations, a.save_steps, a.batch_size, a.grad_accum_steps) == (1e-2, 1000, 10, 4, 1)
+    assert (a.scheduler_step_size, a.scheduler_gamma, a.restart_num, a.clamp_method) == (100, 1.0, 0, "tanh")
+    assert (a.epsilon, a.sigma, a.gblur_kernel_size, a.gblur_sigma) == (0.5, 0.001, 5, 7)
+    assert (a.crop_scale_min, a.crop_scale_max, a.crop_ratio_min, a.crop_ratio_max) == (0.6, 1.0, 0.75, 1.33)
+    from adversarialvlm_amd.crossattack_models import build_parser as cross
+    c = cross().parse_args(["--model_names", "a,b", "--model_weights", "0.2", "0.8"])
+    assert c.model_names == ["a", "b"] and c.model_weights == [0.2, 0.8]
+    assert (c.scheduler_gamma, c.epsilon, c.attack_norm) == (0.9, 0.4, 0.5)
+
+
+def test_trainer_refuses_without_gpu_or_unsupported_flags():
+    from adversarialvlm_amd import attack_model
+    kw = dict(exp_name="x", img_orig="none.png", prompt="list", target_text="t", model_name="synthetic/tiny-llava",
+              lr=1e-2, num_iterations=1, save_steps=1, batch_size=1, grad_accum_steps=1, scheduler_step_size=1,
+              scheduler_gamma=1.0, restart_num=0, mask_type=None, mask_size=None, epsilon=0.5, sigma=1e-3,
+              start_from_white=False, target_text_random=False)
+    with pytest.raises(NotImplementedError):
+        attack_model.train(clamp_method="clamp", **kw)
+    with pytest.raises(NotImplementedError):
+        attack_model.train(clamp_method="tanh", DPO_flag=True, **kw)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            attack_model.train(clamp_method="tanh", **kw)
+
+
+def test_dp_scales():
+    s = dp.Scales(1, [1.0], accum=2, cross_mode=False, prescale=1 / 4)
+    assert s.loss_scale(0) == pytest.approx(1 / 8) and s.imgfit_scale() == pytest.approx(1 / 8)
+    c = dp.Scales(3, [0.2, 0.8, 1.6], accum=2, cross_mode=True, prescale=1.0)
+    assert [c.loss_scale(i) for i in range(3)] == [0.2, 0.8, 1.6] and c.imgfit_scale() == 3.0
+    assert dp.shard_batch(256, 8) == 32
+    with pytest.raises(ValueError):
+        dp.shard_batch(10, 4)
