@@ -1,6 +1,7 @@
 // advx.hip - host side of libadvx_hip.so: plans (geometry + tap tables), launch logic and
 // the extern "C" entry points declared in include/advx.h.  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -43,6 +44,70 @@ static inline int grid_for(long long n, int cap = 2048) {
   if (b < 1) b = 1;
   if (b > cap) b = cap;
   return (int)b;
+}
+
+// --------------------------------------------------------------------------- profiling
+// Optional per-kernel timing of the three B*P_out movers: when enabled, each of their
+// launches goes through hipExtLaunchKernelGGL with its own start/stop event pair, i.e. the
+// device timestamps of that dispatch alone (what rocprofv3 --kernel-trace reports).
+namespace {
+enum ProfKind { PROF_FWD = 0, PROF_BWD = 1, PROF_STEP = 2, PROF_KINDS = 3 };
+struct Prof {
+  bool on = false;
+  int max_launches = 0;
+  int stride = 1;                 // time every stride-th launch of a kind
+  long long seen[PROF_KINDS] = {0, 0, 0};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[PROF_KINDS];
+} g_prof;
+}  // namespace
+
+#define ADVX_LAUNCH_TIMED(kind, kernel, grid, block, stream, ...)                                         \
+  do {                                                                                                    \
+    if (g_prof.on && (g_prof.seen[kind]++ % g_prof.stride) == 0 &&                                        \
+        (int)g_prof.ev[kind].size() < g_prof.max_launches) {                                              \
+      hipEvent_t e0, e1;                                                                                  \
+      if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {                       \
+        hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, e0, e1, 0, __VA_ARGS__);                    \
+        g_prof.ev[kind].push_back({e0, e1});                                                              \
+      } else {                                                                                            \
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                  \
+      }                                                                                                   \
+    } else {                                                                                              \
+      hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                    \
+    }                                                                                                     \
+  } while (0)
+
+extern "C" int32_t advx_profile_begin(int32_t max_launches, int32_t stride) {
+  REQUIRE(max_launches > 0 && max_launches <= (1 << 20) && stride >= 1, ADVX_E_BADARG, "advx_profile_begin: bad arguments");
+  g_prof.stride = stride;
+  for (int k = 0; k < PROF_KINDS; ++k) g_prof.seen[k] = 0;
+  for (int k = 0; k < PROF_KINDS; ++k) {
+    for (auto& e : g_prof.ev[k]) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    g_prof.ev[k].clear();
+  }
+  g_prof.max_launches = max_launches;
+  g_prof.on = true;
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_profile_end(double total_ms[3], int64_t launches[3]) {
+  REQUIRE(total_ms && launches, ADVX_E_BADARG, "advx_profile_end: null argument");
+  g_prof.on = false;
+  for (int k = 0; k < PROF_KINDS; ++k) {
+    total_ms[k] = 0.0;
+    launches[k] = 0;
+    for (auto& e : g_prof.ev[k]) {
+      float ms = 0.0f;
+      if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
+        total_ms[k] += (double)ms;
+        launches[k] += 1;
+      }
+      (void)hipEventDestroy(e.first);
+      (void)hipEventDestroy(e.second);
+    }
+    g_prof.ev[k].clear();
+  }
+  return ADVX_OK;
 }
 
 // ------------------------------------------------------------------------- host tables
@@ -847,8 +912,8 @@ extern "C" int32_t advx_fused_fwd(advx_plan* p, const float* pp, const float* x0
   dim3 grid(gx, slices);
   int noise = unit_noise ? 1 : (use_philox ? 2 : 0);
 #define ADVX_FF(N)                                                                                               \
-  hipLaunchKernelGGL(k_fused_fwd<N>, grid, dim3(kBlock), 0, st, (const float*)v_buf, (const float*)s_buf, x0, n, batch, \
-                     bps, stats, unit_noise, seed, offset, out, f.hdr, f.img_rows[parity], (const double*)f.norm_partials)
+  ADVX_LAUNCH_TIMED(PROF_FWD, k_fused_fwd<N>, grid, dim3(kBlock), st, (const float*)v_buf, (const float*)s_buf, x0, n, batch, \
+                    bps, stats, unit_noise, seed, offset, out, f.hdr, f.img_rows[parity], (const double*)f.norm_partials)
   if (noise == 0) ADVX_FF(0); else if (noise == 1) ADVX_FF(1); else ADVX_FF(2);
 #undef ADVX_FF
   LAUNCH_CHECK();
@@ -872,15 +937,15 @@ extern "C" int32_t advx_fused_bwd(advx_plan* p, const float* g, int32_t batch, f
     REQUIRE(opt->apply, ADVX_E_UNSUPPORTED, "advx_fused_bwd: the fused update always steps (use the generic path to accumulate)");
     int32_t rc = check_opt(opt, m, v);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_fused_bwd<true>, dim3(f.bwd_blocks), dim3(kBlock), 0, st, g, batch, pp, x0, eps, fused_geom(p), c_fit,
-                       mask, m, v, grad_p, to_dev(opt), s_next, v_buf, f.norm_partials, stats, f.hdr,
-                       (const double*)f.img_partials);
+    ADVX_LAUNCH_TIMED(PROF_BWD, k_fused_bwd<true>, dim3(f.bwd_blocks), dim3(kBlock), st, g, batch, pp, x0, eps, fused_geom(p),
+                      c_fit, mask, m, v, grad_p, to_dev(opt), s_next, v_buf, f.norm_partials, stats, f.hdr,
+                      (const double*)f.img_partials);
   } else {
     OptScalars none;
     std::memset(&none, 0, sizeof(none));
-    hipLaunchKernelGGL(k_fused_bwd<false>, dim3(f.bwd_blocks), dim3(kBlock), 0, st, g, batch, pp, x0, eps, fused_geom(p), c_fit,
-                       mask, m, v, grad_p, none, s_next, v_buf, f.norm_partials, stats, f.hdr,
-                       (const double*)f.img_partials);
+    ADVX_LAUNCH_TIMED(PROF_BWD, k_fused_bwd<false>, dim3(f.bwd_blocks), dim3(kBlock), st, g, batch, pp, x0, eps, fused_geom(p),
+                      c_fit, mask, m, v, grad_p, none, s_next, v_buf, f.norm_partials, stats, f.hdr,
+                      (const double*)f.img_partials);
   }
   LAUNCH_CHECK();
   return ADVX_OK;
@@ -932,9 +997,9 @@ extern "C" int32_t advx_fused_step(advx_plan* p, const float* g, int32_t batch, 
   int noise = unit_noise_next ? 1 : (use_philox ? 2 : 0);
   const int grid = step_grid(f.bwd_blocks);
 #define ADVX_FS(N)                                                                                                      \
-  hipLaunchKernelGGL(k_fused_step_ws<N>, dim3(grid), dim3(kStepThreads), 0, st, g, batch, pp, x0, eps, fused_geom(p), c_fit, \
-                     mask, m, v, grad_p, to_dev(opt), s_next, v_buf, unit_noise_next, seed, offset_next, out_next, rows,  \
-                     stats, f.bwd_blocks)
+  ADVX_LAUNCH_TIMED(PROF_STEP, k_fused_step_ws<N>, dim3(grid), dim3(kStepThreads), st, g, batch, pp, x0, eps, fused_geom(p), \
+                    c_fit, mask, m, v, grad_p, to_dev(opt), s_next, v_buf, unit_noise_next, seed, offset_next, out_next, \
+                    rows, stats, f.bwd_blocks)
   if (noise == 0) ADVX_FS(0); else if (noise == 1) ADVX_FS(1); else ADVX_FS(2);
 #undef ADVX_FS
   LAUNCH_CHECK();

@@ -192,6 +192,18 @@ def fused_step_flush(plan, parity, norm_rows, stats, scratch):
                                            _stream(stats)), "advx_fused_step_flush")
 
 
+def profile_begin(max_launches=4096, stride=1):
+    L.check(L.load().advx_profile_begin(int(max_launches), int(stride)), "advx_profile_begin")
+
+
+def profile_end():
+    """{'fwd'|'bwd'|'step': (avg_ms, launches)} of the launches timed since profile_begin."""
+    ms = (C.c_double * 3)()
+    n = (C.c_int64 * 3)()
+    L.check(L.load().advx_profile_end(ms, n), "advx_profile_end")
+    return {k: ((ms[i] / n[i]) if n[i] else 0.0, int(n[i])) for i, k in enumerate(("fwd", "bwd", "step"))}
+
+
 # ------------------------------------------------------------------------ single ops
 def tanh_fwd(p, epsilon):
     _require_cuda(p)

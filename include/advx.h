@@ -245,6 +245,16 @@ int32_t advx_fused_step_rows(const advx_plan* plan, int32_t* rows_after_fwd, int
 int32_t advx_fused_step_flush(advx_plan* plan, int32_t parity, int32_t norm_rows, float* stats,
                               float* scratch, void* stream);
 
+/* ---------------------------------------------------------------- profiling
+ * Per-kernel device time of the B*P_out movers (k_fused_fwd, k_fused_bwd, k_fused_step):
+ * between begin and end each of their launches carries its own start/stop HIP event pair on
+ * the launch stream (hipExtLaunchKernelGGL): every stride-th launch, up to max_launches per
+ * kernel (a sparse stride keeps the timed loop itself unperturbed).
+ * advx_profile_end synchronises those events and returns, for kinds {0 fwd, 1 bwd, 2 step},
+ * the summed milliseconds and the number of timed launches. */
+int32_t advx_profile_begin(int32_t max_launches, int32_t stride);
+int32_t advx_profile_end(double total_ms[3], int64_t launches[3]);
+
 /* ------------------------------------------------- single ops (unit tests)
  * Same kernels the calls above launch, exposed one by one. */
 int32_t advx_tanh_fwd(const float* p, float epsilon, float* x, int64_t n, void* stream);
