@@ -185,19 +185,22 @@ __device__ inline uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
   }
   return c;
 }
-// four N(0,1) draws from one Philox block (Box-Muller on 24-bit uniforms)
+// four N(0,1) draws from one Philox block: Box-Muller on uniforms built with one convert and
+// one fma each (u = r * 2^-32 [+ 2^-33 to keep the logarithm's argument in (0,1]]); raw
+// v_log / v_sqrt / v_sin / v_cos (the angle is in revolutions, v_log is log2).
 __device__ inline float4 philox_normal4(unsigned long long gidx, unsigned long long offset,
                                         unsigned long long seed) {
   uint4 c = make_uint4((uint32_t)gidx, (uint32_t)(gidx >> 32), (uint32_t)offset, (uint32_t)(offset >> 32));
   uint4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-  const float k24 = 1.0f / 16777216.0f;
-  float u1 = (float)((r.x >> 8) + 1u) * k24;  // (0,1]
-  float u2 = (float)(r.y >> 8) * k24;         // [0,1)
-  float u3 = (float)((r.z >> 8) + 1u) * k24;
-  float u4 = (float)(r.w >> 8) * k24;
-  // v_log_f32 is log2; -2 ln u = -2 ln2 log2 u.  v_sin/v_cos take revolutions.
-  float ra = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
-  float rb = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u3));
+  const float k32 = 2.3283064365386963e-10f;   // 2^-32
+  const float k33 = 1.1641532182693481e-10f;   // 2^-33
+  float u1 = __builtin_fmaf((float)r.x, k32, k33);  // (0, 1]
+  float u2 = (float)r.y * k32;                      // [0, 1]  (1.0 is the same angle as 0)
+  float u3 = __builtin_fmaf((float)r.z, k32, k33);
+  float u4 = (float)r.w * k32;
+  // -2 ln u = -2 ln2 log2 u
+  float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+  float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u3));
   float4 z;
   z.x = ra * __builtin_amdgcn_cosf(u2);
   z.y = ra * __builtin_amdgcn_sinf(u2);
