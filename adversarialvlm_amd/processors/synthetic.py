@@ -40,7 +40,8 @@ class ToyTokenizer:
             return self.image_token_id
         if w == "</s>":
             return self.eos_token_id
-        return 3 + zlib.crc32(w.encode()) % (self.vocab_size - 4)
+        i = 3 + zlib.crc32(w.encode()) % (self.vocab_size - 4)
+        return i + 1 if i == self.image_token_id else i     # a word never aliases the placeholder
 
     def _ids(self, text, add_special_tokens=True):
         text = text.replace(IMAGE_TOKEN, f" {IMAGE_TOKEN} ").replace("</s>", " </s> ")
@@ -105,7 +106,11 @@ def _config(model_name):
         return LlavaConfig(vision_config=vc, text_config=tc, image_token_index=511, vision_feature_layer=-1,
                            vision_feature_select_strategy="default")
     if model_name == "synthetic/llava-1.5-7b":
-        return LlavaConfig()       # defaults ARE CLIP-L/14-336 + Llama-7B (transformers configuration_llava.py)
+        # defaults ARE CLIP-L/14-336 + Llama-7B (transformers configuration_llava.py); the released
+        # checkpoint extends the vocabulary to 32064 so that image_token_index 32000 is a valid row
+        cfg = LlavaConfig()
+        cfg.text_config.vocab_size = 32064
+        return cfg
     raise ValueError(model_name)
 
 
@@ -122,5 +127,8 @@ def load_model_and_processor(model_name: str, device, seed: int = 0, dtype=None)
         model = LlavaForConditionalGeneration(cfg).to(dtype).to(device)
     model.eval().requires_grad_(False)
     image_token = getattr(cfg, "image_token_index", None) or getattr(cfg, "image_token_id")
+    rows = model.get_input_embeddings().weight.shape[0]
+    if not (0 <= image_token < rows) or cfg.text_config.vocab_size > rows:
+        raise ValueError(f"image token id {image_token} / vocab {cfg.text_config.vocab_size} outside the {rows}-row embedding")
     proc = ToyLlavaProcessor(cfg.text_config.vocab_size, image_token, cfg.vision_config.image_size, cfg.vision_config.patch_size)
     return model, proc
