@@ -1025,6 +1025,25 @@ extern "C" int32_t advx_fused_step_flush(advx_plan* p, int32_t parity, int32_t n
   return ADVX_OK;
 }
 
+extern "C" int32_t advx_fused_update(advx_plan* p, float* pp, float* m, float* v, float* grad_p, const float* mask,
+                                     const float* x0, float eps, const advx_opt_scalars* opt, float* s_next,
+                                     float* v_buf, float* scratch, void* stream) {
+  REQUIRE(p && pp && grad_p && mask && x0 && opt && s_next && v_buf && scratch, ADVX_E_BADARG,
+          "advx_fused_update: null argument");
+  REQUIRE(advx_fused_supported(p), ADVX_E_UNSUPPORTED, "advx_fused_update: plan is not an identity LLaVA plan");
+  REQUIRE(opt->apply, ADVX_E_UNSUPPORTED, "advx_fused_update always takes the optimiser step");
+  int32_t rc = check_opt(opt, m, v);
+  if (rc) return rc;
+  FusedScratch f = carve_fused(p, scratch);
+  const long long n = 3LL * p->info.in_h * p->info.in_w;
+  // one block per 256 pixels: the norm rows have exactly f.bwd_blocks entries
+  hipLaunchKernelGGL(k_fused_update, dim3(f.bwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, pp, m, v, grad_p, mask, x0,
+                     eps, fused_geom(p), to_dev(opt), s_next, v_buf, f.norm_partials, f.hdr);
+  (void)n;
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
 extern "C" int32_t advx_fused_flush(advx_plan* p, float* stats, float* scratch, int32_t image_too, void* stream) {
   REQUIRE(p && stats && scratch, ADVX_E_BADARG, "advx_fused_flush: null argument");
   REQUIRE(advx_fused_supported(p), ADVX_E_UNSUPPORTED, "advx_fused_flush: plan is not an identity LLaVA plan");

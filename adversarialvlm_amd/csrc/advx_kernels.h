@@ -761,6 +761,43 @@ __global__ void __launch_bounds__(kBlock) k_fused_bwd(const float* __restrict__ 
   if (UPDATE) block_sum_store<1>(nacc, norm_partials + blockIdx.x);
 }
 
+// data-parallel tail of the pair: after the all-reduce of grad_p every rank runs this ONE
+// launch - mask, ||g|| partial, optimiser, and the preparation of the next forward (s, v) -
+// so that a DP step is fwd + bwd(grad only) + all-reduce + this (the norm reduction rides in
+// the next forward like in the single-GPU pair).
+__global__ void __launch_bounds__(kBlock) k_fused_update(float* __restrict__ p, float* __restrict__ m,
+                                                         float* __restrict__ v, float* __restrict__ grad,
+                                                         const float* __restrict__ mask, const float* __restrict__ x0,
+                                                         float eps, FusedGeom geo, OptScalars o,
+                                                         float* __restrict__ s_next, float* __restrict__ v_buf,
+                                                         double* __restrict__ norm_partials,
+                                                         FusedHeader* __restrict__ hdr) {
+  const long long n = 3LL * geo.plane;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  double nacc[1] = {0.0};
+  if (i < n) {
+    float g = grad[i] * mask[i];
+    grad[i] = g;
+    nacc[0] = (double)g * (double)g;
+    float pp = p[i];
+    if (o.kind == 0) {
+      float mm = m[i], vv = v[i];
+      adamw_element(pp, mm, vv, g, o);
+      p[i] = pp; m[i] = mm; v[i] = vv;
+    } else {
+      float sg = (g > 0.0f) ? 1.0f : ((g < 0.0f) ? -1.0f : 0.0f);
+      pp = pp - o.lr * sg;
+      p[i] = pp;
+    }
+    const int c = (int)(i / geo.plane);
+    float sn = x0[i] + eps * tanhf(pp);
+    s_next[i] = sn;
+    v_buf[i] = (sn - geo.mean[c]) / geo.stdv[c];
+  }
+  block_sum_store<1>(nacc, norm_partials + blockIdx.x);
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr->norm_blocks = gridDim.x;
+}
+
 // ------------------------------------------------------------------- one launch per step
 // k_fused_step = k_fused_bwd(t) + k_fused_fwd(t+1) for the same 256 pixels, in one block:
 //   A  stream-read g_t[:, block] (the 4 waves split the batch), reduce in LDS

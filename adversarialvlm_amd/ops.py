@@ -169,6 +169,14 @@ def fused_bwd(plan, grad_out, batch, p, x0, epsilon, imgfit_scale, grad_p, stats
                                     L.ptr(scratch), _stream(p)), "advx_fused_bwd")
 
 
+def fused_update(plan, p, m, v, grad_p, mask, x0, epsilon, opt, s_next, v_buf, scratch):
+    """DP tail of the pair: mask, ||g|| partials, optimiser step, preparation of the next forward."""
+    _require_cuda(p, grad_p, mask, x0, s_next, v_buf, scratch)
+    L.check(L.load().advx_fused_update(plan.handle, L.ptr(p), L.ptr(m), L.ptr(v), L.ptr(grad_p), L.ptr(mask), L.ptr(x0),
+                                       float(epsilon), C.byref(opt), L.ptr(s_next), L.ptr(v_buf), L.ptr(scratch), _stream(p)),
+            "advx_fused_update")
+
+
 def fused_step_rows(plan):
     a, b = C.c_int32(), C.c_int32()
     L.check(L.load().advx_fused_step_rows(plan.handle, C.byref(a), C.byref(b)), "advx_fused_step_rows")

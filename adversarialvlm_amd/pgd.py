@@ -231,8 +231,9 @@ class PixelPGD:
                               self.fused_scratch)
                 # one exchange per step: the shared image gradient (P_in*4 bytes) over RCCL/xGMI
                 dp.allreduce_image_grad_(self.grad, self.pg)
-                ops.update(self.p, self.m, self.v, self.grad, self.mask, opt, self.stats, self.upd_scratch)
-                self.prepared = False
+                # one launch: mask, ||g|| partials, optimiser, s/v of the next forward
+                ops.fused_update(pl, self.p, self.m, self.v, self.grad, self.mask, self.x0, self.eps, opt,
+                                 self.s_bufs[nxt], self.v_buf, self.fused_scratch)
             self.s_cur = nxt          # the next forward's image goes to the other buffer: image() stays valid
         else:
             for i, (pl, g, B) in enumerate(zip(self.plans, grads, st["batches"])):

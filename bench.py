@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="time the generic (unfused) kernel chain instead")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                                                       "the multi-rank path on one GPU)")
     ap.add_argument("--chain", default="auto", choices=["auto", "pair", "step"],
                     help="fused chain: step = one launch per step (single GPU), pair = two launches")
     args = ap.parse_args()
@@ -80,12 +82,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    local_rank = local_rank % max(1, torch.cuda.device_count())      # rehearsal: several ranks on one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(args.backend)
         pg = torch.distributed.group.WORLD
 
     from adversarialvlm_amd.build import build_library

@@ -221,6 +221,13 @@ int32_t advx_fused_bwd(advx_plan* plan, const float* grad_out, int32_t batch, fl
                        float epsilon, float imgfit_scale, const float* mask, float* m, float* v,
                        float* grad_p, const advx_opt_scalars* opt, float* s_next, float* v_buf,
                        float* stats, float* scratch, void* stream);
+/* Data-parallel tail of the pair: after advx_fused_bwd(opt = NULL) and the all-reduce of
+ * grad_p, ONE launch masks the gradient, leaves the ||g|| partials (reduced by the next
+ * advx_fused_fwd / advx_fused_flush), takes the optimiser step and prepares s / v of the next
+ * forward - which may then be called with prepared = 1. */
+int32_t advx_fused_update(advx_plan* plan, float* p, float* m, float* v, float* grad_p, const float* mask,
+                          const float* x0, float epsilon, const advx_opt_scalars* opt, float* s_next,
+                          float* v_buf, float* scratch, void* stream);
 int64_t advx_fused_scratch_floats(const advx_plan* plan);
 int32_t advx_fused_flush(advx_plan* plan, float* stats, float* scratch, int32_t image_too, void* stream);
 

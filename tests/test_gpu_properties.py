@@ -1,0 +1,110 @@
+"""GPU tier: size-independent properties at BASELINE.json's full sizes - the checks that do not
+need the (slow) CPU oracle.
+
+  * adjointness:  <emit(x), g> == <x, collect(g)>  for every plan (the forward is linear in the
+    image up to the constant padding / normalisation offset, so the identity holds for
+    differences), and the same for blur and crop-resize;
+  * linearity of the batch reduction and of collect in g; zero tiles stay exact zeros;
+  * idempotence of the quantiser statistics on lattice images; mask idempotence.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _plans():
+    from adversarialvlm_amd.plan import Plan
+    return [("llava-336", Plan.llava(336, 336)), ("llava-512", Plan.llava(512, 512)), ("mllama-336", Plan.mllama(336, 336)),
+            ("mllama-1352x1988", Plan.mllama(1352, 1988)), ("phi3-512", Plan.phi3(512, 512)),
+            ("phi3-tall", Plan.phi3(900, 500)), ("qwen-512", Plan.qwen2vl(512, 512)), ("qwen-336", Plan.qwen2vl(336, 336))]
+
+
+@pytest.mark.parametrize("name", [n for n, _ in _plans()])
+def test_emit_collect_adjoint_full_size(dev, name):
+    from adversarialvlm_amd import ops
+    plan = dict(_plans())[name]
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    xa = torch.rand(3, plan.in_h, plan.in_w, generator=gen).to(dev)
+    xb = torch.rand(3, plan.in_h, plan.in_w, generator=gen).to(dev)
+    B = 3
+    g = torch.randn(B, plan.out_numel, generator=gen).to(dev)
+    # emit is affine in the image: E(xa) - E(xb) = L(xa - xb), repeated over the batch
+    d_out = (ops.emit(plan, xa, B) - ops.emit(plan, xb, B)).double()
+    lhs = float((d_out * g.double()).sum())
+    gx = ops.collect(plan, g, B).double()
+    rhs = float(((xa - xb).double() * gx).sum())
+    assert lhs == pytest.approx(rhs, rel=2e-5, abs=1e-3), (lhs, rhs)
+    # linearity of collect in g
+    g2 = torch.randn(B, plan.out_numel, generator=gen).to(dev)
+    lin = ops.collect(plan, g + 2 * g2, B) - (ops.collect(plan, g, B) + 2 * ops.collect(plan, g2, B))
+    assert float(lin.abs().max()) <= 2e-5 * float(gx.abs().max() + 1)
+
+
+def test_blur_and_crop_adjoint_full_size(dev):
+    from adversarialvlm_amd import ops
+    gen = torch.Generator().manual_seed(2)
+    for H, W in [(336, 336), (512, 512), (301, 517)]:
+        x = torch.randn(3, H, W, generator=gen).to(dev)
+        g = torch.randn(3, H, W, generator=gen).to(dev)
+        for k, sig in [(5, 7.0), (9, 10.0), (31, 3.3)]:
+            lhs = float((ops.blur_fwd(x, k, sig).double() * g.double()).sum())
+            rhs = float((x.double() * ops.blur_bwd(g, k, sig).double()).sum())
+            assert lhs == pytest.approx(rhs, rel=1e-5, abs=1e-3)
+        for crop in [(10, 20, H - 40, W - 50), (0, 0, H, W), (H // 3, W // 4, H // 2, W // 2)]:
+            lhs = float((ops.crop_resize_fwd(x, crop).double() * g.double()).sum())
+            rhs = float((x.double() * ops.crop_resize_bwd(g, crop).double()).sum())
+            assert lhs == pytest.approx(rhs, rel=1e-5, abs=1e-3)
+
+
+def test_batch_reduce_linear_and_full_size(dev):
+    from adversarialvlm_amd import ops
+    n = 3 * 336 * 336
+    a = torch.randn(64, n, device=dev)
+    b = torch.randn(64, n, device=dev)
+    ra, rb, rab = ops.batch_reduce(a), ops.batch_reduce(b), ops.batch_reduce(a + b)
+    assert float((rab - (ra + rb)).abs().max()) < 1e-4
+    assert torch.allclose(ra, a.double().sum(0).float(), atol=2e-5)
+
+
+def test_zero_tiles_and_padding_are_constant(dev):
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan
+    plan = Plan.mllama(336, 336)
+    a = ops.emit(plan, torch.rand(3, 336, 336, device=dev), 2).view(2, 4, 3, 560, 560)
+    assert torch.count_nonzero(a[:, 1:]) == 0
+    p3 = Plan.phi3(336, 336)
+    b = ops.emit(p3, torch.rand(3, 336, 336, device=dev), 1).view(7, 3, 336, 336)
+    assert torch.count_nonzero(b[p3.info.num_tiles:]) == 0 and torch.count_nonzero(b[:p3.info.num_tiles]) > 0
+
+
+def test_quantiser_statistics_vanish_on_lattice_images(dev):
+    """q(s) == s on the 256-level lattice: the error statistics of such an image are exactly 0."""
+    from adversarialvlm_amd import _lib as L, ops
+    x0 = (torch.randint(0, 256, (3, 336, 336)).float() / 255).to(dev)
+    stats = torch.zeros(L.STATS_N, device=dev)
+    scratch = ops.image_scratch(336, 336, 0, dev)
+    ops.image_fwd(torch.zeros_like(x0), x0, 0.5, stats, scratch)
+    st = stats.cpu()
+    assert float(st[L.STAT_QERR_STD]) == 0.0 and float(st[L.STAT_QERR_MEAN]) == 0.0 and float(st[L.STAT_QERR_L1]) == 0.0
+
+
+def test_masked_pixels_never_move(dev):
+    from adversarialvlm_amd.pgd import PixelPGD
+    from adversarialvlm_amd.plan import Plan
+    x0 = torch.rand(3, 336, 336, device=dev)
+    mask = torch.zeros(3, 336, 336, device=dev)
+    mask[:, :100, :100] = 1
+    for mode in ("pair", "step"):
+        eng = PixelPGD(x0, [Plan.llava(336, 336)], mask=mask, fused_mode=mode)
+        g = torch.randn(8, 3, 336, 336, device=dev)
+        for _ in range(3):
+            eng.forward(8)
+            eng.backward_update([g])
+        assert torch.count_nonzero(eng.p[:, 100:, :]) == 0 and torch.count_nonzero(eng.p[:, :, 100:]) == 0
+        assert torch.count_nonzero(eng.p[:, :100, :100]) > 0
