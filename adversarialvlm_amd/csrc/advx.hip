@@ -909,7 +909,7 @@ extern "C" int32_t advx_fused_fwd(advx_plan* p, const float* pp, const float* x0
   }
   int gx, slices, bps;
   emit_slices(n4, batch, &gx, &slices, &bps);
-  dim3 grid(gx, slices);
+  dim3 grid(gx, slices + 1);  // y == 0: statistics blocks, y >= 1: batch slices
   int noise = unit_noise ? 1 : (use_philox ? 2 : 0);
 #define ADVX_FF(N)                                                                                               \
   ADVX_LAUNCH_TIMED(PROF_FWD, k_fused_fwd<N>, grid, dim3(kBlock), st, (const float*)v_buf, (const float*)s_buf, x0, n, batch, \
