@@ -951,18 +951,18 @@ extern "C" int32_t advx_fused_bwd(advx_plan* p, const float* g, int32_t batch, f
   return ADVX_OK;
 }
 
-// persistent grid of the wave-specialised step: a fixed number of 512-thread workgroups per CU
-static int step_grid(int n_groups) {
-  static int per_cu = -1, cus = 0;
-  if (per_cu < 0) {
-    const char* e = std::getenv("ADVX_STEP_BLOCKS_PER_CU");
-    per_cu = e ? std::max(1, std::min(4, std::atoi(e))) : 2;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    if (cus <= 0) cus = 256;
+// grid of the one-launch step: one wave per 64 pixels, four waves per block, at most
+// ADVX_STEP_MAX_BLOCKS blocks (then waves loop over several groups); never more blocks than
+// the row buffers hold (one partial row per block, f.bwd_blocks rows)
+static int step_grid(long long n) {
+  static int cap = -1;
+  if (cap < 0) {
+    const char* e = std::getenv("ADVX_STEP_MAX_BLOCKS");
+    cap = e ? std::max(64, std::atoi(e)) : 2048;
   }
-  return std::max(1, std::min(n_groups, per_cu * cus));
+  long long groups = (n + kWave - 1) / kWave;
+  long long blocks = (groups + (kBlock / kWave) - 1) / (kBlock / kWave);   // == ceil(n / 256) == bwd_blocks
+  return (int)std::max<long long>(1, std::min<long long>(blocks, cap));
 }
 
 extern "C" int32_t advx_fused_step(advx_plan* p, const float* g, int32_t batch, float* pp, const float* x0, float eps,
@@ -995,11 +995,12 @@ extern "C" int32_t advx_fused_step(advx_plan* p, const float* g, int32_t batch, 
   rows.norm_rows_in = norm_rows_in;
   rows.norm_out = f.norm_rows[1 - parity];
   int noise = unit_noise_next ? 1 : (use_philox ? 2 : 0);
-  const int grid = step_grid(f.bwd_blocks);
+  const long long n_groups = (n + kWave - 1) / kWave;
+  const int grid = step_grid(n);
 #define ADVX_FS(N)                                                                                                      \
-  ADVX_LAUNCH_TIMED(PROF_STEP, k_fused_step_ws<N>, dim3(grid), dim3(kStepThreads), st, g, batch, pp, x0, eps, fused_geom(p), \
+  ADVX_LAUNCH_TIMED(PROF_STEP, k_fused_step_wave<N>, dim3(grid), dim3(kBlock), st, g, batch, pp, x0, eps, fused_geom(p), \
                     c_fit, mask, m, v, grad_p, to_dev(opt), s_next, v_buf, unit_noise_next, seed, offset_next, out_next, \
-                    rows, stats, f.bwd_blocks)
+                    rows, stats, n_groups)
   if (noise == 0) ADVX_FS(0); else if (noise == 1) ADVX_FS(1); else ADVX_FS(2);
 #undef ADVX_FS
   LAUNCH_CHECK();
@@ -1010,7 +1011,7 @@ extern "C" int32_t advx_fused_step_rows(const advx_plan* p, int32_t* rows_after_
   REQUIRE(p && rows_after_fwd && rows_after_step, ADVX_E_BADARG, "advx_fused_step_rows: null argument");
   long long n4 = (3LL * p->info.in_h * p->info.in_w) >> 2;
   *rows_after_fwd = (int32_t)((n4 + kBlock - 1) / kBlock);
-  *rows_after_step = (int32_t)step_grid((int)((n4 + kWave - 1) / kWave));
+  *rows_after_step = (int32_t)step_grid(3LL * p->info.in_h * p->info.in_w);
   return ADVX_OK;
 }
 

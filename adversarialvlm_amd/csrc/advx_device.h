@@ -209,4 +209,12 @@ __device__ inline float4 philox_normal4(unsigned long long gidx, unsigned long l
   return z;
 }
 
+// per-pixel addressing used by the one-launch step (lane = pixel): one Philox block gives the
+// noise of four consecutive batch rows (4*bq .. 4*bq+3) of pixel i
+__device__ inline float4 philox_normal4_pixel(unsigned long long i, unsigned bq, unsigned long long offset,
+                                              unsigned long long seed) {
+  // distinct from philox_normal4's counter space through the key (seed high word is perturbed)
+  return philox_normal4(i, (offset << 20) | (unsigned long long)(bq & 0xFFFFFu), seed ^ 0x9E3779B97F4A7C15ULL);
+}
+
 }  // namespace advx

@@ -810,19 +810,24 @@ __global__ void __launch_bounds__(kBlock) k_fused_update(float* __restrict__ p, 
 }
 
 // ------------------------------------------------------------------- one launch per step
-// k_fused_step = k_fused_bwd(t) + k_fused_fwd(t+1) for the same 256 pixels, in one block:
-//   A  stream-read g_t[:, block] (the 4 waves split the batch), reduce in LDS
-//   B  per pixel: /std, image-fit term, tanh', mask, ||g||, optimiser -> p_{t+1};
-//      s_{t+1}, v_{t+1}; statistics partials of s_{t+1}
-//   C  stream-write out_{t+1}[:, block] = v_{t+1} + sigma_{t+1} * N(0,1) (waves split the batch)
+// k_fused_step_wave = k_fused_bwd(t) + k_fused_fwd(t+1) for the same pixels in ONE launch:
+// grad_out of step t in, pixel_values of step t+1 out.
+// WAVE-INDEPENDENT: lane = one pixel; a wave owns 64 pixels (256-byte rows) and, for them,
+//   A  sums grad_out over the whole batch (fixed order, 8 loads in flight per lane),
+//   B  /std, image-fit term, tanh', mask, ||g||, optimiser -> p_{t+1}; s_{t+1}, v_{t+1};
+//      statistics of s_{t+1} accumulate in registers,
+//   C  emits out_{t+1}[b, pixel] = v_{t+1} + sigma_{t+1} N(0,1) for every b (one Philox block
+//      serves four consecutive b of the lane's pixel).
+// No LDS and no barrier between A, B and C, so waves drift apart and the load stream (A) of
+// some waves overlaps the noise generation and store stream (C) of others on the same SIMD -
+// what a workgroup-synchronous version (4 waves splitting the batch, LDS combine) could not
+// do: it kept every workgroup in lockstep and was slower than two separate launches.
 // sigma_{t+1} = std(|q(s_t) - s_t|) needs a global reduction over s_t: its partial rows were
-// left by the PREVIOUS launch (kernel boundary = visibility), and every block re-reduces
-// the two columns it needs in the same fixed order - redundant L2 reads instead of a grid
-// barrier.  Partial rows are double-buffered (`rows_in` / `rows_out`) because early blocks of
-// this launch write the next rows while late blocks still read the current ones.  Block 0
-// also publishes the statistics of s_t and ||g_{t-1}|| to `stats`.
-// With ~5 blocks resident per CU and phases A (memory) and C (VALU + stores) alternating,
-// the load stream of one block overlaps the noise generation of another.
+// left by the PREVIOUS launch (kernel boundary = visibility) and every block re-reduces the
+// two columns it needs in the same fixed order - redundant L2 reads instead of a grid barrier.
+// Rows are double-buffered because early blocks of this launch write the next rows while late
+// blocks still read the current ones.  Block 0 also publishes the statistics of s_t and
+// ||g_{t-1}|| to `stats`.
 struct StepRows {
   const double* img_in;    // [img_rows_in][kStatSlots]  statistics partials of s_t
   int img_rows_in;
@@ -833,142 +838,24 @@ struct StepRows {
 };
 
 template <int NOISE>
-__global__ void __launch_bounds__(kBlock) k_fused_step(const float* __restrict__ g, int batch, float* __restrict__ p,
-                                                       const float* __restrict__ x0, float eps, FusedGeom geo,
-                                                       float c_fit, const float* __restrict__ mask,
-                                                       float* __restrict__ m, float* __restrict__ v,
-                                                       float* __restrict__ grad_p, OptScalars o,
-                                                       float* __restrict__ s_next, float* __restrict__ v_buf,
-                                                       const float* __restrict__ unit_noise, unsigned long long seed,
-                                                       unsigned long long offset, float* __restrict__ out,
-                                                       StepRows rows, float* __restrict__ stats) {
-  __shared__ float4 part4[kBlock / kWave][kWave];
-  __shared__ float4 vsh4[kWave];
+__global__ void __launch_bounds__(kBlock) k_fused_step_wave(const float* __restrict__ g, int batch, float* __restrict__ p,
+                                                            const float* __restrict__ x0, float eps, FusedGeom geo,
+                                                            float c_fit, const float* __restrict__ mask,
+                                                            float* __restrict__ m, float* __restrict__ v,
+                                                            float* __restrict__ grad_p, OptScalars o,
+                                                            float* __restrict__ s_next, float* __restrict__ v_buf,
+                                                            const float* __restrict__ unit_noise, unsigned long long seed,
+                                                            unsigned long long offset, float* __restrict__ out,
+                                                            StepRows rows, float* __restrict__ stats, long long n_groups) {
   __shared__ double sig2[2];
   const long long n = 3LL * geo.plane;
-  const long long n4 = n >> 2;
-  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  const long long q = (long long)blockIdx.x * kWave + lane;
-  const long long i = (long long)blockIdx.x * (kWave * 4) + threadIdx.x;
-  // ---- prefetch this thread's pixel state
-  float pp = 0.f, xv = 0.f, mk = 0.f, mm = 0.f, vv = 0.f;
-  if (i < n) {
-    pp = p[i];
-    xv = x0[i];
-    mk = mask[i];
-    if (o.kind == 0) {
-      mm = m[i];
-      vv = v[i];
-    }
-  }
+  const int lane = threadIdx.x & (kWave - 1);
+  const long long wave = ((long long)blockIdx.x * kBlock + threadIdx.x) / kWave;
+  const long long nwaves = (long long)gridDim.x * (kBlock / kWave);
   // ---- sigma_{t+1}: fixed-order reduction of columns 0,1 of the current partial rows
   {
     double acc[2] = {0.0, 0.0};
     for (int r = threadIdx.x; r < rows.img_rows_in; r += kBlock) {
-      acc[0] += rows.img_in[(size_t)r * kStatSlots + 0];
-      acc[1] += rows.img_in[(size_t)r * kStatSlots + 1];
-    }
-    block_sum_store<2>(acc, sig2);
-  }
-  double N = (double)n;
-  double var_d = (n > 1) ? (sig2[1] - sig2[0] * sig2[0] / N) / (N - 1.0) : 0.0;
-  const float sigma = (float)sqrt(var_d > 0.0 ? var_d : 0.0);
-  if (blockIdx.x == 0) {
-    // publish the statistics of s_t (rotating SIGMA) and the previous step's gradient norm
-    finalize_image_block<true>(rows.img_in, rows.img_rows_in, n, stats);
-    if (rows.norm_rows_in > 0) finalize_norm_block(rows.norm_in, rows.norm_rows_in, stats);
-  }
-  // ---- A: batch reduction
-  float4 a = make_float4(0, 0, 0, 0);
-  if (q < n4) a = batch_column_sum(g, batch, n, q << 2, wid, kBlock / kWave);
-  part4[wid][lane] = a;
-  __syncthreads();
-  const float(*part)[kWave * 4] = reinterpret_cast<const float(*)[kWave * 4]>(&part4[0][0]);
-  float* vsh = reinterpret_cast<float*>(&vsh4[0]);
-  // ---- B: per-pixel update and preparation
-  double nacc[1] = {0.0};
-  double sacc[kStatSlots] = {0, 0, 0, 0, 0, 0};
-  float vn = 0.0f;
-  if (i < n) {
-    float gs = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
-    const int c = (int)(i / geo.plane);
-    const float sd = geo.stdv[c];
-    float t = tanhf(pp);
-    float s = xv + eps * t;
-    float gx = gs / sd + imgfit_grad(s, c_fit);
-    float gp = ((gx * eps) * (1.0f - t * t)) * mk;
-    nacc[0] = (double)gp * (double)gp;
-    grad_p[i] = gp;
-    if (o.kind == 0) {
-      adamw_element(pp, mm, vv, gp, o);
-      p[i] = pp; m[i] = mm; v[i] = vv;
-    } else {
-      float sg = (gp > 0.0f) ? 1.0f : ((gp < 0.0f) ? -1.0f : 0.0f);
-      pp = pp - o.lr * sg;
-      p[i] = pp;
-    }
-    float xn = eps * tanhf(pp);
-    float sn = xv + xn;
-    vn = (sn - geo.mean[c]) / sd;
-    s_next[i] = sn;
-    v_buf[i] = vn;
-    stat_accumulate(sn, xn, sacc);
-  }
-  vsh[threadIdx.x] = vn;
-  block_sum_store<1>(nacc, rows.norm_out + blockIdx.x);
-  block_sum_store<kStatSlots>(sacc, rows.img_out + (size_t)blockIdx.x * kStatSlots);  // ends with a barrier: vsh visible
-  // ---- C: emit the next forward's rows of this block
-  if (q < n4) {
-    const float4 v4 = vsh4[lane];
-    const long long i0 = q << 2;
-    for (int b = wid; b < batch; b += kBlock / kWave) {
-      float4 ov = v4;
-      if (NOISE == 1) {
-        float4 z = *reinterpret_cast<const float4*>(unit_noise + (size_t)b * n + i0);
-        ov = make_float4(v4.x + z.x * sigma, v4.y + z.y * sigma, v4.z + z.z * sigma, v4.w + z.w * sigma);
-      } else if (NOISE == 2) {
-        float4 z = philox_normal4((unsigned long long)b * (unsigned long long)n4 + (unsigned long long)q, offset, seed);
-        ov = make_float4(v4.x + z.x * sigma, v4.y + z.y * sigma, v4.z + z.z * sigma, v4.w + z.w * sigma);
-      }
-      *reinterpret_cast<float4*>(out + (size_t)b * n + i0) = ov;
-    }
-  }
-}
-
-// ---------------------------------------------------- one launch per step, wave-specialised
-// Same contract as k_fused_step, but built so that the gradient stream and the noise
-// generation really overlap: a persistent 512-thread workgroup whose waves 0-3 (R) reduce and
-// update pixel group j while waves 4-7 (E) emit group j-1, handing v over through a 2-slot
-// LDS ring.  The memory-bound role and the VALU-bound role share every SIMD of the CU at
-// the same time, from the second slot on.  CDNA has one hardware barrier per workgroup, so
-// both roles meet at the same two barriers per slot (E simply splits its batch in two).
-constexpr int kStepThreads = 512;
-
-template <int NOISE>
-__global__ void __launch_bounds__(kStepThreads) k_fused_step_ws(const float* __restrict__ g, int batch,
-                                                                float* __restrict__ p, const float* __restrict__ x0,
-                                                                float eps, FusedGeom geo, float c_fit,
-                                                                const float* __restrict__ mask, float* __restrict__ m,
-                                                                float* __restrict__ v, float* __restrict__ grad_p,
-                                                                OptScalars o, float* __restrict__ s_next,
-                                                                float* __restrict__ v_buf,
-                                                                const float* __restrict__ unit_noise,
-                                                                unsigned long long seed, unsigned long long offset,
-                                                                float* __restrict__ out, StepRows rows,
-                                                                float* __restrict__ stats, int n_groups) {
-  __shared__ float4 part4[4][kWave];
-  __shared__ float4 vring[2][kWave];
-  __shared__ double sig2[2];
-  const long long n = 3LL * geo.plane;
-  const long long n4 = n >> 2;
-  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  const bool is_r = wid < 4;
-  const int rw = wid & 3;                 // wave index inside its role
-  const int rtid = threadIdx.x & 255;     // thread index inside its role
-  // ---- sigma_{t+1}: every block reduces columns 0,1 of the current rows in the same order
-  {
-    double acc[2] = {0.0, 0.0};
-    for (int r = threadIdx.x; r < rows.img_rows_in; r += kStepThreads) {
       acc[0] += rows.img_in[(size_t)r * kStatSlots + 0];
       acc[1] += rows.img_in[(size_t)r * kStatSlots + 1];
     }
@@ -981,107 +868,70 @@ __global__ void __launch_bounds__(kStepThreads) k_fused_step_ws(const float* __r
     finalize_image_block<true>(rows.img_in, rows.img_rows_in, n, stats);
     if (rows.norm_rows_in > 0) finalize_norm_block(rows.norm_in, rows.norm_rows_in, stats);
   }
-  const int G = (n_groups > (int)blockIdx.x) ? (n_groups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-  const int per_wave = (batch + 3) >> 2;      // emission iterations of one E wave
-  const int half = (per_wave + 1) >> 1;
   double nacc[1] = {0.0};
   double sacc[kStatSlots] = {0, 0, 0, 0, 0, 0};
-  float pp = 0.f, xv = 0.f, mk = 0.f, mm = 0.f, vv = 0.f;
-  for (int j = 0; j <= G; ++j) {
-    const int grp_r = (int)blockIdx.x + j * (int)gridDim.x;          // group the R waves work on
-    const int grp_e = (int)blockIdx.x + (j - 1) * (int)gridDim.x;    // group the E waves emit
-    const long long ir = (long long)grp_r * 256 + rtid;              // pixel owned by an R thread
-    float4 v4 = make_float4(0, 0, 0, 0);
-    long long qe = 0;
-    // ------------------------------------------------------------------ first half
-    if (is_r) {
-      if (j < G) {
-        if (ir < n) {
-          pp = p[ir];
-          xv = x0[ir];
-          mk = mask[ir];
-          if (o.kind == 0) {
-            mm = m[ir];
-            vv = v[ir];
-          }
-        }
-        const long long q = (long long)grp_r * kWave + lane;
-        float4 a = make_float4(0, 0, 0, 0);
-        if (q < n4) a = batch_column_sum(g, batch, n, q << 2, rw, 4);
-        part4[rw][lane] = a;
+  for (long long grp = wave; grp < n_groups; grp += nwaves) {
+    const long long i = grp * kWave + lane;
+    if (i >= n) continue;
+    // ---- A: this pixel's state and its gradient column
+    float pp = p[i];
+    const float xv = x0[i];
+    const float mk = mask[i];
+    float mm = 0.f, vv = 0.f;
+    if (o.kind == 0) {
+      mm = m[i];
+      vv = v[i];
+    }
+    float gs = 0.0f;
+    {
+      int b = 0;
+      for (; b + 8 <= batch; b += 8) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = g[(size_t)(b + k) * n + i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gs += t[k];
       }
-    } else if (j >= 1) {
-      qe = (long long)grp_e * kWave + lane;
-      v4 = vring[(j - 1) & 1][lane];
-      if (qe < n4) {
-        for (int t = 0; t < half; ++t) {
-          const int b = rw + 4 * t;
-          if (b < batch) {
-            float4 ov = v4;
-            if (NOISE == 1) {
-              float4 z = *reinterpret_cast<const float4*>(unit_noise + (size_t)b * n + (qe << 2));
-              ov = make_float4(v4.x + z.x * sigma, v4.y + z.y * sigma, v4.z + z.z * sigma, v4.w + z.w * sigma);
-            } else if (NOISE == 2) {
-              float4 z = philox_normal4((unsigned long long)b * (unsigned long long)n4 + (unsigned long long)qe, offset, seed);
-              ov = make_float4(v4.x + z.x * sigma, v4.y + z.y * sigma, v4.z + z.z * sigma, v4.w + z.w * sigma);
-            }
-            *reinterpret_cast<float4*>(out + (size_t)b * n + (qe << 2)) = ov;
-          }
+      for (; b < batch; ++b) gs += g[(size_t)b * n + i];
+    }
+    // ---- B: update and preparation
+    const int c = (int)(i / geo.plane);
+    const float sd = geo.stdv[c];
+    float t = tanhf(pp);
+    float s = xv + eps * t;
+    float gx = gs / sd + imgfit_grad(s, c_fit);
+    float gp = ((gx * eps) * (1.0f - t * t)) * mk;
+    nacc[0] += (double)gp * (double)gp;
+    grad_p[i] = gp;
+    if (o.kind == 0) {
+      adamw_element(pp, mm, vv, gp, o);
+      p[i] = pp; m[i] = mm; v[i] = vv;
+    } else {
+      float sg = (gp > 0.0f) ? 1.0f : ((gp < 0.0f) ? -1.0f : 0.0f);
+      pp = pp - o.lr * sg;
+      p[i] = pp;
+    }
+    const float xn = eps * tanhf(pp);
+    const float sn = xv + xn;
+    const float vn = (sn - geo.mean[c]) / sd;
+    s_next[i] = sn;
+    v_buf[i] = vn;
+    stat_accumulate(sn, xn, sacc);
+    // ---- C: emit this pixel for every b
+    for (int b = 0; b < batch; b += 4) {
+      float z[4] = {0.f, 0.f, 0.f, 0.f};
+      if (NOISE == 2) {
+        float4 zz = philox_normal4_pixel((unsigned long long)i, (unsigned)(b >> 2), offset, seed);
+        z[0] = zz.x; z[1] = zz.y; z[2] = zz.z; z[3] = zz.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (b + k < batch) {
+          if (NOISE == 1) z[k] = unit_noise[(size_t)(b + k) * n + i];
+          __builtin_nontemporal_store(vn + z[k] * sigma, out + (size_t)(b + k) * n + i);
         }
       }
     }
-    __syncthreads();
-    // ----------------------------------------------------------------- second half
-    if (is_r) {
-      if (j < G) {
-        const float(*part)[kWave * 4] = reinterpret_cast<const float(*)[kWave * 4]>(&part4[0][0]);
-        float vn = 0.0f;
-        if (ir < n) {
-          float gs = ((part[0][rtid] + part[1][rtid]) + part[2][rtid]) + part[3][rtid];
-          const int c = (int)(ir / geo.plane);
-          const float sd = geo.stdv[c];
-          float t = tanhf(pp);
-          float s = xv + eps * t;
-          float gx = gs / sd + imgfit_grad(s, c_fit);
-          float gp = ((gx * eps) * (1.0f - t * t)) * mk;
-          nacc[0] += (double)gp * (double)gp;
-          grad_p[ir] = gp;
-          if (o.kind == 0) {
-            adamw_element(pp, mm, vv, gp, o);
-            p[ir] = pp; m[ir] = mm; v[ir] = vv;
-          } else {
-            float sg = (gp > 0.0f) ? 1.0f : ((gp < 0.0f) ? -1.0f : 0.0f);
-            pp = pp - o.lr * sg;
-            p[ir] = pp;
-          }
-          float xn = eps * tanhf(pp);
-          float sn = xv + xn;
-          vn = (sn - geo.mean[c]) / sd;
-          s_next[ir] = sn;
-          v_buf[ir] = vn;
-          stat_accumulate(sn, xn, sacc);
-        }
-        reinterpret_cast<float*>(&vring[j & 1][0])[rtid] = vn;
-      }
-    } else if (j >= 1) {
-      if (qe < n4) {
-        for (int t = half; t < per_wave; ++t) {
-          const int b = rw + 4 * t;
-          if (b < batch) {
-            float4 ov = v4;
-            if (NOISE == 1) {
-              float4 z = *reinterpret_cast<const float4*>(unit_noise + (size_t)b * n + (qe << 2));
-              ov = make_float4(v4.x + z.x * sigma, v4.y + z.y * sigma, v4.z + z.z * sigma, v4.w + z.w * sigma);
-            } else if (NOISE == 2) {
-              float4 z = philox_normal4((unsigned long long)b * (unsigned long long)n4 + (unsigned long long)qe, offset, seed);
-              ov = make_float4(v4.x + z.x * sigma, v4.y + z.y * sigma, v4.z + z.z * sigma, v4.w + z.w * sigma);
-            }
-            *reinterpret_cast<float4*>(out + (size_t)b * n + (qe << 2)) = ov;
-          }
-        }
-      }
-    }
-    __syncthreads();
   }
   block_sum_store<1>(nacc, rows.norm_out + blockIdx.x);
   block_sum_store<kStatSlots>(sacc, rows.img_out + (size_t)blockIdx.x * kStatSlots);

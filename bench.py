@@ -143,7 +143,7 @@ def main():
     steps_per_s = args.steps / dt
     if eng.mode == "step":
         # one launch per step: backward of step t + forward of step t+1 in the same kernel
-        dom_name, dom_bytes, dom_ms = "k_fused_step_ws", bytes_step, step_avg
+        dom_name, dom_bytes, dom_ms = "k_fused_step_wave", bytes_step, step_avg
     elif eng.mode == "pair":
         dom_name, dom_bytes, dom_ms = (("k_fused_fwd", bytes_fwd, fwd_avg) if fwd_avg >= bwd_avg
                                        else ("k_fused_bwd", bytes_bwd, bwd_avg))
@@ -175,7 +175,7 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 5),
                          "kernel_ms": {"k_fused_fwd": round(fwd_avg, 5), "k_fused_bwd": round(bwd_avg, 5),
-                                       "k_fused_step_ws": round(step_avg, 5)},
+                                       "k_fused_step_wave": round(step_avg, 5)},
                          "timed_launches": {k: v[1] for k, v in prof.items()},
                          "step_algorithmic_bytes": bytes_step,
                          "step_frac_of_hbm_peak": round(bytes_step * steps_per_s / 1e9 / HBM_PEAK_GBS, 4)},

@@ -105,9 +105,11 @@ def test_sign_optimizer_step_chain(dev):
                 fused_mode="step", noise_ahead=True)
 
 
-def test_fused_chains_agree_bitwise(dev):
-    """pair (two launches) and step (one launch) are the same arithmetic in the same order:
-    identical p, statistics and Philox-noised pixel_values, bit for bit."""
+def test_fused_chains_agree(dev):
+    """pair (two launches) and step (one launch) are the same arithmetic; they differ in the
+    order the batch is summed (four partial columns vs one column per pixel) and in how the
+    Philox counter is addressed, so p / statistics / image agree to rounding and the emitted
+    noise agrees in distribution."""
     from adversarialvlm_amd.pgd import PixelPGD
     Plan = _plans()
     x0 = torch.rand(3, 112, 112, generator=torch.Generator().manual_seed(3)).to(dev)
@@ -119,16 +121,17 @@ def test_fused_chains_agree_bitwise(dev):
         for _ in range(4):
             outs.append(eng.forward(8)[0].clone())
             eng.backward_update([g])
-        runs[mode] = (eng.p.clone(), outs, eng.stats_dict(), eng.image().clone())
-    assert torch.equal(runs["pair"][0], runs["step"][0])
-    for a, b in zip(runs["pair"][1], runs["step"][1]):
-        assert torch.equal(a, b)
+        clean = eng.forward(8, use_philox=False)[0].clone()
+        runs[mode] = (eng.p.clone(), outs, eng.stats_dict(), eng.image().clone(), clean)
+    assert rel_err(runs["pair"][0].cpu(), runs["step"][0].cpu()) < 1e-5
+    assert rel_err(runs["pair"][4].cpu(), runs["step"][4].cpu()) < 1e-6
     for k, v in runs["pair"][2].items():
-        if k in ("x_mean", "x_std"):      # pair: x recovered as s - x0 ; step: eps*tanh(p) directly
-            assert v == pytest.approx(runs["step"][2][k], rel=1e-5, abs=1e-9)
-        else:
-            assert v == runs["step"][2][k], k
-    assert torch.equal(runs["pair"][3], runs["step"][3])
+        assert v == pytest.approx(runs["step"][2][k], rel=1e-4, abs=1e-9), k
+    assert rel_err(runs["pair"][3].cpu(), runs["step"][3].cpu()) < 1e-6
+    # the last emission of the step chain came from the one-launch kernel: unit-variance noise
+    sig = runs["step"][2]["sigma"]
+    z = ((runs["step"][1][3] - runs["pair"][1][3]).cpu() / sig).flatten()     # difference of two N(0,1) draws
+    assert abs(float(z.mean())) < 2e-2 and abs(float(z.std()) - 2 ** 0.5) < 3e-2
 
 
 def test_llava_downsample_blur_crop_mask_accum(dev):
