@@ -126,7 +126,8 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
           crop_scale_max=1.0, crop_ratio_min=0.75, crop_ratio_max=1.33,
           # --- additions of this framework (defaults reproduce the reference behaviour)
           questions_file=None, test_questions_file=None, answers_file=None, optimizer="adamw", log_every=1,
-          use_wandb=False, seed=0, base_path="./runs", components=None, return_engine=False):
+          use_wandb=False, seed=0, base_path="./runs", components=None, return_engine=False,
+          generation_probe=False, resume_from=None):
     if clamp_method != "tanh":
         raise NotImplementedError("Clamping method except tanh are not implemented")       # attack_model.py:186
     if DPO_flag:
@@ -197,7 +198,14 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
     accumulated_loss = 0.0
     refuse_flag = False
     history = []
-    for iteration in range(num_iterations):
+    start_iteration = 0
+    if resume_from:
+        sd = torch.load(resume_from, map_location="cpu")
+        engine.load_state_dict(sd["engine"])
+        global_iteration, start_iteration = int(sd["global_iteration"]), int(sd["iteration"]) + 1
+        random.setstate(sd["py_random"])
+        torch.set_rng_state(sd["torch_rng"])
+    for iteration in range(start_iteration, num_iterations):
         if target_text_random:
             inputs_processor.set_target_text(random.choice(inputs_processor.target_texts))  # :283-290
         inputs = inputs_processor.get_inputs_train()                                        # :292
@@ -231,7 +239,18 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
             logger.log(rec)
         if rank == 0 and (iteration % save_steps == 0 or iteration == num_iterations - 1):  # :410-416 (Q10 naming)
             img = engine.image()
-            save_checkpoint(adv_processor.tensor2pil(img), img, exp_path, global_iteration)
+            pil = adv_processor.tensor2pil(img)
+            save_checkpoint(pil, img, exp_path, global_iteration)
+            # true resume state (not in the reference): optimiser moments, schedules, RNG streams
+            torch.save({"engine": {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in engine.state_dict().items()},
+                        "global_iteration": global_iteration, "iteration": iteration, "py_random": random.getstate(),
+                        "torch_rng": torch.get_rng_state()}, os.path.join(exp_path, f"state_iter_{global_iteration}.pt"))
+            if generation_probe:                                                            # :435-445
+                from .train_test import run_model_test
+                first_row, probe = run_model_test([model], [processor], [inputs_processor], [model_name], test_questions,
+                                                  inputs_processor.target_texts[0], exp_path, iteration, pil,
+                                                  adv_processors=[adv_processor])
+                logger.log(dict(iteration=iteration, **probe))
         if restart_num > 0 and (iteration + 1) % restart_num == 0 and rank == 0:
             print("restart_num has no effect on the optimised tensor in the reference (Q5); ignored")
     if rank == 0:
@@ -283,6 +302,8 @@ def build_parser():
     p.add_argument("--log_every", type=int, default=1)
     p.add_argument("--use_wandb", action="store_true")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--generation_probe", action="store_true", help="greedy-generate the test prompts at every save step")
+    p.add_argument("--resume_from", type=str, default=None, help="state_iter_*.pt written by a previous run")
     return p
 
 

@@ -136,3 +136,38 @@ def test_cross_trainer_two_models(tmp_path):
                                     use_gaussian_blur=True, gblur_kernel_size=5, base_path=str(tmp_path))
     assert len(hist) == 4 and all(np.isfinite(h["loss_per_iteration"]) for h in hist)
     assert "optimized_image_iter_final.png" in os.listdir(os.path.join(str(tmp_path), "t3"))
+
+
+def _kw(tmp, name, iters, **extra):
+    kw = dict(exp_name=name, img_orig=_gray(tmp), prompt="list", target_text="sure here it is",
+              model_name="synthetic/tiny-llava", lr=1e-2, num_iterations=iters, save_steps=3, batch_size=4,
+              grad_accum_steps=1, scheduler_step_size=2, scheduler_gamma=0.8, restart_num=0, mask_type=None,
+              mask_size=None, clamp_method="tanh", epsilon=0.5, sigma=1e-3, start_from_white=False,
+              target_text_random=False, base_path=tmp, seed=3)
+    kw.update(extra)
+    return kw
+
+
+def test_resume_continues_bit_for_bit(tmp_path):
+    """optimiser moments, schedule, RNG streams and noise counters are saved, so
+    4 iterations + resume + 3 more equal 7 iterations in one go, bit for bit."""
+    from adversarialvlm_amd import attack_model
+    tmp = str(tmp_path)
+    attack_model.train(**_kw(tmp, "full", 7))
+    attack_model.train(**_kw(tmp, "part", 4))
+    # iteration 3 (save_steps=3) wrote state_iter_4.pt: resume from it and run iterations 4..6
+    attack_model.train(**_kw(tmp, "rest", 7, resume_from=os.path.join(tmp, "part", "state_iter_4.pt")))
+    a = np.fromfile(os.path.join(tmp, "full", "optimized_image_iter_final.bin"), dtype=np.float32)
+    b = np.fromfile(os.path.join(tmp, "rest", "optimized_image_iter_final.bin"), dtype=np.float32)
+    assert np.array_equal(a, b)
+
+
+def test_generation_probe_writes_reference_csv(tmp_path):
+    import csv
+    from adversarialvlm_amd import attack_model
+    tmp = str(tmp_path)
+    attack_model.train(**_kw(tmp, "probe", 2, generation_probe=True))
+    rows = list(csv.reader(open(os.path.join(tmp, "probe", "test_results_iter_0.csv"))))
+    assert rows[0] == ["question", "synthetic/tiny-llava"] and len(rows) == 1 + 8
+    logged = [json.loads(l) for l in open(os.path.join(tmp, "probe", "metrics.jsonl"))]
+    assert any("test_target_acc" in r for r in logged)

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Step time of the generic kernel chain for the non-identity configurations (development tool)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from adversarialvlm_amd.pgd import PixelPGD  # noqa: E402
+from adversarialvlm_amd.plan import Plan  # noqa: E402
+
+
+def run(name, plans, H, W, B, blur=None, crop=None, steps=50, cross=False):
+    dev = torch.device("cuda:0")
+    x0 = torch.rand(3, H, W, device=dev)
+    eng = PixelPGD(x0, plans, blur_kernel=blur, use_crop=crop is not None, cross_mode=cross, allow_fused=False)
+    gs = [torch.randn(B, pl.out_numel, device=dev) for pl in plans]
+
+    def step():
+        eng.forward(B, blur_sigma=7.0 if blur else None, crop=crop)
+        eng.backward_update(gs)
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    by = 4 * (2 * B * sum(pl.out_numel for pl in plans) + 10 * 3 * H * W)
+    print(f"{name:34s} B={B:3d}  {dt * 1e6:9.1f} us/step  {1 / dt:9.1f} steps/s  algorithmic {by / 1e6:8.1f} MB  "
+          f"{by / dt / 1e12:5.2f} TB/s ({by / dt / 8e12:4.2f} of HBM peak)", flush=True)
+
+
+if __name__ == "__main__":
+    run("llava 336 identity (generic)", [Plan.llava(336, 336)], 336, 336, 64)
+    run("llava 512->336", [Plan.llava(512, 512)], 512, 512, 64)
+    run("llava 512->336 blur9 crop", [Plan.llava(512, 512)], 512, 512, 64, blur=9, crop=(20, 30, 400, 420))
+    run("mllama 336 (4x560 tiles)", [Plan.mllama(336, 336)], 336, 336, 64)
+    run("mllama 336 B=32", [Plan.mllama(336, 336)], 336, 336, 32)
+    run("phi3 512", [Plan.phi3(512, 512)], 512, 512, 64)
+    run("qwen2vl 512", [Plan.qwen2vl(512, 512)], 512, 512, 64)
+    run("cross phi3+qwen+mllama 336 blur5", [Plan.phi3(336, 336), Plan.qwen2vl(336, 336), Plan.mllama(336, 336)], 336, 336,
+        16, blur=5, cross=True)
