@@ -388,6 +388,10 @@ extern "C" int32_t advx_plan_create(const advx_plan_desc* d, advx_plan** out) {
   }
   I.out_numel = 1;
   for (int k = 0; k < I.out_rank; ++k) I.out_numel *= I.out_shape[k];
+  if (I.out_numel >= (1LL << 31)) {   // the layout maps index one sample with 32-bit arithmetic
+    delete p;
+    return fail(ADVX_E_SHAPE, "advx_plan_create: one sample has 2^31 or more elements");
+  }
   for (int k = 0; k < I.n_stage; ++k) I.stage[k] = p->st[k].info;
   // workspace: canvases, gradient buffers of canvases that feed a later stage, gsum
   long long off = 0;

@@ -62,26 +62,31 @@ struct DPlan {
 };
 
 // ------------------------------------------------------------------ layout index maps
+// All per-sample index math is 32-bit unsigned (advx_plan_create rejects plans whose sample
+// has 2^31 or more elements): 64-bit integer division costs several times more on the VALU.
 // flat output index (first temporal copy) of canvas element (c,y,x)
 __device__ __host__ inline long long emit_index(const DEmit& e, int c, int y, int x) {
+  const unsigned base = (unsigned)e.out_begin;
   if (e.kind == ADVX_EMIT_PLAIN) {
-    return e.out_begin + ((long long)c * e.can_h + y) * e.can_w + x;
+    return (long long)(base + ((unsigned)c * (unsigned)e.can_h + (unsigned)y) * (unsigned)e.can_w + (unsigned)x);
   }
   if (e.kind == ADVX_EMIT_TILES) {
-    int tyi = y / e.tile, ty = y - tyi * e.tile;
-    int txi = x / e.tile, tx = x - txi * e.tile;
-    long long t = (long long)tyi * e.tiles_w + txi;
-    return e.out_begin + ((t * 3 + c) * e.tile + ty) * e.tile + tx;
+    unsigned T = (unsigned)e.tile;
+    unsigned tyi = (unsigned)y / T, ty = (unsigned)y - tyi * T;
+    unsigned txi = (unsigned)x / T, tx = (unsigned)x - txi * T;
+    unsigned t = tyi * (unsigned)e.tiles_w + txi;
+    return (long long)(base + ((t * 3u + (unsigned)c) * T + ty) * T + tx);
   }
   // QWEN: row = ((by*(grid_w/merge)+bx)*merge+mh)*merge+mw ; col = ((c*T+t)*P+ph)*P+pw
-  int gy = y / e.patch, ph = y - gy * e.patch;
-  int gx = x / e.patch, pw = x - gx * e.patch;
-  int by = gy / e.merge, mh = gy - by * e.merge;
-  int bx = gx / e.merge, mw = gx - bx * e.merge;
-  long long row = (((long long)by * (e.grid_w / e.merge) + bx) * e.merge + mh) * e.merge + mw;
-  long long col = (((long long)c * e.temporal + 0) * e.patch + ph) * e.patch + pw;
-  long long row_len = 3LL * e.temporal * e.patch * e.patch;
-  return e.out_begin + row * row_len + col;
+  unsigned P = (unsigned)e.patch, M = (unsigned)e.merge;
+  unsigned gy = (unsigned)y / P, ph = (unsigned)y - gy * P;
+  unsigned gx = (unsigned)x / P, pw = (unsigned)x - gx * P;
+  unsigned by = gy / M, mh = gy - by * M;
+  unsigned bx = gx / M, mw = gx - bx * M;
+  unsigned row = ((by * ((unsigned)e.grid_w / M) + bx) * M + mh) * M + mw;
+  unsigned col = (((unsigned)c * (unsigned)e.temporal + 0u) * P + ph) * P + pw;
+  unsigned row_len = 3u * (unsigned)e.temporal * P * P;
+  return (long long)(base + row * row_len + col);
 }
 
 // stride between the temporal copies of one canvas element (QWEN), number of copies
@@ -90,44 +95,46 @@ __device__ __host__ inline long long emit_copy_stride(const DEmit& e) { return (
 
 // inverse: flat index (inside this emit's range) -> canvas element
 __device__ __host__ inline void emit_inverse(const DEmit& e, long long idx, int& c, int& y, int& x) {
-  long long r = idx - e.out_begin;
+  unsigned r = (unsigned)(idx - e.out_begin);
   if (e.kind == ADVX_EMIT_PLAIN) {
-    long long plane = (long long)e.can_h * e.can_w;
-    c = (int)(r / plane);
-    long long q = r - (long long)c * plane;
-    y = (int)(q / e.can_w);
-    x = (int)(q - (long long)y * e.can_w);
+    unsigned W = (unsigned)e.can_w, plane = (unsigned)e.can_h * W;
+    unsigned cc = r / plane;
+    unsigned q = r - cc * plane;
+    unsigned yy = q / W;
+    c = (int)cc;
+    y = (int)yy;
+    x = (int)(q - yy * W);
     return;
   }
   if (e.kind == ADVX_EMIT_TILES) {
-    long long tt = (long long)e.tile * e.tile;
-    long long t = r / (3 * tt);
-    long long q = r - t * 3 * tt;
-    c = (int)(q / tt);
-    q -= (long long)c * tt;
-    int ty = (int)(q / e.tile);
-    int tx = (int)(q - (long long)ty * e.tile);
-    int tyi = (int)(t / e.tiles_w), txi = (int)(t - (long long)tyi * e.tiles_w);
-    y = tyi * e.tile + ty;
-    x = txi * e.tile + tx;
+    unsigned T = (unsigned)e.tile, tt = T * T;
+    unsigned t = r / (3u * tt);
+    unsigned q = r - t * 3u * tt;
+    unsigned cc = q / tt;
+    q -= cc * tt;
+    unsigned ty = q / T, tx = q - ty * T;
+    unsigned tyi = t / (unsigned)e.tiles_w, txi = t - tyi * (unsigned)e.tiles_w;
+    c = (int)cc;
+    y = (int)(tyi * T + ty);
+    x = (int)(txi * T + tx);
     return;
   }
-  long long row_len = 3LL * e.temporal * e.patch * e.patch;
-  long long row = r / row_len;
-  int col = (int)(r - row * row_len);
-  int pp = e.patch * e.patch;
-  int ct = col / pp;
-  int q = col - ct * pp;
-  c = ct / e.temporal;
-  int ph = q / e.patch, pw = q - ph * e.patch;
-  int mw = (int)(row % e.merge);
-  long long r2 = row / e.merge;
-  int mh = (int)(r2 % e.merge);
-  long long blk = r2 / e.merge;
-  int bw = e.grid_w / e.merge;
-  int by = (int)(blk / bw), bx = (int)(blk - (long long)by * bw);
-  y = (by * e.merge + mh) * e.patch + ph;
-  x = (bx * e.merge + mw) * e.patch + pw;
+  unsigned P = (unsigned)e.patch, M = (unsigned)e.merge, pp = P * P;
+  unsigned row_len = 3u * (unsigned)e.temporal * pp;
+  unsigned row = r / row_len;
+  unsigned col = r - row * row_len;
+  unsigned ct = col / pp;
+  unsigned q = col - ct * pp;
+  c = (int)(ct / (unsigned)e.temporal);
+  unsigned ph = q / P, pw = q - ph * P;
+  unsigned mw = row % M;
+  unsigned r2 = row / M;
+  unsigned mh = r2 % M;
+  unsigned blk = r2 / M;
+  unsigned bw = (unsigned)e.grid_w / M;
+  unsigned by = blk / bw, bx = blk - by * bw;
+  y = (int)((by * M + mh) * P + ph);
+  x = (int)((bx * M + mw) * P + pw);
 }
 
 // ------------------------------------------------------------------------- reductions

@@ -324,8 +324,8 @@ __global__ void __launch_bounds__(kBlock) k_stage_fwd(DStage st, const float* __
   long long n = 3LL * st.can_h * st.can_w;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
-    int c = (int)(i / ((long long)st.can_h * st.can_w));
-    int rem = (int)(i - (long long)c * st.can_h * st.can_w);
+    int c = (int)((unsigned)i / ((unsigned)st.can_h * (unsigned)st.can_w));
+    int rem = (int)((unsigned)i - (unsigned)c * (unsigned)st.can_h * (unsigned)st.can_w);
     int y = rem / st.can_w, x = rem - y * st.can_w;
     int ry = y - st.off_y, rx = x - st.off_x;
     float v;
@@ -383,8 +383,8 @@ __global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, DPlan pl, int s
   long long n = 3LL * st.src_h * st.src_w;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
-    int c = (int)(i / ((long long)st.src_h * st.src_w));
-    int rem = (int)(i - (long long)c * st.src_h * st.src_w);
+    int c = (int)((unsigned)i / ((unsigned)st.src_h * (unsigned)st.src_w));
+    int rem = (int)((unsigned)i - (unsigned)c * (unsigned)st.src_h * (unsigned)st.src_w);
     int ys = rem / st.src_w, xs = rem - ys * st.src_w;
     int oy = st.tth.start[ys], oyc = st.tth.count[ys];
     int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
@@ -410,8 +410,8 @@ __global__ void __launch_bounds__(kBlock) k_resize_bwd_plain(DStage st, const fl
   long long n = 3LL * st.src_h * st.src_w;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
-    int c = (int)(i / ((long long)st.src_h * st.src_w));
-    int rem = (int)(i - (long long)c * st.src_h * st.src_w);
+    int c = (int)((unsigned)i / ((unsigned)st.src_h * (unsigned)st.src_w));
+    int rem = (int)((unsigned)i - (unsigned)c * (unsigned)st.src_h * (unsigned)st.src_w);
     int ys = rem / st.src_w, xs = rem - ys * st.src_w;
     int oy = st.tth.start[ys], oyc = st.tth.count[ys];
     int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
