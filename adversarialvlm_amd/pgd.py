@@ -31,7 +31,7 @@ class PixelPGD:
     def __init__(self, x0, plans, epsilon=0.5, lr=1e-2, sigma0=1e-3, mask=None, scheduler_step_size=100,
                  scheduler_gamma=1.0, grad_accum_steps=1, blur_kernel=None, use_crop=False, model_weights=None,
                  optimizer="adamw", cross_mode=False, betas=(0.9, 0.999), adam_eps=1e-8, weight_decay=1e-2, seed=0,
-                 process_group=None, allow_fused=True, fused_mode="auto", grad_prescale=None):
+                 process_group=None, allow_fused=True, fused_mode="auto", grad_prescale=None, force_exchange=False):
         if not x0.is_cuda:
             raise L.AdvxError("PixelPGD needs x0 on a ROCm device (there is no CPU fallback)")
         if not isinstance(plans, (list, tuple)):
@@ -68,6 +68,9 @@ class PixelPGD:
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+        # run the data-parallel chain (gradient-only backward, all-reduce, separate update) even
+        # for a group of one rank: lets a single GPU exercise the RCCL path
+        self.exchange = self.world > 1 or bool(force_exchange)
         # factor every rank applies to its contribution before the SUM all-reduce: 1/world gives
         # the data-parallel average; cross-model groups pass 1/group_size (average inside a
         # model's group, sum across models - crossattack_models.py:391)
@@ -85,7 +88,7 @@ class PixelPGD:
             # chain; the one-launch step is kept behind fused_mode="step"
             self.mode = "pair"
         else:
-            if fused_mode == "step" and self.world > 1:
+            if fused_mode == "step" and self.exchange:
                 raise L.AdvxError("the one-launch step cannot host the gradient all-reduce: use fused_mode='pair'")
             self.mode = fused_mode
         if self.fused:
@@ -222,7 +225,7 @@ class PixelPGD:
                 self.norm_rows = self.rows_step
                 self._out_next = out_next
                 self._out_kind = "given" if next_unit_noise is not None else ("philox" if use_philox else "none")
-            elif self.world == 1:
+            elif not self.exchange:
                 ops.fused_bwd(pl, grads[0], B, self.p, self.x0, self.eps, self.imgfit_scale(), self.grad, self.stats,
                               self.fused_scratch, mask=self.mask, m=self.m, v=self.v, opt=opt,
                               s_next=self.s_bufs[nxt], v_buf=self.v_buf)
@@ -241,7 +244,7 @@ class PixelPGD:
                             workspace=self.workspaces[i])
             ops.image_bwd(self.p, self.s, self.garg, self.eps, self.imgfit_scale(), self.grad, self.img_scratch,
                           blur=st["blur"], crop=st["crop"], accumulate=accumulate)
-            if self.world > 1 and take_step:
+            if self.exchange and take_step:
                 # The reduction is linear, so a gradient-accumulation window is exchanged once,
                 # at its end (intermediate grad norms are then rank-local).
                 dp.allreduce_image_grad_(self.grad, self.pg)

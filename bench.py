@@ -62,6 +62,21 @@ def cpu_baseline(seconds_budget=15.0):
                 sample=f"{n} steps of the same workload (336x336x3, B=64), {dt:.1f} s", steps_per_s=round(n / dt, 3))
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on fd 1 when a communicator is created; keep stdout for the
+    single JSON line by pointing fd 1 at stderr while the process group comes up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +86,8 @@ def main():
     ap.add_argument("--no-fused", action="store_true", help="time the generic (unfused) kernel chain instead")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                        "the multi-rank path on one GPU)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="rehearsal: run the data-parallel chain (RCCL all-reduce included) with a single rank")
     ap.add_argument("--chain", default="auto", choices=["auto", "pair", "step"],
                     help="fused chain: step = one launch per step (single GPU), pair = two launches")
     args = ap.parse_args()
@@ -86,13 +103,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or args.force_exchange:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=dev)
-        else:
-            torch.distributed.init_process_group(args.backend)
-        pg = torch.distributed.group.WORLD
+        with stdout_to_stderr():
+            if args.backend == "nccl":
+                torch.distributed.init_process_group("nccl", device_id=dev)
+            else:
+                torch.distributed.init_process_group(args.backend)
+            pg = torch.distributed.group.WORLD
+            warm = torch.ones(1, device=dev)
+            torch.distributed.all_reduce(warm)          # communicator creation happens here
+            torch.cuda.synchronize()
 
     from adversarialvlm_amd.build import build_library
     build_library()
@@ -104,7 +128,7 @@ def main():
     g = torch.randn(BATCH, 3, H, W, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     plan = Plan.llava(H, W)
     eng = PixelPGD(x0, [plan], epsilon=0.5, lr=1e-2, sigma0=1e-3, seed=1234 + rank, process_group=pg,
-                   allow_fused=not args.no_fused, fused_mode=args.chain)
+                   allow_fused=not args.no_fused, fused_mode=args.chain, force_exchange=args.force_exchange)
     # every rank pre-scales its share so that the SUM all-reduce is the DP average
     gs = g * eng.loss_scale(0)
 
@@ -183,7 +207,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

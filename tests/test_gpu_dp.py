@@ -71,3 +71,42 @@ def test_two_ranks_match_single_process(chain):
     err = float((p0 - ref.p.cpu()).norm() / ref.p.cpu().norm())
     assert err < 1e-5, err
     assert n0 == pytest.approx(rst["grad_norm"], rel=1e-5) and s0 == pytest.approx(rst["sigma_next"], rel=1e-6)
+
+
+def _rccl_single(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    torch.distributed.init_process_group("nccl", device_id=dev)
+    from adversarialvlm_amd.pgd import PixelPGD
+    from adversarialvlm_amd.plan import Plan
+    gen = torch.Generator().manual_seed(0)
+    x0 = torch.rand(3, 64, 64, generator=gen).to(dev)
+    zs = [torch.randn(4, 3, 64, 64, generator=gen).to(dev) for _ in range(3)]
+    gs = [(torch.randn(4, 3, 64, 64, generator=gen) * 0.01).to(dev) for _ in range(3)]
+    res = []
+    for force in (True, False):
+        eng = PixelPGD(x0, [Plan.llava(64, 64, 64, 64)], process_group=torch.distributed.group.WORLD, force_exchange=force)
+        for t in range(3):
+            eng.forward(4, [zs[t]])
+            eng.backward_update([gs[t]])
+        res.append((eng.p.cpu(), eng.stats_dict()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    out["same_p"] = bool(torch.equal(res[0][0], res[1][0]))
+    out["stats"] = (res[0][1], res[1][1])
+
+
+@pytest.mark.timeout(300)
+def test_rccl_exchange_chain_single_rank():
+    """backend "nccl" IS RCCL on ROCm: a one-rank group drives the real data-parallel chain
+    (fused_bwd grad-only -> RCCL all-reduce -> fused_update -> prepared forward) on the GPU and
+    must reproduce the single-launch update bit for bit."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_rccl_single, args=(_free_port(), out), nprocs=1, join=True)
+    assert out["same_p"]
+    a, b = out["stats"]
+    for k in a:
+        assert a[k] == pytest.approx(b[k], rel=1e-6, abs=1e-12), k
