@@ -538,11 +538,7 @@ extern "C" int32_t advx_plan_upload(advx_plan* p, void* stream) {
 static void emit_slices(long long n4, int batch, int* gx, int* slices, int* b_per_slice) {
   long long bx = (n4 + kBlock - 1) / kBlock;
   if (bx < 1) bx = 1;
-  static int target = -1;
-  if (target < 0) {
-    const char* e = std::getenv("ADVX_EMIT_TARGET_BLOCKS");
-    target = e ? std::max(256, std::atoi(e)) : 2048;
-  }
+  const int target = 2048;   // ~8 workgroups per CU: measured best on MI355X (profiles/r01)
   int want = (int)std::max<long long>(1, (target + bx - 1) / bx);
   int sl = std::min(batch, want);
   while (sl < batch && batch % sl != 0) ++sl;  // equal slices: no straggler slice
@@ -955,15 +951,11 @@ extern "C" int32_t advx_fused_bwd(advx_plan* p, const float* g, int32_t batch, f
   return ADVX_OK;
 }
 
-// grid of the one-launch step: one wave per 64 pixels, four waves per block, at most
-// ADVX_STEP_MAX_BLOCKS blocks (then waves loop over several groups); never more blocks than
-// the row buffers hold (one partial row per block, f.bwd_blocks rows)
+// grid of the one-launch step: one wave per 64 pixels, four waves per block, at most 2048
+// blocks (then waves loop over several groups); never more blocks than the row buffers hold
+// (one partial row per block, f.bwd_blocks rows)
 static int step_grid(long long n) {
-  static int cap = -1;
-  if (cap < 0) {
-    const char* e = std::getenv("ADVX_STEP_MAX_BLOCKS");
-    cap = e ? std::max(64, std::atoi(e)) : 2048;
-  }
+  const int cap = 2048;
   long long groups = (n + kWave - 1) / kWave;
   long long blocks = (groups + (kBlock / kWave) - 1) / (kBlock / kWave);   // == ceil(n / 256) == bwd_blocks
   return (int)std::max<long long>(1, std::min<long long>(blocks, cap));

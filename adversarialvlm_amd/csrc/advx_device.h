@@ -172,9 +172,7 @@ __device__ inline void block_sum_store(const double (&acc)[NS], double* dst) {
 }
 
 // ----------------------------------------------------------------------- Philox noise
-struct Philox {
-  uint32_t k0, k1;
-};
+// Philox4x32 (Salmon et al., SC'11) with the standard 10 rounds
 #ifndef ADVX_PHILOX_ROUNDS
 #define ADVX_PHILOX_ROUNDS 10
 #endif

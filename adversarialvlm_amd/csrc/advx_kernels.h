@@ -597,9 +597,10 @@ __global__ void __launch_bounds__(kBlock) k_finalize_norm(const double* __restri
 // ================================================================= fused (identity plan)
 // LLaVA at native resolution: process() is (s - mean)/std with s = x0 + eps*tanh(p).
 // The step is software-pipelined over two launches:
-//   k_fused_fwd(t) : stream out[b,i] = v_t[i] + sigma_t * N(0,1) from the PREPARED v_t.  The
-//                    blocks of batch-slice 0 also read s_t, x0 and leave the statistics
-//                    partials of s_t; block (0,0) reduces ||g|| of step t-1 (slot 7).
+//   k_fused_fwd(t) : stream out[b,i] = v_t[i] + sigma_t * N(0,1) from the PREPARED v_t
+//                    (blockIdx.y >= 1: one slice of the batch each).  The short blocks with
+//                    blockIdx.y == 0 read s_t, x0 and leave the statistics partials of s_t;
+//                    block (0,0) first reduces ||g|| of step t-1 (slot 7).
 //                    sigma_t is slot QERR_STD, i.e. the quantise error of s_{t-1}.
 //   k_fused_bwd(t) : reads the B gradients once, /std, image-fit term, tanh', mask, ||g||,
 //                    optimiser, and - same thread, same registers - prepares step t+1 from
@@ -722,6 +723,13 @@ __global__ void __launch_bounds__(kBlock) k_fused_bwd(const float* __restrict__ 
       }
     }
   }
+  // everything that does not need the gradient sum is computed while the stream is in flight
+  const int c = (i < n) ? (int)(i / geo.plane) : 0;
+  const float sd = geo.stdv[c];
+  const float t = tanhf(pp);
+  const float s = xv + eps * t;
+  const float fit = imgfit_grad(s, c_fit);
+  const float dtanh = 1.0f - t * t;
   float4 a = make_float4(0, 0, 0, 0);
   if (q < n4) a = batch_column_sum(g, batch, n, q << 2, wid, kBlock / kWave);
   if (blockIdx.x == 0) {
@@ -741,12 +749,8 @@ __global__ void __launch_bounds__(kBlock) k_fused_bwd(const float* __restrict__ 
   double nacc[1] = {0.0};
   if (i < n) {
     float gs = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
-    const int c = (int)(i / geo.plane);
-    const float sd = geo.stdv[c];
-    float t = tanhf(pp);
-    float s = xv + eps * t;
-    float gx = gs / sd + imgfit_grad(s, c_fit);
-    float gp = (gx * eps) * (1.0f - t * t);
+    float gx = gs / sd + fit;
+    float gp = (gx * eps) * dtanh;
     if (UPDATE) {
       gp = gp * mk;
       nacc[0] = (double)gp * (double)gp;

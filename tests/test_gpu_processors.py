@@ -179,3 +179,39 @@ def test_layout_index_map_matches_device(dev):
             c, y, x = int(rng.integers(3)), int(rng.integers(st.can_h)), int(rng.integers(st.can_w))
             for idx in p2.out_index(0, c, y, x):
                 assert out[idx].item() == canvas[c, y, x].item()
+
+
+def test_odd_sizes_take_the_scalar_paths(dev):
+    """P_out not a multiple of 4: rows are not 16-byte aligned, so emit / batch-reduce must fall
+    back to scalar stores and columns (and still match the oracle, noise included)."""
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan
+    torch.manual_seed(8)
+    H, W, ch, cw, B = 37, 91, 25, 31, 3
+    plan = Plan.llava(H, W, ch, cw)
+    assert plan.out_numel % 4 != 0
+    img = torch.rand(3, H, W, requires_grad=True)
+    z = torch.randn(B, 3, ch, cw)
+    ref = LlavaOracle(ch, cw).process(img)["pixel_values"].repeat(B, 1, 1, 1) + z * 0.02
+    up = torch.randn_like(ref)
+    ref.backward(up)
+    sig = torch.tensor([0.02], device=dev)
+    out = ops.emit(plan, img.detach().to(dev), B, sigma_dev=sig, unit_noise=z.to(dev))
+    assert rel_err(out.cpu().view(ref.shape), ref.detach()) < TIGHT
+    g = ops.collect(plan, up.to(dev).view(B, -1), B)
+    assert rel_err(g.cpu(), img.grad) < TIGHT
+    noisy = ops.emit(plan, img.detach().to(dev), B, sigma_dev=sig, philox=(1, 1))
+    d = ((noisy - ops.emit(plan, img.detach().to(dev), B)) / 0.02).cpu()
+    assert abs(float(d.mean())) < 0.05 and abs(float(d.std()) - 1) < 0.05
+
+
+def test_batch_of_one_and_large_batch(dev):
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan
+    plan = Plan.llava(48, 48, 48, 48)
+    img = torch.rand(3, 48, 48, device=dev)
+    one = ops.emit(plan, img, 1)
+    many = ops.emit(plan, img, 130)                       # more rows than batch slices
+    assert torch.equal(many, one.expand(130, -1))
+    g = torch.randn(130, plan.out_numel, device=dev)
+    assert rel_err(ops.collect(plan, g, 130).cpu(), ops.collect(plan, g.double().sum(0, keepdim=True).float(), 1).cpu()) < 1e-5
