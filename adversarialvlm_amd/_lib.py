@@ -76,6 +76,9 @@ SIGNATURES = {
     "advx_fused_supported": (_I32, [_P]),
     "advx_fused_fwd": (_I32, [_P, _P, _P, _F, _I32, _P, _I32, _U64, _U64, _P, _P, _P, _I32, _I32, _P, _P, _P]),
     "advx_fused_bwd": (_I32, [_P, _P, _I32, _P, _P, _F, _F, _P, _P, _P, _P, C.POINTER(OptScalars), _P, _P, _P, _P, _P]),
+    "advx_fused_fwd_io": (_I32, [_P, _P, _P, _F, _I32, _P, _I32, _U64, _U64, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P]),
+    "advx_fused_bwd_io": (_I32, [_P, _P, _I32, _I32, _P, _P, _F, _F, _P, _P, _P, _P, C.POINTER(OptScalars), _P, _P, _P, _P,
+                                 _P]),
     "advx_fused_update": (_I32, [_P, _P, _P, _P, _P, _P, _P, _F, C.POINTER(OptScalars), _P, _P, _P, _P]),
     "advx_fused_scratch_floats": (_I64, [_P]),
     "advx_fused_flush": (_I32, [_P, _P, _P, _I32, _P]),

@@ -25,6 +25,7 @@ import torch
 from PIL import Image
 
 from . import prompts as P
+from .ops import IO_DTYPES
 from .pgd import PixelPGD
 from .processors import load_components
 
@@ -127,7 +128,12 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
           # --- additions of this framework (defaults reproduce the reference behaviour)
           questions_file=None, test_questions_file=None, answers_file=None, optimizer="adamw", log_every=1,
           use_wandb=False, seed=0, base_path="./runs", components=None, return_engine=False,
-          generation_probe=False, resume_from=None):
+          generation_probe=False, resume_from=None, pixel_io="float32"):
+    """pixel_io: "float32" hands the VLM fp32 pixel_values as the reference does; "model" lets
+    the fused pair write them in model.dtype (the cast the vision tower's patch embedding applies
+    first anyway) and read the half gradient directly - same numbers, half the traffic."""
+    if pixel_io not in ("float32", "model"):
+        raise ValueError("pixel_io must be 'float32' or 'model'")
     if clamp_method != "tanh":
         raise NotImplementedError("Clamping method except tanh are not implemented")       # attack_model.py:186
     if DPO_flag:
@@ -181,6 +187,10 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
                       grad_accum_steps=grad_accum_steps, blur_kernel=gblur_kernel_size if use_gaussian_blur else None,
                       use_crop=use_local_crop, optimizer=optimizer, seed=seed + 7919 * rank,
                       process_group=torch.distributed.group.WORLD if world > 1 else None)
+    if pixel_io == "model" and engine.mode == "pair":
+        model_dtype = next(model.parameters()).dtype
+        if model_dtype in IO_DTYPES:
+            engine.io_dtype = model_dtype
 
     # shared draws (target text, crop window) come from the global generators, which every
     # rank seeds identically; prompt sampling uses a rank-local stream
@@ -304,6 +314,8 @@ def build_parser():
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--generation_probe", action="store_true", help="greedy-generate the test prompts at every save step")
     p.add_argument("--resume_from", type=str, default=None, help="state_iter_*.pt written by a previous run")
+    p.add_argument("--pixel_io", type=str, default="float32", choices=["float32", "model"],
+                   help="dtype of pixel_values at the VLM boundary (model = the VLM's own half dtype)")
     return p
 
 

@@ -887,11 +887,12 @@ static FusedGeom fused_geom(const advx_plan* p) {
   return g;
 }
 
-extern "C" int32_t advx_fused_fwd(advx_plan* p, const float* pp, const float* x0, float eps, int32_t batch,
-                                  const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset, float* out,
-                                  float* s_buf, float* v_buf, int32_t prepared, int32_t parity, float* stats,
-                                  float* scratch, void* stream) {
+static int32_t fused_fwd_impl(advx_plan* p, const float* pp, const float* x0, float eps, int32_t batch,
+                              const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset, void* out,
+                              int32_t io, float* s_buf, float* v_buf, int32_t prepared, int32_t parity, float* stats,
+                              float* scratch, void* stream) {
   REQUIRE(p && pp && x0 && out && stats && scratch && s_buf && v_buf, ADVX_E_BADARG, "advx_fused_fwd: null argument");
+  REQUIRE(io >= 0 && io <= 2, ADVX_E_BADARG, "advx_fused_fwd: io_dtype must be ADVX_IO_F32 / F16 / BF16");
   REQUIRE(parity == 0 || parity == 1, ADVX_E_BADARG, "advx_fused_fwd: parity must be 0 or 1");
   REQUIRE(advx_fused_supported(p), ADVX_E_UNSUPPORTED, "advx_fused_fwd: plan is not an identity LLaVA plan");
   REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_fused_fwd: batch out of range");
@@ -911,20 +912,41 @@ extern "C" int32_t advx_fused_fwd(advx_plan* p, const float* pp, const float* x0
   emit_slices(n4, batch, &gx, &slices, &bps);
   dim3 grid(gx, slices + 1);  // y == 0: statistics blocks, y >= 1: batch slices
   int noise = unit_noise ? 1 : (use_philox ? 2 : 0);
-#define ADVX_FF(N)                                                                                               \
-  ADVX_LAUNCH_TIMED(PROF_FWD, k_fused_fwd<N>, grid, dim3(kBlock), st, (const float*)v_buf, (const float*)s_buf, x0, n, batch, \
-                    bps, stats, unit_noise, seed, offset, out, f.hdr, f.img_rows[parity], (const double*)f.norm_partials)
-  if (noise == 0) ADVX_FF(0); else if (noise == 1) ADVX_FF(1); else ADVX_FF(2);
+#define ADVX_FF(N, T)                                                                                            \
+  ADVX_LAUNCH_TIMED(PROF_FWD, (k_fused_fwd<N, T>), grid, dim3(kBlock), st, (const float*)v_buf, (const float*)s_buf, x0, n, \
+                    batch, bps, stats, unit_noise, seed, offset, out, f.hdr, f.img_rows[parity],                  \
+                    (const double*)f.norm_partials)
+#define ADVX_FF_IO(N) \
+  do { if (io == 0) ADVX_FF(N, 0); else if (io == 1) ADVX_FF(N, 1); else ADVX_FF(N, 2); } while (0)
+  if (noise == 0) ADVX_FF_IO(0); else if (noise == 1) ADVX_FF_IO(1); else ADVX_FF_IO(2);
+#undef ADVX_FF_IO
 #undef ADVX_FF
   LAUNCH_CHECK();
   return ADVX_OK;
 }
 
-extern "C" int32_t advx_fused_bwd(advx_plan* p, const float* g, int32_t batch, float* pp, const float* x0, float eps,
-                                  float imgfit_scale, const float* mask, float* m, float* v, float* grad_p,
-                                  const advx_opt_scalars* opt, float* s_next, float* v_buf, float* stats, float* scratch,
-                                  void* stream) {
+extern "C" int32_t advx_fused_fwd(advx_plan* p, const float* pp, const float* x0, float eps, int32_t batch,
+                                  const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset, float* out,
+                                  float* s_buf, float* v_buf, int32_t prepared, int32_t parity, float* stats,
+                                  float* scratch, void* stream) {
+  return fused_fwd_impl(p, pp, x0, eps, batch, unit_noise, use_philox, seed, offset, out, 0, s_buf, v_buf, prepared, parity,
+                        stats, scratch, stream);
+}
+
+extern "C" int32_t advx_fused_fwd_io(advx_plan* p, const float* pp, const float* x0, float eps, int32_t batch,
+                                     const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset,
+                                     void* out, int32_t io_dtype, float* s_buf, float* v_buf, int32_t prepared,
+                                     int32_t parity, float* stats, float* scratch, void* stream) {
+  return fused_fwd_impl(p, pp, x0, eps, batch, unit_noise, use_philox, seed, offset, out, io_dtype, s_buf, v_buf, prepared,
+                        parity, stats, scratch, stream);
+}
+
+static int32_t fused_bwd_impl(advx_plan* p, const void* g, int32_t io, int32_t batch, float* pp, const float* x0, float eps,
+                              float imgfit_scale, const float* mask, float* m, float* v, float* grad_p,
+                              const advx_opt_scalars* opt, float* s_next, float* v_buf, float* stats, float* scratch,
+                              void* stream) {
   REQUIRE(p && g && pp && x0 && grad_p && scratch && stats, ADVX_E_BADARG, "advx_fused_bwd: null argument");
+  REQUIRE(io >= 0 && io <= 2, ADVX_E_BADARG, "advx_fused_bwd: io_dtype must be ADVX_IO_F32 / F16 / BF16");
   REQUIRE(advx_fused_supported(p), ADVX_E_UNSUPPORTED, "advx_fused_bwd: plan is not an identity LLaVA plan");
   REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_fused_bwd: batch out of range");
   REQUIRE(aligned16(g) && aligned16(scratch), ADVX_E_BADARG, "advx_fused_bwd: grad_out/scratch must be 16-byte aligned");
@@ -937,18 +959,38 @@ extern "C" int32_t advx_fused_bwd(advx_plan* p, const float* g, int32_t batch, f
     REQUIRE(opt->apply, ADVX_E_UNSUPPORTED, "advx_fused_bwd: the fused update always steps (use the generic path to accumulate)");
     int32_t rc = check_opt(opt, m, v);
     if (rc) return rc;
-    ADVX_LAUNCH_TIMED(PROF_BWD, k_fused_bwd<true>, dim3(f.bwd_blocks), dim3(kBlock), st, g, batch, pp, x0, eps, fused_geom(p),
-                      c_fit, mask, m, v, grad_p, to_dev(opt), s_next, v_buf, f.norm_partials, stats, f.hdr,
-                      (const double*)f.img_partials);
+#define ADVX_FB(U, T, O)                                                                                          \
+  ADVX_LAUNCH_TIMED(PROF_BWD, (k_fused_bwd<U, T>), dim3(f.bwd_blocks), dim3(kBlock), st, g, batch, pp, x0, eps,    \
+                    fused_geom(p), c_fit, mask, m, v, grad_p, O, s_next, v_buf, f.norm_partials, stats, f.hdr,     \
+                    (const double*)f.img_partials)
+#define ADVX_FB_IO(U, O) \
+  do { if (io == 0) ADVX_FB(U, 0, O); else if (io == 1) ADVX_FB(U, 1, O); else ADVX_FB(U, 2, O); } while (0)
+    ADVX_FB_IO(true, to_dev(opt));
   } else {
     OptScalars none;
     std::memset(&none, 0, sizeof(none));
-    ADVX_LAUNCH_TIMED(PROF_BWD, k_fused_bwd<false>, dim3(f.bwd_blocks), dim3(kBlock), st, g, batch, pp, x0, eps, fused_geom(p),
-                      c_fit, mask, m, v, grad_p, none, s_next, v_buf, f.norm_partials, stats, f.hdr,
-                      (const double*)f.img_partials);
+    ADVX_FB_IO(false, none);
+#undef ADVX_FB_IO
+#undef ADVX_FB
   }
   LAUNCH_CHECK();
   return ADVX_OK;
+}
+
+extern "C" int32_t advx_fused_bwd(advx_plan* p, const float* g, int32_t batch, float* pp, const float* x0, float eps,
+                                  float imgfit_scale, const float* mask, float* m, float* v, float* grad_p,
+                                  const advx_opt_scalars* opt, float* s_next, float* v_buf, float* stats, float* scratch,
+                                  void* stream) {
+  return fused_bwd_impl(p, g, 0, batch, pp, x0, eps, imgfit_scale, mask, m, v, grad_p, opt, s_next, v_buf, stats, scratch,
+                        stream);
+}
+
+extern "C" int32_t advx_fused_bwd_io(advx_plan* p, const void* g, int32_t io_dtype, int32_t batch, float* pp,
+                                     const float* x0, float eps, float imgfit_scale, const float* mask, float* m, float* v,
+                                     float* grad_p, const advx_opt_scalars* opt, float* s_next, float* v_buf, float* stats,
+                                     float* scratch, void* stream) {
+  return fused_bwd_impl(p, g, io_dtype, batch, pp, x0, eps, imgfit_scale, mask, m, v, grad_p, opt, s_next, v_buf, stats,
+                        scratch, stream);
 }
 
 // grid of the one-launch step: one wave per 64 pixels, four waves per block, at most 2048

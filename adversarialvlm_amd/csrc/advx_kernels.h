@@ -490,26 +490,68 @@ __global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restri
 // (b ascending inside a wave, waves 0..3) so the result is bitwise reproducible.
 __device__ inline float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-__device__ inline float4 batch_column_sum(const float* __restrict__ g, int batch, long long n, long long i0,
+// Element type of the two B*P_out tensors at the VLM boundary: 0 = float32 (what the reference
+// hands to / gets from the model), 1 = float16, 2 = bfloat16.  A half-precision model casts
+// pixel_values on entry and autograd casts the gradient back, both exactly representable
+// steps (round-to-nearest-even on the way in, widening on the way out), so emitting / reading
+// the model's dtype directly gives bit-identical numerics with half the traffic.
+template <int IO>
+__device__ inline float4 io_load4(const void* __restrict__ base, size_t idx) {
+  if (IO == 0) return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
+  uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+  if (IO == 1) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 a = __builtin_bit_cast(h2, raw.x), b = __builtin_bit_cast(h2, raw.y);
+    return make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+  }
+  return make_float4(__builtin_bit_cast(float, raw.x << 16), __builtin_bit_cast(float, raw.x & 0xffff0000u),
+                     __builtin_bit_cast(float, raw.y << 16), __builtin_bit_cast(float, raw.y & 0xffff0000u));
+}
+
+// streaming (non-temporal) store of four consecutive elements
+template <int IO>
+__device__ inline void io_store4(void* __restrict__ base, size_t idx, float4 v) {
+  if (IO == 0) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v ov = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(ov, reinterpret_cast<f4v*>(reinterpret_cast<float*>(base) + idx));
+    return;
+  }
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  u2v packed;
+  if (IO == 1) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 a = {(_Float16)v.x, (_Float16)v.y}, b = {(_Float16)v.z, (_Float16)v.w};   // v_cvt_f16_f32: RNE
+    packed = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+  } else {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    b2 a = {(__bf16)v.x, (__bf16)v.y}, b = {(__bf16)v.z, (__bf16)v.w};           // v_cvt_pk_bf16_f32: RNE
+    packed = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+  }
+  __builtin_nontemporal_store(packed, reinterpret_cast<u2v*>(reinterpret_cast<unsigned short*>(base) + idx));
+}
+
+template <int IO = 0>
+__device__ inline float4 batch_column_sum(const void* __restrict__ g, int batch, long long n, long long i0,
                                           int wid, int nw) {
   float4 a = make_float4(0, 0, 0, 0);
   int b = wid;
-  // 8, then 4 independent 16-byte loads in flight per lane (1 KiB per wave-instruction)
+  // 8, then 4 independent loads in flight per lane (1 KiB per wave-instruction in float32)
   for (; b + 7 * nw < batch; b += 8 * nw) {
     float4 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(g + (size_t)(b + k * nw) * n + i0);
+    for (int k = 0; k < 8; ++k) v[k] = io_load4<IO>(g, (size_t)(b + k * nw) * n + i0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) a = f4add(a, v[k]);
   }
   for (; b + 3 * nw < batch; b += 4 * nw) {
-    float4 v0 = *reinterpret_cast<const float4*>(g + (size_t)b * n + i0);
-    float4 v1 = *reinterpret_cast<const float4*>(g + (size_t)(b + nw) * n + i0);
-    float4 v2 = *reinterpret_cast<const float4*>(g + (size_t)(b + 2 * nw) * n + i0);
-    float4 v3 = *reinterpret_cast<const float4*>(g + (size_t)(b + 3 * nw) * n + i0);
+    float4 v0 = io_load4<IO>(g, (size_t)b * n + i0);
+    float4 v1 = io_load4<IO>(g, (size_t)(b + nw) * n + i0);
+    float4 v2 = io_load4<IO>(g, (size_t)(b + 2 * nw) * n + i0);
+    float4 v3 = io_load4<IO>(g, (size_t)(b + 3 * nw) * n + i0);
     a = f4add(f4add(f4add(f4add(a, v0), v1), v2), v3);
   }
-  for (; b < batch; b += nw) a = f4add(a, *reinterpret_cast<const float4*>(g + (size_t)b * n + i0));
+  for (; b < batch; b += nw) a = f4add(a, io_load4<IO>(g, (size_t)b * n + i0));
   return a;
 }
 
@@ -627,12 +669,12 @@ __global__ void __launch_bounds__(kBlock) k_fused_prep(const float* __restrict__
 }
 
 // NOISE: 0 none, 1 unit-noise tensor supplied, 2 in-kernel Philox
-template <int NOISE>
+template <int NOISE, int IO>
 __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ v_buf, const float* __restrict__ s_buf,
                                                       const float* __restrict__ x0, long long n, int batch,
                                                       int b_per_slice, float* stats, const float* __restrict__ unit_noise,
                                                       unsigned long long seed, unsigned long long offset,
-                                                      float* __restrict__ out, FusedHeader* __restrict__ hdr,
+                                                      void* __restrict__ out, FusedHeader* __restrict__ hdr,
                                                       double* __restrict__ img_partials,
                                                       const double* __restrict__ norm_partials) {
   const long long n4 = n >> 2;
@@ -678,15 +720,9 @@ __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ 
       float4 z = philox_normal4((unsigned long long)b * (unsigned long long)n4 + (unsigned long long)q, offset, seed);
       o = make_float4(v.x + z.x * sigma, v.y + z.y * sigma, v.z + z.z * sigma, v.w + z.w * sigma);
     }
-#ifndef ADVX_NO_NT_STORES
     // write-once stream: non-temporal stores keep it out of the way of grad_out in the
     // Infinity Cache (measured -1 us on this kernel)
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    f4v ov = {o.x, o.y, o.z, o.w};
-    __builtin_nontemporal_store(ov, reinterpret_cast<f4v*>(out + (size_t)b * n + i0));
-#else
-    *reinterpret_cast<float4*>(out + (size_t)b * n + i0) = o;
-#endif
+    io_store4<IO>(out, (size_t)b * n + i0, o);
   }
 }
 
@@ -694,8 +730,8 @@ __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ 
 // block = 64 float4 columns (256 pixels); the 4 waves split the batch and meet in LDS; then
 // thread t owns pixel t of the block.  Its per-pixel state is prefetched before the batch
 // loop so that no dependent load sits on the tail.
-template <bool UPDATE>
-__global__ void __launch_bounds__(kBlock) k_fused_bwd(const float* __restrict__ g, int batch, float* __restrict__ p,
+template <bool UPDATE, int IO>
+__global__ void __launch_bounds__(kBlock) k_fused_bwd(const void* __restrict__ g, int batch, float* __restrict__ p,
                                                       const float* __restrict__ x0, float eps, FusedGeom geo,
                                                       float c_fit, const float* __restrict__ mask,
                                                       float* __restrict__ m, float* __restrict__ v,
@@ -731,7 +767,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_bwd(const float* __restrict__ 
   const float fit = imgfit_grad(s, c_fit);
   const float dtanh = 1.0f - t * t;
   float4 a = make_float4(0, 0, 0, 0);
-  if (q < n4) a = batch_column_sum(g, batch, n, q << 2, wid, kBlock / kWave);
+  if (q < n4) a = batch_column_sum<IO>(g, batch, n, q << 2, wid, kBlock / kWave);
   if (blockIdx.x == 0) {
     // statistics partials left by this step's forward: reduce them here, beside the other
     // blocks' streaming work (rotates SIGMA <- old QERR_STD, then QERR_STD <- new)

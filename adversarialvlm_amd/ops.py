@@ -147,26 +147,44 @@ def fused_flush(plan, stats, scratch, image_too=False):
             "advx_fused_flush")
 
 
+# ADVX_IO_* of include/advx.h
+IO_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def io_code(dtype):
+    try:
+        return IO_DTYPES[dtype]
+    except KeyError:
+        raise L.AdvxError(f"the fused pair reads/writes float32, float16 or bfloat16, not {dtype}") from None
+
+
 def fused_fwd(plan, p, x0, epsilon, batch, stats, scratch, s_buf, v_buf, prepared, unit_noise=None, philox=None, out=None,
-              parity=0):
+              parity=0, out_dtype=torch.float32):
     _require_cuda(p, x0, stats, scratch, s_buf, v_buf)
     if out is None:
-        out = torch.empty((batch, plan.out_numel), dtype=torch.float32, device=p.device)
+        out = torch.empty((batch, plan.out_numel), dtype=out_dtype, device=p.device)
+    elif not out.is_contiguous() or out.numel() != batch * plan.out_numel:
+        raise L.AdvxError("out must be a contiguous [batch, out_numel] tensor")
     seed, offset = (philox if philox is not None else (0, 0))
-    L.check(L.load().advx_fused_fwd(plan.handle, L.ptr(p), L.ptr(x0), float(epsilon), int(batch), L.ptr(unit_noise),
-                                    int(philox is not None), int(seed), int(offset), L.ptr(out), L.ptr(s_buf), L.ptr(v_buf),
-                                    int(bool(prepared)), int(parity), L.ptr(stats), L.ptr(scratch), _stream(p)),
-            "advx_fused_fwd")
+    L.check(L.load().advx_fused_fwd_io(plan.handle, L.ptr(p), L.ptr(x0), float(epsilon), int(batch), L.ptr(unit_noise),
+                                       int(philox is not None), int(seed), int(offset), L.ptr(out), io_code(out.dtype),
+                                       L.ptr(s_buf), L.ptr(v_buf), int(bool(prepared)), int(parity), L.ptr(stats),
+                                       L.ptr(scratch), _stream(p)), "advx_fused_fwd_io")
     return out
 
 
 def fused_bwd(plan, grad_out, batch, p, x0, epsilon, imgfit_scale, grad_p, stats, scratch, mask=None, m=None, v=None,
               opt=None, s_next=None, v_buf=None):
+    """grad_out may be float32, float16 or bfloat16 (read as is, accumulated in fp32)."""
     _require_cuda(grad_out, p, x0, grad_p, scratch, stats)
-    L.check(L.load().advx_fused_bwd(plan.handle, L.ptr(_f32c(grad_out)), int(batch), L.ptr(p), L.ptr(x0), float(epsilon),
-                                    float(imgfit_scale), L.ptr(mask), L.ptr(m), L.ptr(v), L.ptr(grad_p),
-                                    C.byref(opt) if opt is not None else None, L.ptr(s_next), L.ptr(v_buf), L.ptr(stats),
-                                    L.ptr(scratch), _stream(p)), "advx_fused_bwd")
+    io = io_code(grad_out.dtype)
+    grad_out = grad_out.contiguous()
+    if grad_out.numel() != batch * plan.out_numel:
+        raise L.AdvxError("grad_out has the wrong number of elements")
+    L.check(L.load().advx_fused_bwd_io(plan.handle, L.ptr(grad_out), io, int(batch), L.ptr(p), L.ptr(x0), float(epsilon),
+                                       float(imgfit_scale), L.ptr(mask), L.ptr(m), L.ptr(v), L.ptr(grad_p),
+                                       C.byref(opt) if opt is not None else None, L.ptr(s_next), L.ptr(v_buf),
+                                       L.ptr(stats), L.ptr(scratch), _stream(p)), "advx_fused_bwd_io")
 
 
 def fused_update(plan, p, m, v, grad_p, mask, x0, epsilon, opt, s_next, v_buf, scratch):

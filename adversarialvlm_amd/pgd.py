@@ -31,7 +31,12 @@ class PixelPGD:
     def __init__(self, x0, plans, epsilon=0.5, lr=1e-2, sigma0=1e-3, mask=None, scheduler_step_size=100,
                  scheduler_gamma=1.0, grad_accum_steps=1, blur_kernel=None, use_crop=False, model_weights=None,
                  optimizer="adamw", cross_mode=False, betas=(0.9, 0.999), adam_eps=1e-8, weight_decay=1e-2, seed=0,
-                 process_group=None, allow_fused=True, fused_mode="auto", grad_prescale=None, force_exchange=False):
+                 process_group=None, allow_fused=True, fused_mode="auto", grad_prescale=None, force_exchange=False,
+                 io_dtype=torch.float32):
+        """io_dtype: dtype of the pixel_values handed to the VLM by the fused pair.  float32 is
+        the reference's own boundary; float16 / bfloat16 emit the tensor already cast to the
+        model's dtype (the cast the model's first layer would apply) and let backward_update
+        read the half gradient directly."""
         if not x0.is_cuda:
             raise L.AdvxError("PixelPGD needs x0 on a ROCm device (there is no CPU fallback)")
         if not isinstance(plans, (list, tuple)):
@@ -91,6 +96,10 @@ class PixelPGD:
             if fused_mode == "step" and self.exchange:
                 raise L.AdvxError("the one-launch step cannot host the gradient all-reduce: use fused_mode='pair'")
             self.mode = fused_mode
+        ops.io_code(io_dtype)
+        if io_dtype != torch.float32 and self.mode != "pair":
+            raise L.AdvxError(f"io_dtype={io_dtype} needs the fused pair; this engine runs the {self.mode} chain")
+        self.io_dtype = io_dtype
         if self.fused:
             # the forward reads its sigma from slot QERR_STD (the previous image's quantise error)
             self.stats[L.STAT_QERR_STD] = float(sigma0)
@@ -173,7 +182,8 @@ class PixelPGD:
                 ph = None if (unit_noises[0] is not None or not use_philox) else (self.seed, self.iteration)
                 out = ops.fused_fwd(pl, self.p, self.x0, self.eps, B, self.stats, self.fused_scratch,
                                     self.s_bufs[self.s_cur], self.v_buf, self.prepared, unit_noise=unit_noises[0],
-                                    philox=ph, parity=self.par if self.mode == "step" else 0)
+                                    philox=ph, parity=self.par if self.mode == "step" else 0,
+                                    out_dtype=self.io_dtype)
                 self.prepared = True
                 self.img_rows = self.rows_fwd
                 self._out_next = None

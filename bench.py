@@ -90,7 +90,12 @@ def main():
                     help="rehearsal: run the data-parallel chain (RCCL all-reduce included) with a single rank")
     ap.add_argument("--chain", default="auto", choices=["auto", "pair", "step"],
                     help="fused chain: step = one launch per step (single GPU), pair = two launches")
+    ap.add_argument("--io", default="f32", choices=["f32", "f16", "bf16"],
+                    help="dtype of pixel_values / their gradient at the VLM boundary (f32 = the reference's own "
+                         "boundary and the headline; f16/bf16 = emit in the model's dtype, pair chain only)")
     args = ap.parse_args()
+    io_dtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.io]
+    io_bytes = 4 if args.io == "f32" else 2
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -128,9 +133,9 @@ def main():
     g = torch.randn(BATCH, 3, H, W, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     plan = Plan.llava(H, W)
     eng = PixelPGD(x0, [plan], epsilon=0.5, lr=1e-2, sigma0=1e-3, seed=1234 + rank, process_group=pg,
-                   allow_fused=not args.no_fused, fused_mode=args.chain, force_exchange=args.force_exchange)
+                   allow_fused=not args.no_fused, fused_mode=args.chain, force_exchange=args.force_exchange, io_dtype=io_dtype)
     # every rank pre-scales its share so that the SUM all-reduce is the DP average
-    gs = g * eng.loss_scale(0)
+    gs = (g * eng.loss_scale(0)).to(io_dtype)
 
     def step():
         eng.forward(BATCH)
@@ -161,9 +166,9 @@ def main():
     fwd_avg, bwd_avg, step_avg = prof["fwd"][0], prof["bwd"][0], prof["step"][0]
 
     n_in = 3 * H * W
-    bytes_fwd = 4 * (BATCH * n_in + 2 * n_in)          # write B*P_out, read p,x0
-    bytes_bwd = 4 * (BATCH * n_in + 8 * n_in)          # read B*P_out; p,x0,mask,m,v in; p,m,v(+grad) out
-    bytes_step = 4 * (2 * BATCH * n_in + 10 * n_in)
+    bytes_fwd = io_bytes * BATCH * n_in + 4 * 2 * n_in     # write B*P_out, read p,x0
+    bytes_bwd = io_bytes * BATCH * n_in + 4 * 8 * n_in     # read B*P_out; p,x0,mask,m,v in; p,m,v(+grad) out
+    bytes_step = bytes_fwd + bytes_bwd                     # 4*(2*B*P_out + 10*P_in) at f32
     steps_per_s = args.steps / dt
     if eng.mode == "step":
         # one launch per step: backward of step t + forward of step t+1 in the same kernel
@@ -179,7 +184,8 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
-            traffic = json.load(f).get(dom_name, {}).get("traffic_bytes_per_launch")
+            traffic = json.load(f).get(dom_name if args.io == "f32" else f"{dom_name}:{args.io}", {}) \
+                .get("traffic_bytes_per_launch")
     if rank == 0:
         line = {
             "metric": "adversarial PGD steps/sec x prompt-batch, LLaVA-1.5-7B pixel path at 1/2/4/8 MI355X",
@@ -193,7 +199,7 @@ def main():
                                    "owned pixel path isolated (synthetic upstream gradient in HBM; VLM fwd/bwd not included)",
                        "prompts_per_gpu": BATCH, "global_prompts": BATCH * world, "image": [3, H, W],
                        "noise": "in-kernel Philox4x32-10", "optimizer": "AdamW", "parallelism": f"dp{world}",
-                       "path": eng.mode},
+                       "path": eng.mode, "boundary_dtype": args.io},
             "steps_per_s": round(steps_per_s, 1),
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

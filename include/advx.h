@@ -228,6 +228,23 @@ int32_t advx_fused_bwd(advx_plan* plan, const float* grad_out, int32_t batch, fl
 int32_t advx_fused_update(advx_plan* plan, float* p, float* m, float* v, float* grad_p, const float* mask,
                           const float* x0, float epsilon, const advx_opt_scalars* opt, float* s_next,
                           float* v_buf, float* scratch, void* stream);
+/* The same pair with pixel_values written, and grad_out read, in the VLM's own dtype.  The
+ * reference hands fp32 pixel_values to a half-precision model whose first op casts them
+ * (attack_model.py:326-333, the vision tower's patch embedding runs in model.dtype), and
+ * autograd casts the half gradient back to fp32 on the way out; io_dtype = F16 / BF16 makes
+ * both round-to-nearest-even casts part of the pair, so `out` equals the fp32 result cast once
+ * and the fp32 copy (2 x 4 x B x P bytes) never touches HBM.  All arithmetic stays fp32. */
+#define ADVX_IO_F32 0
+#define ADVX_IO_F16 1
+#define ADVX_IO_BF16 2
+int32_t advx_fused_fwd_io(advx_plan* plan, const float* p, const float* x0, float epsilon, int32_t batch,
+                          const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset,
+                          void* out, int32_t io_dtype, float* s_buf, float* v_buf, int32_t prepared,
+                          int32_t parity, float* stats, float* scratch, void* stream);
+int32_t advx_fused_bwd_io(advx_plan* plan, const void* grad_out, int32_t io_dtype, int32_t batch, float* p,
+                          const float* x0, float epsilon, float imgfit_scale, const float* mask, float* m,
+                          float* v, float* grad_p, const advx_opt_scalars* opt, float* s_next, float* v_buf,
+                          float* stats, float* scratch, void* stream);
 int64_t advx_fused_scratch_floats(const advx_plan* plan);
 int32_t advx_fused_flush(advx_plan* plan, float* stats, float* scratch, int32_t image_too, void* stream);
 

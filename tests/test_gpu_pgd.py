@@ -192,3 +192,45 @@ def test_determinism_bitwise(dev):
             eng.backward_update([g])
         ps.append(eng.p.clone())
     assert torch.equal(ps[0], ps[1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("noise", ["philox", "given"])
+def test_pair_half_io_is_the_models_own_cast(dev, dtype, noise):
+    """io_dtype = the VLM's dtype: pixel_values must be the fp32 pixel_values rounded once
+    (round-to-nearest-even, what `pixel_values.to(model.dtype)` in the vision tower does,
+    attack_model.py:324 -> CLIP patch embedding), and a half gradient must give the same
+    update as that gradient widened to fp32 (what autograd's cast-backward hands the
+    reference).  Both bit-exact."""
+    from adversarialvlm_amd.pgd import PixelPGD
+    Plan = _plans()
+    B, H = 6, 112
+    x0 = torch.rand(3, H, H, generator=torch.Generator().manual_seed(11)).to(dev)
+    gen = torch.Generator().manual_seed(12)
+    grads = [(torch.randn(B, 3, H, H, generator=gen) * 0.02).to(dev).to(dtype) for _ in range(3)]
+    zs = [torch.randn(B, 3 * H * H, generator=gen).to(dev) for _ in range(3)]
+    engines = {io: PixelPGD(x0, [Plan.llava(H, H, H, H)], seed=3, fused_mode="pair", io_dtype=io)
+               for io in (torch.float32, dtype)}
+    for t in range(3):
+        outs = {}
+        for io, eng in engines.items():
+            z = zs[t] if noise == "given" else None
+            outs[io] = eng.forward(B, unit_noises=z)[0]
+            assert outs[io].dtype == io
+        assert torch.equal(outs[torch.float32].to(dtype), outs[dtype])
+        engines[torch.float32].backward_update([grads[t].float()])
+        engines[dtype].backward_update([grads[t]])
+        assert torch.equal(engines[torch.float32].p, engines[dtype].p)
+    a, b = engines[torch.float32].stats_dict(), engines[dtype].stats_dict()
+    assert a == b
+
+
+def test_half_io_needs_the_pair(dev):
+    from adversarialvlm_amd import _lib as L
+    from adversarialvlm_amd.pgd import PixelPGD
+    Plan = _plans()
+    x0 = torch.rand(3, 64, 64).to(dev)
+    with pytest.raises(L.AdvxError):
+        PixelPGD(x0, [Plan.llava(64, 64, 32, 32)], io_dtype=torch.float16)          # generic chain
+    with pytest.raises(L.AdvxError):
+        PixelPGD(x0, [Plan.llava(64, 64, 64, 64)], io_dtype=torch.float64)

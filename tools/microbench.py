@@ -71,6 +71,15 @@ def main():
         print(f"B={B:3d} ({mb:6.1f} MB): fused_fwd none {t0:6.1f}us  given-noise {t1:6.1f}us  philox {t2:6.1f}us | "
               f"fused_bwd+adamw {t3:6.1f}us  grad-only {t4:6.1f}us | batch_reduce {t5:6.1f}us | emit(philox) {t6:6.1f}us | "
               f"torch copy {t7:6.1f}us ({2 * mb / t7:.2f} TB/s r+w) | fused_step philox {t8:6.1f}us  no-noise {t9:6.1f}us", flush=True)
+        for dt in (torch.float16, torch.bfloat16):
+            oh, gh = out.to(dt), g.to(dt)
+            h0 = timeit(lambda: ops.fused_fwd(plan, p, x0, 0.5, B, stats, scr, s, vb, True, out=oh))
+            h1 = timeit(lambda: ops.fused_fwd(plan, p, x0, 0.5, B, stats, scr, s, vb, True, unit_noise=z, out=oh))
+            h2 = timeit(lambda: ops.fused_fwd(plan, p, x0, 0.5, B, stats, scr, s, vb, True, philox=(1, 2), out=oh))
+            h3 = timeit(lambda: ops.fused_bwd(plan, gh, B, p, x0, 0.5, 1.0, gp, stats, scr, mask=mask, m=m, v=v, opt=o,
+                                              s_next=s, v_buf=vb))
+            print(f"      io {str(dt):15s}: fused_fwd none {h0:6.1f}us  given-noise {h1:6.1f}us  philox {h2:6.1f}us | "
+                  f"fused_bwd+adamw {h3:6.1f}us", flush=True)
 
 
 if __name__ == "__main__":
