@@ -86,6 +86,17 @@ SIGNATURES = {
                                _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "advx_fused_step_rows": (_I32, [_P, _PI32, _PI32]),
     "advx_fused_step_flush": (_I32, [_P, _I32, _I32, _P, _P, _P]),
+    "advx_comm_create": (_I32, [_I32, _I32, _I64, _I32, C.POINTER(_P)]),
+    "advx_comm_export": (_I32, [_P, _P]),
+    "advx_comm_connect": (_I32, [_P, _P]),
+    "advx_comm_send_buffer": (_P, [_P]),
+    "advx_comm_recv_buffer": (_P, [_P]),
+    "advx_comm_mem_kind": (_I32, [_P]),
+    "advx_comm_allreduce": (_I32, [_P, _I64, C.c_double, _P]),
+    "advx_comm_status": (_I32, [_P, _PI32, _P]),
+    "advx_comm_destroy": (_I32, [_P]),
+    "advx_fused_bwd_dp": (_I32, [_P, _P, _P, _I32, _I32, _P, _P, _F, _F, _P, _P, _P, C.POINTER(OptScalars), _P, _P, _P, _P,
+                                 C.c_double, _P]),
     "advx_profile_begin": (_I32, [_I32, _I32]),
     "advx_profile_end": (_I32, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "advx_tanh_fwd": (_I32, [_P, _F, _P, _I64, _P]),

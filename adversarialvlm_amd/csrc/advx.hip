@@ -13,6 +13,7 @@
 
 #include "../../include/advx.h"
 #include "advx_kernels.h"
+#include "advx_comm.h"
 
 using namespace advx;
 
@@ -1166,4 +1167,191 @@ extern "C" int32_t advx_philox_normal(float* out, int64_t n, uint64_t seed, uint
                      (long long)n, seed, offset);
   LAUNCH_CHECK();
   return ADVX_OK;
+}
+
+// ----------------------------------------------------------- peer all-reduce (xGMI / IPC)
+// Data-parallel exchange of the shared image gradient without RCCL: see advx_comm.h for the
+// protocol.  The host code below only allocates the segment, trades IPC handles (the caller
+// moves the 64-byte handles between processes) and launches three kernels per all-reduce.
+struct advx_comm {
+  int rank = 0, world = 1;
+  long long floats = 0;          // capacity of send / recv
+  size_t bytes = 0;
+  char* base = nullptr;          // local segment
+  int mem_kind = 0;              // ADVX_COMM_MEM_*
+  void* peer[kCommMaxRanks] = {nullptr};
+  bool connected = false;
+  CommDev dev;
+};
+
+static size_t comm_payload_offset(long long floats, int which) {
+  size_t seg = ((size_t)floats * sizeof(float) + 255) & ~(size_t)255;
+  return (size_t)kCommFlagBytes + (size_t)which * seg;
+}
+
+extern "C" int32_t advx_comm_create(int32_t rank, int32_t world, int64_t floats, int32_t mem_kind, advx_comm** out) {
+  REQUIRE(out, ADVX_E_BADARG, "advx_comm_create: null out");
+  REQUIRE(world >= 1 && world <= kCommMaxRanks && rank >= 0 && rank < world, ADVX_E_BADARG,
+          "advx_comm_create: rank/world out of range (at most 16 ranks)");
+  REQUIRE(floats > 0 && floats % 4 == 0, ADVX_E_BADARG, "advx_comm_create: floats must be a positive multiple of 4");
+  advx_comm* c = new advx_comm();
+  c->rank = rank;
+  c->world = world;
+  c->floats = floats;
+  c->bytes = comm_payload_offset(floats, 2);
+  // exchange memory must not linger in the writer's or a reader's L2: uncached first, then
+  // fine-grained, then ordinary device memory (cross-process on ONE device only)
+  const int order_auto[3] = {ADVX_COMM_MEM_UNCACHED, ADVX_COMM_MEM_FINEGRAINED, ADVX_COMM_MEM_DEFAULT};
+  hipError_t e = hipErrorUnknown;
+  for (int k = 0; k < 3 && e != hipSuccess; ++k) {
+    int kind = (mem_kind == ADVX_COMM_MEM_AUTO) ? order_auto[k] : mem_kind;
+    void* ptr = nullptr;
+    if (kind == ADVX_COMM_MEM_UNCACHED) e = hipExtMallocWithFlags(&ptr, c->bytes, hipDeviceMallocUncached);
+    else if (kind == ADVX_COMM_MEM_FINEGRAINED) e = hipExtMallocWithFlags(&ptr, c->bytes, hipDeviceMallocFinegrained);
+    else if (kind == ADVX_COMM_MEM_DEFAULT) e = hipMalloc(&ptr, c->bytes);
+    else { delete c; return fail(ADVX_E_BADARG, "advx_comm_create: unknown mem_kind"); }
+    if (e == hipSuccess) {
+      // the segment must also be exportable: probe the handle now
+      hipIpcMemHandle_t h;
+      hipError_t e2 = (world > 1) ? hipIpcGetMemHandle(&h, ptr) : hipSuccess;
+      if (e2 != hipSuccess) {
+        (void)hipFree(ptr);
+        (void)hipGetLastError();
+        e = e2;
+      } else {
+        c->base = (char*)ptr;
+        c->mem_kind = kind;
+      }
+    } else {
+      (void)hipGetLastError();
+    }
+    if (mem_kind != ADVX_COMM_MEM_AUTO) break;
+  }
+  if (e != hipSuccess) {
+    delete c;
+    return fail(ADVX_E_HIP, std::string("advx_comm_create: no exportable device memory: ") + hipGetErrorString(e));
+  }
+  hipError_t em = hipMemset(c->base, 0, c->bytes);
+  if (em == hipSuccess) em = hipDeviceSynchronize();
+  if (em != hipSuccess) {
+    (void)hipFree(c->base);
+    delete c;
+    return fail(ADVX_E_HIP, std::string("advx_comm_create: memset: ") + hipGetErrorString(em));
+  }
+  c->peer[rank] = c->base;
+  if (world == 1) c->connected = true;
+  *out = c;
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_comm_export(advx_comm* c, void* handle) {
+  REQUIRE(c && handle, ADVX_E_BADARG, "advx_comm_export: null argument");
+  static_assert(sizeof(hipIpcMemHandle_t) == ADVX_COMM_HANDLE_BYTES, "IPC handle size");
+  hipIpcMemHandle_t h;
+  HIP_TRY(hipIpcGetMemHandle(&h, c->base));
+  std::memcpy(handle, &h, sizeof(h));
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_comm_connect(advx_comm* c, const void* handles) {
+  REQUIRE(c && handles, ADVX_E_BADARG, "advx_comm_connect: null argument");
+  REQUIRE(!c->connected, ADVX_E_BADARG, "advx_comm_connect: already connected");
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank) continue;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, (const char*)handles + (size_t)r * ADVX_COMM_HANDLE_BYTES, sizeof(h));
+    void* ptr = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      for (int q = 0; q < r; ++q)
+        if (q != c->rank && c->peer[q]) { (void)hipIpcCloseMemHandle(c->peer[q]); c->peer[q] = nullptr; }
+      return fail(ADVX_E_HIP, std::string("advx_comm_connect: hipIpcOpenMemHandle(rank ") + std::to_string(r) +
+                                  "): " + hipGetErrorString(e));
+    }
+    c->peer[r] = ptr;
+  }
+  c->connected = true;
+  return ADVX_OK;
+}
+
+static void comm_fill_dev(advx_comm* c, double timeout_s) {
+  CommDev& d = c->dev;
+  d.rank = c->rank;
+  d.world = c->world;
+  for (int r = 0; r < kCommMaxRanks; ++r) {
+    char* b = (r < c->world) ? (char*)c->peer[r] : nullptr;
+    d.flags[r] = b ? reinterpret_cast<uint32_t*>(b) : nullptr;
+    d.send[r] = b ? reinterpret_cast<const float*>(b + comm_payload_offset(c->floats, 0)) : nullptr;
+    d.recv[r] = b ? reinterpret_cast<float*>(b + comm_payload_offset(c->floats, 1)) : nullptr;
+  }
+  // local words behind the flag array (flags take kCommMaxRanks * 4 bytes)
+  d.epoch = reinterpret_cast<uint32_t*>(c->base + 1024);
+  d.error = reinterpret_cast<uint32_t*>(c->base + 1024 + 64);
+  d.timeout_ticks = (unsigned long long)(timeout_s * 1e8);   // wall_clock64 runs at 100 MHz
+}
+
+extern "C" float* advx_comm_send_buffer(advx_comm* c) {
+  return c ? reinterpret_cast<float*>(c->base + comm_payload_offset(c->floats, 0)) : nullptr;
+}
+extern "C" float* advx_comm_recv_buffer(advx_comm* c) {
+  return c ? reinterpret_cast<float*>(c->base + comm_payload_offset(c->floats, 1)) : nullptr;
+}
+extern "C" int32_t advx_comm_mem_kind(const advx_comm* c) { return c ? c->mem_kind : ADVX_E_BADARG; }
+
+static int32_t comm_allreduce_launch(advx_comm* c, long long floats, double timeout_s, hipStream_t st) {
+  REQUIRE(c->connected, ADVX_E_BADARG, "advx_comm_allreduce: not connected");
+  REQUIRE(floats > 0 && floats <= c->floats && floats % 4 == 0, ADVX_E_BADARG,
+          "advx_comm_allreduce: floats must be a multiple of 4 within the segment");
+  REQUIRE(timeout_s > 0.0 && timeout_s <= 600.0, ADVX_E_BADARG, "advx_comm_allreduce: timeout out of range");
+  comm_fill_dev(c, timeout_s);
+  const long long n4 = floats >> 2;
+  const long long per = (n4 + c->world - 1) / c->world;
+  hipLaunchKernelGGL(k_comm_barrier, dim3(1), dim3(64), 0, st, c->dev);   // every rank's send is complete
+  hipLaunchKernelGGL(k_comm_reduce, dim3(grid_for(per, 512)), dim3(kBlock), 0, st, c->dev, n4);
+  hipLaunchKernelGGL(k_comm_barrier, dim3(1), dim3(64), 0, st, c->dev);   // every slice has landed in recv
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_comm_allreduce(advx_comm* c, int64_t floats, double timeout_s, void* stream) {
+  REQUIRE(c, ADVX_E_BADARG, "advx_comm_allreduce: null comm");
+  return comm_allreduce_launch(c, floats, timeout_s, (hipStream_t)stream);
+}
+
+extern "C" int32_t advx_comm_status(advx_comm* c, int32_t* timed_out, void* stream) {
+  REQUIRE(c && timed_out, ADVX_E_BADARG, "advx_comm_status: null argument");
+  uint32_t w = 0;
+  HIP_TRY(hipMemcpyAsync(&w, c->base + 1024 + 64, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  *timed_out = (int32_t)w;
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_comm_destroy(advx_comm* c) {
+  if (!c) return ADVX_OK;
+  for (int r = 0; r < c->world; ++r)
+    if (r != c->rank && c->peer[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
+  if (c->base) (void)hipFree(c->base);
+  delete c;
+  return ADVX_OK;
+}
+
+// One call for the whole data-parallel backward of the fused pair: gradient-only backward into
+// the send buffer, peer all-reduce, then the fused update reading the recv buffer.
+extern "C" int32_t advx_fused_bwd_dp(advx_plan* p, advx_comm* c, const void* g, int32_t io_dtype, int32_t batch, float* pp,
+                                     const float* x0, float eps, float imgfit_scale, const float* mask, float* m, float* v,
+                                     const advx_opt_scalars* opt, float* s_next, float* v_buf, float* stats, float* scratch,
+                                     double timeout_s, void* stream) {
+  REQUIRE(p && c && opt, ADVX_E_BADARG, "advx_fused_bwd_dp: null argument");
+  const long long n = 3LL * p->info.in_h * p->info.in_w;
+  REQUIRE(n <= c->floats, ADVX_E_SHAPE, "advx_fused_bwd_dp: the exchange segment is smaller than the image");
+  float* send = advx_comm_send_buffer(c);
+  float* recv = advx_comm_recv_buffer(c);
+  int32_t rc = fused_bwd_impl(p, g, io_dtype, batch, pp, x0, eps, imgfit_scale, nullptr, nullptr, nullptr, send, nullptr,
+                              nullptr, nullptr, stats, scratch, stream);
+  if (rc) return rc;
+  rc = comm_allreduce_launch(c, n, timeout_s, (hipStream_t)stream);
+  if (rc) return rc;
+  return advx_fused_update(p, pp, m, v, recv, mask, x0, eps, opt, s_next, v_buf, scratch, stream);
 }

@@ -184,7 +184,9 @@ __device__ inline uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
     unsigned long long p1 = (unsigned long long)0xCD9E8D57u * (unsigned long long)c.z;
     uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-    c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+    // three-input xor in one VALU op (v_bitop3_b32, truth table 0x96; new on gfx950)
+    c = make_uint4(__builtin_amdgcn_bitop3_b32(hi1, c.y, k0, 0x96), lo1, __builtin_amdgcn_bitop3_b32(hi0, c.w, k1, 0x96),
+                   lo0);
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }

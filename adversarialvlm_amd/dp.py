@@ -54,3 +54,161 @@ def allreduce_image_grad_(grad, group=None):
     """The one exchange of a step."""
     torch.distributed.all_reduce(grad, op=torch.distributed.ReduceOp.SUM, group=group)
     return grad
+
+
+# ----------------------------------------------------------------------- peer exchange
+class _DevicePointer:
+    """Lets torch alias comm-owned device memory (zero copy) through __cuda_array_interface__."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+class PeerExchange:
+    """All-reduce(sum) of the image gradient by peer access over xGMI (advx_comm_* of
+    include/advx.h): every rank exports one uncached exchange segment through HIP IPC, maps the
+    others', and an all-reduce is barrier -> rank-ordered slice sums -> barrier on the caller's
+    stream.  torch.distributed is used ONCE, to carry the 64-byte handles between processes."""
+
+    MEM_NAMES = {1: "uncached", 2: "fine-grained", 3: "device"}
+
+    def __init__(self, floats, device, group=None, mem_kind=0, timeout_s=2.0):
+        import ctypes as C
+
+        from . import _lib as L
+        self.L = L
+        self.group = group
+        self.device = torch.device(device)
+        dist = torch.distributed
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.floats = (int(floats) + 3) // 4 * 4
+        self.timeout_s = float(timeout_s)
+        self.handle = None
+        lib = L.load()
+        with torch.cuda.device(self.device):
+            h = C.c_void_p()
+            rc = lib.advx_comm_create(self.rank, self.world, self.floats, int(mem_kind), C.byref(h))
+            err = None if rc == 0 else lib.advx_last_error().decode()
+            blob = b""
+            if rc == 0:
+                buf = C.create_string_buffer(64)
+                rc = lib.advx_comm_export(h, buf) if self.world > 1 else 0
+                err = None if rc == 0 else lib.advx_last_error().decode()
+                blob = buf.raw
+            # every rank must learn whether EVERY rank got this far, or the survivors would wait
+            # in all_gather for a peer that raised
+            blobs = [None] * self.world
+            if self.world > 1:
+                dist.all_gather_object(blobs, (err, blob), group=group)
+            else:
+                blobs = [(err, blob)]
+            errs = [e for e, _ in blobs if e]
+            if not errs and self.world > 1:
+                allh = C.create_string_buffer(b"".join(b for _, b in blobs), 64 * self.world)
+                rc = lib.advx_comm_connect(h, allh)
+                err = None if rc == 0 else lib.advx_last_error().decode()
+                flags = [None] * self.world
+                dist.all_gather_object(flags, err, group=group)
+                errs = [e for e in flags if e]
+            if errs:
+                if h:
+                    lib.advx_comm_destroy(h)
+                raise L.AdvxError("peer exchange unavailable: " + "; ".join(sorted(set(errs))))
+            self.handle = h
+            self.mem_kind = self.MEM_NAMES.get(lib.advx_comm_mem_kind(h), "?")
+            self.send = torch.as_tensor(_DevicePointer(lib.advx_comm_send_buffer(h), self.floats), device=self.device)
+            self.recv = torch.as_tensor(_DevicePointer(lib.advx_comm_recv_buffer(h), self.floats), device=self.device)
+
+    def all_reduce(self, floats=None):
+        """send -> (sum over ranks, rank order) -> recv of every rank, on the current stream."""
+        L = self.L
+        n = self.floats if floats is None else (int(floats) + 3) // 4 * 4
+        L.check(L.load().advx_comm_allreduce(self.handle, n, self.timeout_s, L.current_stream(self.device)),
+                "advx_comm_allreduce")
+        return self.recv
+
+    def all_reduce_(self, tensor):
+        """In-place convenience for tensors that live elsewhere (two small device copies)."""
+        n = tensor.numel()
+        self.send[:n].copy_(tensor.reshape(-1))
+        self.all_reduce(n)
+        tensor.copy_(self.recv[:n].view_as(tensor))
+        return tensor
+
+    def timed_out(self):
+        """True once any barrier of this rank gave up waiting (synchronises the stream)."""
+        import ctypes as C
+        L = self.L
+        w = C.c_int32(0)
+        L.check(L.load().advx_comm_status(self.handle, C.byref(w), L.current_stream(self.device)), "advx_comm_status")
+        return bool(w.value)
+
+    def close(self):
+        if self.handle is not None:
+            # the views die with the segment
+            self.send = self.recv = None
+            self.L.load().advx_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def probe_peer_exchange(ex, group=None, rounds=3, seed=1234):
+    """Trust the peer path only after it has reproduced, bit for bit, the rank-ordered sum of
+    known data on THIS machine; every rank returns the same verdict."""
+    dist = torch.distributed
+    ok = True
+    n = ex.floats
+    for r in range(rounds):
+        gen = torch.Generator().manual_seed(seed + 1000 * r + ex.rank)
+        mine = torch.randn(n, generator=gen).to(ex.device)
+        ex.send.copy_(mine)
+        got = ex.all_reduce().clone()
+        if ex.world > 1:
+            # the reference sum comes over the host library (staged through the CPU for gloo)
+            src = mine.cpu() if dist.get_backend(group) == "gloo" else mine
+            parts = [torch.empty_like(src) for _ in range(ex.world)]
+            dist.all_gather(parts, src, group=group)
+            parts = [q.to(ex.device) for q in parts]
+        else:
+            parts = [mine]
+        want = parts[0].clone()
+        for q in parts[1:]:
+            want += q
+        ok = ok and bool(torch.equal(got, want))
+    ok = ok and not ex.timed_out()
+    if ex.world > 1:
+        flag = torch.tensor([1 if ok else 0], device=ex.device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = bool(flag.item())
+    return ok
+
+
+def make_exchange(floats, device, group=None, transport="auto", timeout_s=2.0):
+    """transport: "rccl" -> None (torch.distributed all-reduce); "peer" -> PeerExchange or an
+    error; "auto" -> PeerExchange if it can be set up AND passes the probe, else None."""
+    if transport not in ("auto", "peer", "rccl"):
+        raise ValueError("transport must be auto, peer or rccl")
+    if transport == "rccl":
+        return None
+    dist = torch.distributed
+    if dist.is_initialized() and dist.get_backend(group) == "gloo" and transport == "auto":
+        return None          # CPU rehearsal groups keep the host all-reduce
+    try:
+        ex = PeerExchange(floats, device, group=group, timeout_s=timeout_s)
+    except Exception:
+        if transport == "peer":
+            raise
+        return None
+    if not probe_peer_exchange(ex, group):
+        ex.close()
+        if transport == "peer":
+            from . import _lib as L
+            raise L.AdvxError("peer exchange failed its self-test on this machine")
+        return None
+    return ex

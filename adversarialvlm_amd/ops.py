@@ -187,6 +187,21 @@ def fused_bwd(plan, grad_out, batch, p, x0, epsilon, imgfit_scale, grad_p, stats
                                        L.ptr(stats), L.ptr(scratch), _stream(p)), "advx_fused_bwd_io")
 
 
+def fused_bwd_dp(plan, exchange, grad_out, batch, p, x0, epsilon, imgfit_scale, stats, scratch, mask, m, v, opt, s_next,
+                 v_buf):
+    """Data-parallel backward of the pair in ONE call: gradient-only backward into the exchange's
+    send buffer, peer all-reduce (dp.PeerExchange), fused update from its recv buffer."""
+    _require_cuda(grad_out, p, x0, scratch, stats, mask, s_next, v_buf)
+    io = io_code(grad_out.dtype)
+    grad_out = grad_out.contiguous()
+    if grad_out.numel() != batch * plan.out_numel:
+        raise L.AdvxError("grad_out has the wrong number of elements")
+    L.check(L.load().advx_fused_bwd_dp(plan.handle, exchange.handle, L.ptr(grad_out), io, int(batch), L.ptr(p), L.ptr(x0),
+                                       float(epsilon), float(imgfit_scale), L.ptr(mask), L.ptr(m), L.ptr(v), C.byref(opt),
+                                       L.ptr(s_next), L.ptr(v_buf), L.ptr(stats), L.ptr(scratch),
+                                       float(exchange.timeout_s), _stream(p)), "advx_fused_bwd_dp")
+
+
 def fused_update(plan, p, m, v, grad_p, mask, x0, epsilon, opt, s_next, v_buf, scratch):
     """DP tail of the pair: mask, ||g|| partials, optimiser step, preparation of the next forward."""
     _require_cuda(p, grad_p, mask, x0, s_next, v_buf, scratch)

@@ -32,11 +32,14 @@ class PixelPGD:
                  scheduler_gamma=1.0, grad_accum_steps=1, blur_kernel=None, use_crop=False, model_weights=None,
                  optimizer="adamw", cross_mode=False, betas=(0.9, 0.999), adam_eps=1e-8, weight_decay=1e-2, seed=0,
                  process_group=None, allow_fused=True, fused_mode="auto", grad_prescale=None, force_exchange=False,
-                 io_dtype=torch.float32):
+                 io_dtype=torch.float32, exchange_transport="auto"):
         """io_dtype: dtype of the pixel_values handed to the VLM by the fused pair.  float32 is
         the reference's own boundary; float16 / bfloat16 emit the tensor already cast to the
         model's dtype (the cast the model's first layer would apply) and let backward_update
-        read the half gradient directly."""
+        read the half gradient directly.
+        exchange_transport: how the data-parallel all-reduce of the image gradient travels -
+        "peer" (advx_comm_*: IPC-mapped segments over xGMI, in-library kernels), "rccl"
+        (torch.distributed) or "auto" (peer if it sets up and passes its self-test here)."""
         if not x0.is_cuda:
             raise L.AdvxError("PixelPGD needs x0 on a ROCm device (there is no CPU fallback)")
         if not isinstance(plans, (list, tuple)):
@@ -76,6 +79,9 @@ class PixelPGD:
         # run the data-parallel chain (gradient-only backward, all-reduce, separate update) even
         # for a group of one rank: lets a single GPU exercise the RCCL path
         self.exchange = self.world > 1 or bool(force_exchange)
+        self.peer = None
+        if self.exchange:
+            self.peer = dp.make_exchange(self.x0.numel(), dev, process_group, exchange_transport)
         # factor every rank applies to its contribution before the SUM all-reduce: 1/world gives
         # the data-parallel average; cross-model groups pass 1/group_size (average inside a
         # model's group, sum across models - crossattack_models.py:391)
@@ -100,6 +106,9 @@ class PixelPGD:
         if io_dtype != torch.float32 and self.mode != "pair":
             raise L.AdvxError(f"io_dtype={io_dtype} needs the fused pair; this engine runs the {self.mode} chain")
         self.io_dtype = io_dtype
+        if self.peer is not None and self.mode == "pair":
+            # the masked, all-reduced gradient of the last step lives in the exchange's recv buffer
+            self.grad = self.peer.recv[:self.x0.numel()].view_as(self.x0)
         if self.fused:
             # the forward reads its sigma from slot QERR_STD (the previous image's quantise error)
             self.stats[L.STAT_QERR_STD] = float(sigma0)
@@ -239,6 +248,11 @@ class PixelPGD:
                 ops.fused_bwd(pl, grads[0], B, self.p, self.x0, self.eps, self.imgfit_scale(), self.grad, self.stats,
                               self.fused_scratch, mask=self.mask, m=self.m, v=self.v, opt=opt,
                               s_next=self.s_bufs[nxt], v_buf=self.v_buf)
+            elif self.peer is not None:
+                # backward, peer all-reduce (rank-ordered sums over xGMI) and update: one call,
+                # five launches, nothing on the host in between
+                ops.fused_bwd_dp(pl, self.peer, grads[0], B, self.p, self.x0, self.eps, self.imgfit_scale(), self.stats,
+                                 self.fused_scratch, self.mask, self.m, self.v, opt, self.s_bufs[nxt], self.v_buf)
             else:
                 ops.fused_bwd(pl, grads[0], B, self.p, self.x0, self.eps, self.imgfit_scale(), self.grad, self.stats,
                               self.fused_scratch)
@@ -257,7 +271,10 @@ class PixelPGD:
             if self.exchange and take_step:
                 # The reduction is linear, so a gradient-accumulation window is exchanged once,
                 # at its end (intermediate grad norms are then rank-local).
-                dp.allreduce_image_grad_(self.grad, self.pg)
+                if self.peer is not None:
+                    self.peer.all_reduce_(self.grad)
+                else:
+                    dp.allreduce_image_grad_(self.grad, self.pg)
             ops.update(self.p, self.m, self.v, self.grad, self.mask, opt, self.stats, self.upd_scratch)
         if take_step:
             self._scheduler_step()

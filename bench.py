@@ -88,6 +88,9 @@ def main():
                                                        "the multi-rank path on one GPU)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="rehearsal: run the data-parallel chain (RCCL all-reduce included) with a single rank")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "peer", "rccl"],
+                    help="transport of the per-step image-gradient all-reduce: peer = IPC-mapped segments over xGMI "
+                         "(advx_comm_*), rccl = torch.distributed, auto = peer if it passes its self-test here")
     ap.add_argument("--chain", default="auto", choices=["auto", "pair", "step"],
                     help="fused chain: step = one launch per step (single GPU), pair = two launches")
     ap.add_argument("--io", default="f32", choices=["f32", "f16", "bf16"],
@@ -133,7 +136,12 @@ def main():
     g = torch.randn(BATCH, 3, H, W, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     plan = Plan.llava(H, W)
     eng = PixelPGD(x0, [plan], epsilon=0.5, lr=1e-2, sigma0=1e-3, seed=1234 + rank, process_group=pg,
-                   allow_fused=not args.no_fused, fused_mode=args.chain, force_exchange=args.force_exchange, io_dtype=io_dtype)
+                   allow_fused=not args.no_fused, fused_mode=args.chain, force_exchange=args.force_exchange, io_dtype=io_dtype,
+                   exchange_transport=args.exchange)
+    if not eng.exchange:
+        exchange = "none (single rank)"
+    else:
+        exchange = f"peer ({eng.peer.mem_kind} IPC segments)" if eng.peer is not None else f"{args.backend} all-reduce"
     # every rank pre-scales its share so that the SUM all-reduce is the DP average
     gs = (g * eng.loss_scale(0)).to(io_dtype)
 
@@ -164,6 +172,16 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     fwd_avg, bwd_avg, step_avg = prof["fwd"][0], prof["bwd"][0], prof["step"][0]
+    # after the timed region: the replicas of p must still hold the same bits on every rank, and no
+    # barrier of the peer exchange may have timed out
+    replicas_identical = None
+    if world > 1:
+        digest = torch.stack([eng.p.double().sum(), eng.p.double().abs().sum(), (eng.p.double() ** 2).sum()])
+        lo, hi = digest.clone(), digest.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo, hi))
+    exchange_timed_out = bool(eng.peer.timed_out()) if eng.peer is not None else None
 
     n_in = 3 * H * W
     bytes_fwd = io_bytes * BATCH * n_in + 4 * 2 * n_in     # write B*P_out, read p,x0
@@ -199,7 +217,8 @@ def main():
                                    "owned pixel path isolated (synthetic upstream gradient in HBM; VLM fwd/bwd not included)",
                        "prompts_per_gpu": BATCH, "global_prompts": BATCH * world, "image": [3, H, W],
                        "noise": "in-kernel Philox4x32-10", "optimizer": "AdamW", "parallelism": f"dp{world}",
-                       "path": eng.mode, "boundary_dtype": args.io},
+                       "path": eng.mode, "boundary_dtype": args.io, "exchange": exchange,
+                       "replicas_identical": replicas_identical, "exchange_timed_out": exchange_timed_out},
             "steps_per_s": round(steps_per_s, 1),
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

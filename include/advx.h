@@ -269,6 +269,45 @@ int32_t advx_fused_step_rows(const advx_plan* plan, int32_t* rows_after_fwd, int
 int32_t advx_fused_step_flush(advx_plan* plan, int32_t parity, int32_t norm_rows, float* stats,
                               float* scratch, void* stream);
 
+/* -------------------------------------------------- data-parallel exchange
+ * The reference has no data parallelism (one process, one model per GPU:
+ * crossattack_models.py:244-258); the exchange added here is ONE all-reduce(sum) per step of the
+ * shared image gradient (P_in floats, 1.35 MB at 336x336), each rank having pre-scaled its
+ * share.  Two transports behind the same call sites: RCCL (torch.distributed, host side) and
+ * this peer all-reduce, which needs no host library at all:
+ *   - every rank creates ONE exchange segment in uncached device memory
+ *     [flags | send | recv], exports its HIP IPC handle (64 bytes; the caller carries the
+ *     handles between the processes) and maps the segments of all peers over xGMI;
+ *   - advx_comm_allreduce = barrier -> reduce -> barrier, three launches with constant
+ *     arguments: rank r sums the r-th slice of all send buffers IN RANK ORDER (every replica
+ *     gets the same bits) and posts the sum into the recv buffer of every peer;
+ *   - a barrier that does not complete within timeout_s sets a sticky error word and lets
+ *     its kernel exit: a lost peer costs a wrong step, reported by advx_comm_status, never a
+ *     hung device.
+ * send / recv are device pointers owned by the comm (valid until advx_comm_destroy). */
+typedef struct advx_comm advx_comm;
+#define ADVX_COMM_HANDLE_BYTES 64
+#define ADVX_COMM_MEM_AUTO 0        /* uncached, else fine-grained, else ordinary device memory */
+#define ADVX_COMM_MEM_UNCACHED 1
+#define ADVX_COMM_MEM_FINEGRAINED 2
+#define ADVX_COMM_MEM_DEFAULT 3     /* coherent between processes of ONE device only */
+int32_t advx_comm_create(int32_t rank, int32_t world, int64_t floats, int32_t mem_kind, advx_comm** out);
+int32_t advx_comm_export(advx_comm* comm, void* handle /* ADVX_COMM_HANDLE_BYTES */);
+int32_t advx_comm_connect(advx_comm* comm, const void* handles /* world x 64 bytes, rank order */);
+float* advx_comm_send_buffer(advx_comm* comm);
+float* advx_comm_recv_buffer(advx_comm* comm);
+int32_t advx_comm_mem_kind(const advx_comm* comm);
+int32_t advx_comm_allreduce(advx_comm* comm, int64_t floats, double timeout_s, void* stream);
+int32_t advx_comm_status(advx_comm* comm, int32_t* timed_out, void* stream); /* synchronises */
+int32_t advx_comm_destroy(advx_comm* comm);
+/* The data-parallel backward of the fused pair in one call: advx_fused_bwd_io(opt = NULL) into
+ * the send buffer, advx_comm_allreduce, advx_fused_update from the recv buffer. */
+int32_t advx_fused_bwd_dp(advx_plan* plan, advx_comm* comm, const void* grad_out, int32_t io_dtype,
+                          int32_t batch, float* p, const float* x0, float epsilon, float imgfit_scale,
+                          const float* mask, float* m, float* v, const advx_opt_scalars* opt,
+                          float* s_next, float* v_buf, float* stats, float* scratch, double timeout_s,
+                          void* stream);
+
 /* ---------------------------------------------------------------- profiling
  * Per-kernel device time of the B*P_out movers (k_fused_fwd, k_fused_bwd, k_fused_step):
  * between begin and end each of their launches carries its own start/stop HIP event pair on

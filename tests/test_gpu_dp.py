@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank(rank, world, port, chain, out):
+def _rank(rank, world, port, chain, out, transport="rccl"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
@@ -35,8 +35,10 @@ def _rank(rank, world, port, chain, out):
     local = B // world
     sl = slice(rank * local, (rank + 1) * local)
     kw = dict(allow_fused=False) if chain == "generic" else dict(fused_mode="pair")
-    eng = PixelPGD(x0.to(dev), [Plan.llava(H, H, H, H)], lr=1e-2, process_group=torch.distributed.group.WORLD, **kw)
+    eng = PixelPGD(x0.to(dev), [Plan.llava(H, H, H, H)], lr=1e-2, process_group=torch.distributed.group.WORLD,
+                   exchange_transport=transport, **kw)
     assert eng.world == world
+    assert (eng.peer is not None) == (transport == "peer")
     for t in range(3):
         eng.forward(local, [zs[t][sl].to(dev)])
         # mean-type loss over the LOCAL batch, then the engine's DP pre-scale
@@ -47,15 +49,15 @@ def _rank(rank, world, port, chain, out):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("chain", ["pair", "generic"])
-def test_two_ranks_match_single_process(chain):
+@pytest.mark.parametrize("chain,transport", [("pair", "rccl"), ("generic", "rccl"), ("pair", "peer"), ("generic", "peer")])
+def test_two_ranks_match_single_process(chain, transport):
     from adversarialvlm_amd.pgd import PixelPGD
     from adversarialvlm_amd.plan import Plan
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     out = mgr.dict()
     port = _free_port()
-    mp.spawn(_rank, args=(2, port, chain, out), nprocs=2, join=True)
+    mp.spawn(_rank, args=(2, port, chain, out, transport), nprocs=2, join=True)
     (p0, n0, s0), (p1, n1, s1) = out[0], out[1]
     assert torch.equal(p0, p1) and n0 == n1 and s0 == s1        # replicas bit-identical
     dev = torch.device("cuda:0")
@@ -73,7 +75,7 @@ def test_two_ranks_match_single_process(chain):
     assert n0 == pytest.approx(rst["grad_norm"], rel=1e-5) and s0 == pytest.approx(rst["sigma_next"], rel=1e-6)
 
 
-def _rccl_single(rank, port, out):
+def _rccl_single(rank, port, out, transport):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
@@ -87,7 +89,9 @@ def _rccl_single(rank, port, out):
     gs = [(torch.randn(4, 3, 64, 64, generator=gen) * 0.01).to(dev) for _ in range(3)]
     res = []
     for force in (True, False):
-        eng = PixelPGD(x0, [Plan.llava(64, 64, 64, 64)], process_group=torch.distributed.group.WORLD, force_exchange=force)
+        eng = PixelPGD(x0, [Plan.llava(64, 64, 64, 64)], process_group=torch.distributed.group.WORLD, force_exchange=force,
+                       exchange_transport=transport)
+        assert (eng.peer is not None) == (force and transport == "peer")
         for t in range(3):
             eng.forward(4, [zs[t]])
             eng.backward_update([gs[t]])
@@ -99,14 +103,94 @@ def _rccl_single(rank, port, out):
 
 
 @pytest.mark.timeout(300)
-def test_rccl_exchange_chain_single_rank():
+@pytest.mark.parametrize("transport", ["rccl", "peer"])
+def test_rccl_exchange_chain_single_rank(transport):
     """backend "nccl" IS RCCL on ROCm: a one-rank group drives the real data-parallel chain
     (fused_bwd grad-only -> RCCL all-reduce -> fused_update -> prepared forward) on the GPU and
     must reproduce the single-launch update bit for bit."""
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
-    mp.spawn(_rccl_single, args=(_free_port(), out), nprocs=1, join=True)
+    mp.spawn(_rccl_single, args=(_free_port(), out, transport), nprocs=1, join=True)
     assert out["same_p"]
     a, b = out["stats"]
     for k in a:
         assert a[k] == pytest.approx(b[k], rel=1e-6, abs=1e-12), k
+
+
+# ------------------------------------------------------------------ peer all-reduce (advx_comm_*)
+def _peer_rank(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    torch.distributed.init_process_group("gloo")
+    from adversarialvlm_amd import dp
+    res = {}
+    for n in (3 * 336 * 336, 1000, 8):
+        ex = dp.PeerExchange(n, dev, timeout_s=5.0)
+        res["mem"] = ex.mem_kind
+        ok = dp.probe_peer_exchange(ex, rounds=2)
+        # many back-to-back exchanges with fresh data: the epoch protocol must never let a rank
+        # read a peer's buffer of the wrong step
+        same = True
+        for t in range(25):
+            gen = torch.Generator().manual_seed(100 * t + rank)
+            mine = torch.randn(ex.floats, generator=gen)
+            ex.send.copy_(mine.to(dev))
+            got = ex.all_reduce().cpu()
+            want = torch.randn(ex.floats, generator=torch.Generator().manual_seed(100 * t))
+            for r in range(1, world):
+                want += torch.randn(ex.floats, generator=torch.Generator().manual_seed(100 * t + r))
+            same = same and bool(torch.equal(got, want))
+        res[n] = (ok, same, ex.timed_out())
+        torch.distributed.barrier()
+        ex.close()
+    out[rank] = res
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_allreduce_is_the_rank_ordered_sum(world):
+    """advx_comm_*: IPC-mapped exchange segments, barrier -> slice sums in rank order -> barrier.
+    Ranks share the one GPU of the box (the mapping and the protocol are the ones xGMI peers
+    use); the result must equal ((r0 + r1) + r2) bit for bit on every rank, for sizes that do
+    and do not divide by the world size."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_peer_rank, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        for n in (3 * 336 * 336, 1000, 8):
+            ok, same, timed_out = out[r][n]
+            assert ok and same and not timed_out, (r, n, out[r])
+
+
+def _peer_lost(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    torch.distributed.init_process_group("gloo")
+    import time
+
+    from adversarialvlm_amd import dp
+    ex = dp.PeerExchange(4096, dev, timeout_s=0.25)
+    if rank == 0:
+        t0 = time.perf_counter()
+        ex.all_reduce()                     # rank 1 never joins
+        lost = ex.timed_out()               # synchronises: the kernels have exited
+        out["rank0"] = (lost, time.perf_counter() - t0)
+    torch.distributed.barrier()
+    ex.close()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_peer_barrier_gives_up_instead_of_hanging():
+    """A peer that never arrives must cost a reported time-out, not a hung device: both barrier
+    kernels of the lonely rank exit after timeout_s and the sticky error word is set."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_peer_lost, args=(2, _free_port(), out), nprocs=2, join=True)
+    lost, seconds = out["rank0"]
+    assert lost and seconds < 5.0
