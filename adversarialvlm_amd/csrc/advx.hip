@@ -13,7 +13,6 @@
 
 #include "../../include/advx.h"
 #include "advx_kernels.h"
-#include "advx_comm.h"
 
 using namespace advx;
 
@@ -586,12 +585,16 @@ extern "C" int32_t advx_emit(advx_plan* p, const float* argument, int32_t batch,
   return ADVX_OK;
 }
 
-static int32_t launch_batch_reduce(const float* g, int batch, long long n, float* out, hipStream_t st) {
+// [live_lo, live_hi): flat indices of a sample whose gradient is needed (defaults: all of it)
+static int32_t launch_batch_reduce(const float* g, int batch, long long n, float* out, hipStream_t st,
+                                   long long live_lo = 0, long long live_hi = -1) {
   REQUIRE(aligned16(g) && aligned16(out), ADVX_E_BADARG, "batch_reduce: pointers must be 16-byte aligned");
+  if (live_hi < 0 || live_hi > n) live_hi = n;
   if ((n & 3) == 0) {
-    long long n4 = n >> 2;
-    int blocks = (int)((n4 + kWave - 1) / kWave);
-    hipLaunchKernelGGL(k_batch_reduce, dim3(blocks), dim3(kBlock), 0, st, g, batch, n, out);
+    long long q_lo = live_lo >> 2, q_hi = (live_hi + 3) >> 2;
+    if (q_hi <= q_lo) return ADVX_OK;
+    int blocks = (int)((q_hi - q_lo + kWave - 1) / kWave);
+    hipLaunchKernelGGL(k_batch_reduce, dim3(blocks), dim3(kBlock), 0, st, g, batch, n, out, q_lo, q_hi);
   } else {
     // rows are not 16-byte aligned: scalar columns (test-sized inputs only)
     hipLaunchKernelGGL(k_batch_reduce_scalar, dim3(grid_for(n)), dim3(kBlock), 0, st, g, batch, n, out);
@@ -610,7 +613,14 @@ extern "C" int32_t advx_collect(advx_plan* p, const float* grad_out, int32_t bat
   hipStream_t st = (hipStream_t)stream;
   const float* gsum = grad_out;
   if (batch > 1) {
-    rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st);
+    // the emits cover [lo, hi); what lies outside is constant padding whose gradient goes nowhere
+    long long lo = p->info.out_numel, hi = 0;
+    for (int k = 0; k < p->dplan.n_emit; ++k) {
+      const DEmit& e = p->dplan.e[k];
+      lo = std::min(lo, e.out_begin);
+      hi = std::max(hi, e.out_begin + e.out_count);   // out_count includes the temporal copies (QWEN)
+    }
+    rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st, lo, hi);
     if (rc) return rc;
     gsum = ws + p->dplan.gsum_off;
   }
@@ -1065,9 +1075,10 @@ extern "C" int32_t advx_fused_step_flush(advx_plan* p, int32_t parity, int32_t n
   return ADVX_OK;
 }
 
-extern "C" int32_t advx_fused_update(advx_plan* p, float* pp, float* m, float* v, float* grad_p, const float* mask,
-                                     const float* x0, float eps, const advx_opt_scalars* opt, float* s_next,
-                                     float* v_buf, float* scratch, void* stream) {
+// comm != nullptr: grad_p is the recv buffer of that peer exchange and the kernel waits for it
+static int32_t fused_update_impl(advx_plan* p, float* pp, float* m, float* v, float* grad_p, const float* mask,
+                                 const float* x0, float eps, const advx_opt_scalars* opt, float* s_next, float* v_buf,
+                                 float* scratch, const CommDev* comm, void* stream) {
   REQUIRE(p && pp && grad_p && mask && x0 && opt && s_next && v_buf && scratch, ADVX_E_BADARG,
           "advx_fused_update: null argument");
   REQUIRE(advx_fused_supported(p), ADVX_E_UNSUPPORTED, "advx_fused_update: plan is not an identity LLaVA plan");
@@ -1075,13 +1086,24 @@ extern "C" int32_t advx_fused_update(advx_plan* p, float* pp, float* m, float* v
   int32_t rc = check_opt(opt, m, v);
   if (rc) return rc;
   FusedScratch f = carve_fused(p, scratch);
-  const long long n = 3LL * p->info.in_h * p->info.in_w;
   // one block per 256 pixels: the norm rows have exactly f.bwd_blocks entries
-  hipLaunchKernelGGL(k_fused_update, dim3(f.bwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, pp, m, v, grad_p, mask, x0,
-                     eps, fused_geom(p), to_dev(opt), s_next, v_buf, f.norm_partials, f.hdr);
-  (void)n;
+  if (comm) {
+    hipLaunchKernelGGL(k_fused_update<true>, dim3(f.bwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, pp, m, v, grad_p, mask,
+                       x0, eps, fused_geom(p), to_dev(opt), s_next, v_buf, f.norm_partials, f.hdr, *comm);
+  } else {
+    CommDev none;
+    std::memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL(k_fused_update<false>, dim3(f.bwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, pp, m, v, grad_p, mask,
+                       x0, eps, fused_geom(p), to_dev(opt), s_next, v_buf, f.norm_partials, f.hdr, none);
+  }
   LAUNCH_CHECK();
   return ADVX_OK;
+}
+
+extern "C" int32_t advx_fused_update(advx_plan* p, float* pp, float* m, float* v, float* grad_p, const float* mask,
+                                     const float* x0, float eps, const advx_opt_scalars* opt, float* s_next,
+                                     float* v_buf, float* scratch, void* stream) {
+  return fused_update_impl(p, pp, m, v, grad_p, mask, x0, eps, opt, s_next, v_buf, scratch, nullptr, stream);
 }
 
 extern "C" int32_t advx_fused_flush(advx_plan* p, float* stats, float* scratch, int32_t image_too, void* stream) {
@@ -1176,6 +1198,7 @@ extern "C" int32_t advx_philox_normal(float* out, int64_t n, uint64_t seed, uint
 struct advx_comm {
   int rank = 0, world = 1;
   long long floats = 0;          // capacity of send / recv
+  uint32_t epoch = 0, posted = 0; // exchanges / reduce workgroups launched so far (same on all ranks)
   size_t bytes = 0;
   char* base = nullptr;          // local segment
   int mem_kind = 0;              // ADVX_COMM_MEM_*
@@ -1279,15 +1302,9 @@ static void comm_fill_dev(advx_comm* c, double timeout_s) {
   CommDev& d = c->dev;
   d.rank = c->rank;
   d.world = c->world;
-  for (int r = 0; r < kCommMaxRanks; ++r) {
-    char* b = (r < c->world) ? (char*)c->peer[r] : nullptr;
-    d.flags[r] = b ? reinterpret_cast<uint32_t*>(b) : nullptr;
-    d.send[r] = b ? reinterpret_cast<const float*>(b + comm_payload_offset(c->floats, 0)) : nullptr;
-    d.recv[r] = b ? reinterpret_cast<float*>(b + comm_payload_offset(c->floats, 1)) : nullptr;
-  }
-  // local words behind the flag array (flags take kCommMaxRanks * 4 bytes)
-  d.epoch = reinterpret_cast<uint32_t*>(c->base + 1024);
-  d.error = reinterpret_cast<uint32_t*>(c->base + 1024 + 64);
+  for (int r = 0; r < kCommMaxRanks; ++r) d.base[r] = (r < c->world) ? (char*)c->peer[r] : nullptr;
+  d.send_off = (long long)comm_payload_offset(c->floats, 0);
+  d.recv_off = (long long)comm_payload_offset(c->floats, 1);
   d.timeout_ticks = (unsigned long long)(timeout_s * 1e8);   // wall_clock64 runs at 100 MHz
 }
 
@@ -1299,7 +1316,9 @@ extern "C" float* advx_comm_recv_buffer(advx_comm* c) {
 }
 extern "C" int32_t advx_comm_mem_kind(const advx_comm* c) { return c ? c->mem_kind : ADVX_E_BADARG; }
 
-static int32_t comm_allreduce_launch(advx_comm* c, long long floats, double timeout_s, hipStream_t st) {
+// reduce (with the "send complete" rendezvous on entry, "slices posted" signal on exit); the
+// consumer of recv waits for the second rendezvous itself (wait_kernel: a one-block launch does)
+static int32_t comm_allreduce_launch(advx_comm* c, long long floats, double timeout_s, bool wait_kernel, hipStream_t st) {
   REQUIRE(c->connected, ADVX_E_BADARG, "advx_comm_allreduce: not connected");
   REQUIRE(floats > 0 && floats <= c->floats && floats % 4 == 0, ADVX_E_BADARG,
           "advx_comm_allreduce: floats must be a multiple of 4 within the segment");
@@ -1307,22 +1326,25 @@ static int32_t comm_allreduce_launch(advx_comm* c, long long floats, double time
   comm_fill_dev(c, timeout_s);
   const long long n4 = floats >> 2;
   const long long per = (n4 + c->world - 1) / c->world;
-  hipLaunchKernelGGL(k_comm_barrier, dim3(1), dim3(64), 0, st, c->dev);   // every rank's send is complete
-  hipLaunchKernelGGL(k_comm_reduce, dim3(grid_for(per, 512)), dim3(kBlock), 0, st, c->dev, n4);
-  hipLaunchKernelGGL(k_comm_barrier, dim3(1), dim3(64), 0, st, c->dev);   // every slice has landed in recv
+  const int blocks = grid_for(per, 512);
+  // every rank makes the same sequence of calls, so these host counters agree everywhere
+  c->dev.epoch = ++c->epoch;
+  c->dev.posted = (c->posted += (uint32_t)blocks);
+  hipLaunchKernelGGL(k_comm_reduce, dim3(blocks), dim3(kBlock), 0, st, c->dev, n4);
+  if (wait_kernel) hipLaunchKernelGGL(k_comm_wait, dim3(1), dim3(64), 0, st, c->dev);
   LAUNCH_CHECK();
   return ADVX_OK;
 }
 
 extern "C" int32_t advx_comm_allreduce(advx_comm* c, int64_t floats, double timeout_s, void* stream) {
   REQUIRE(c, ADVX_E_BADARG, "advx_comm_allreduce: null comm");
-  return comm_allreduce_launch(c, floats, timeout_s, (hipStream_t)stream);
+  return comm_allreduce_launch(c, floats, timeout_s, true, (hipStream_t)stream);
 }
 
 extern "C" int32_t advx_comm_status(advx_comm* c, int32_t* timed_out, void* stream) {
   REQUIRE(c && timed_out, ADVX_E_BADARG, "advx_comm_status: null argument");
   uint32_t w = 0;
-  HIP_TRY(hipMemcpyAsync(&w, c->base + 1024 + 64, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipMemcpyAsync(&w, c->base + kCommOffError, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   *timed_out = (int32_t)w;
   return ADVX_OK;
@@ -1351,7 +1373,7 @@ extern "C" int32_t advx_fused_bwd_dp(advx_plan* p, advx_comm* c, const void* g, 
   int32_t rc = fused_bwd_impl(p, g, io_dtype, batch, pp, x0, eps, imgfit_scale, nullptr, nullptr, nullptr, send, nullptr,
                               nullptr, nullptr, stats, scratch, stream);
   if (rc) return rc;
-  rc = comm_allreduce_launch(c, n, timeout_s, (hipStream_t)stream);
+  rc = comm_allreduce_launch(c, n, timeout_s, false, (hipStream_t)stream);
   if (rc) return rc;
-  return advx_fused_update(p, pp, m, v, recv, mask, x0, eps, opt, s_next, v_buf, scratch, stream);
+  return fused_update_impl(p, pp, m, v, recv, mask, x0, eps, opt, s_next, v_buf, scratch, &c->dev, stream);
 }

@@ -7,6 +7,7 @@
 // separate mul / add unless fmaf is written explicitly.
 #pragma once
 #include "advx_device.h"
+#include "advx_comm.h"
 
 namespace advx {
 
@@ -555,22 +556,24 @@ __device__ inline float4 batch_column_sum(const void* __restrict__ g, int batch,
   return a;
 }
 
+// Only the float4 columns [q_lo, q_hi) are reduced: the gradient of the constant padding tiles
+// (llama32processor.py:344-346, phi3processor.py:232-235) is never read.
 __global__ void __launch_bounds__(kBlock) k_batch_reduce(const float* __restrict__ g, int batch, long long n,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, long long q_lo, long long q_hi) {
   __shared__ float4 part[kBlock / kWave][kWave];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  const long long q = (long long)blockIdx.x * kWave + lane;  // float4 column
+  const long long q = q_lo + (long long)blockIdx.x * kWave + lane;  // float4 column
   const long long n4 = n >> 2;
   float4 a = make_float4(0, 0, 0, 0);
-  if (q < n4) a = batch_column_sum(g, batch, n, q << 2, wid, kBlock / kWave);
+  if (q < q_hi) a = batch_column_sum(g, batch, n, q << 2, wid, kBlock / kWave);
   part[wid][lane] = a;
   __syncthreads();
-  if (wid == 0 && q < n4) {
+  if (wid == 0 && q < q_hi) {
     float4 t = f4add(f4add(f4add(part[0][lane], part[1][lane]), part[2][lane]), part[3][lane]);
     *reinterpret_cast<float4*>(out + (q << 2)) = t;
   }
   // scalar tail (n not a multiple of 4): last block, first threads
-  if (blockIdx.x == gridDim.x - 1) {
+  if (q_hi == n4 && blockIdx.x == gridDim.x - 1) {
     long long tail0 = n4 << 2;
     long long i = tail0 + threadIdx.x;
     if (i < n) {
@@ -815,22 +818,33 @@ __global__ void __launch_bounds__(kBlock) k_fused_bwd(const void* __restrict__ g
 // data-parallel tail of the pair: after the all-reduce of grad_p every rank runs this ONE
 // launch - mask, ||g|| partial, optimiser, and the preparation of the next forward (s, v) -
 // so that a DP step is fwd + bwd(grad only) + all-reduce + this (the norm reduction rides in
-// the next forward like in the single-GPU pair).
+// the next forward like in the single-GPU pair).  COMM: `grad` is the recv buffer of the peer
+// exchange; every block first waits until all peers have posted their slices (advx_comm.h).
+template <bool COMM>
 __global__ void __launch_bounds__(kBlock) k_fused_update(float* __restrict__ p, float* __restrict__ m,
                                                          float* __restrict__ v, float* __restrict__ grad,
                                                          const float* __restrict__ mask, const float* __restrict__ x0,
                                                          float eps, FusedGeom geo, OptScalars o,
                                                          float* __restrict__ s_next, float* __restrict__ v_buf,
                                                          double* __restrict__ norm_partials,
-                                                         FusedHeader* __restrict__ hdr) {
+                                                         FusedHeader* __restrict__ hdr, CommDev comm) {
   const long long n = 3LL * geo.plane;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   double nacc[1] = {0.0};
+  // state that does not depend on the exchange is fetched before the rendezvous
+  float mk = 0.f, pp0 = 0.f, xv0 = 0.f;
   if (i < n) {
-    float g = grad[i] * mask[i];
+    mk = mask[i];
+    pp0 = p[i];
+    xv0 = x0[i];
+  }
+  if (COMM) comm_wait_b(comm);
+  if (i < n) {
+    // COMM: recv is rewritten by the peers every step - read it past every cache
+    float g = (COMM ? comm_load1(grad + i) : grad[i]) * mk;
     grad[i] = g;
     nacc[0] = (double)g * (double)g;
-    float pp = p[i];
+    float pp = pp0;
     if (o.kind == 0) {
       float mm = m[i], vv = v[i];
       adamw_element(pp, mm, vv, g, o);
@@ -841,7 +855,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_update(float* __restrict__ p, 
       p[i] = pp;
     }
     const int c = (int)(i / geo.plane);
-    float sn = x0[i] + eps * tanhf(pp);
+    float sn = xv0 + eps * tanhf(pp);
     s_next[i] = sn;
     v_buf[i] = (sn - geo.mean[c]) / geo.stdv[c];
   }

@@ -278,11 +278,14 @@ int32_t advx_fused_step_flush(advx_plan* plan, int32_t parity, int32_t norm_rows
  *   - every rank creates ONE exchange segment in uncached device memory
  *     [flags | send | recv], exports its HIP IPC handle (64 bytes; the caller carries the
  *     handles between the processes) and maps the segments of all peers over xGMI;
- *   - advx_comm_allreduce = barrier -> reduce -> barrier, three launches with constant
- *     arguments: rank r sums the r-th slice of all send buffers IN RANK ORDER (every replica
- *     gets the same bits) and posts the sum into the recv buffer of every peer;
- *   - a barrier that does not complete within timeout_s sets a sticky error word and lets
- *     its kernel exit: a lost peer costs a wrong step, reported by advx_comm_status, never a
+ *   - advx_comm_allreduce = one reduce launch + the consumer's wait, all with constant
+ *     arguments: the reduce kernel meets its peers on entry ("send complete"), rank r sums the
+ *     r-th slice of all send buffers IN RANK ORDER (every replica gets the same bits), posts
+ *     the sum into the recv buffer of every peer and signals "slices posted"; whoever reads
+ *     recv waits for that signal first (advx_fused_bwd_dp: inside the update kernel; plain
+ *     callers: a one-block launch appended by advx_comm_allreduce);
+ *   - a wait that does not complete within timeout_s sets a sticky error word and lets its
+ *     kernel go on: a lost peer costs a wrong step, reported by advx_comm_status, never a
  *     hung device.
  * send / recv are device pointers owned by the comm (valid until advx_comm_destroy). */
 typedef struct advx_comm advx_comm;
