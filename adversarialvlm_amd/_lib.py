@@ -99,6 +99,7 @@ SIGNATURES = {
                                  C.c_double, _P]),
     "advx_profile_begin": (_I32, [_I32, _I32]),
     "advx_profile_end": (_I32, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "advx_quantise": (_I32, [_P, _P, _I64, _P]),
     "advx_tanh_fwd": (_I32, [_P, _F, _P, _I64, _P]),
     "advx_tanh_bwd": (_I32, [_P, _P, _F, _P, _I64, _P]),
     "advx_blur_fwd": (_I32, [_P, _I32, _I32, _I32, _F, _P, _P]),

@@ -128,7 +128,7 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
           # --- additions of this framework (defaults reproduce the reference behaviour)
           questions_file=None, test_questions_file=None, answers_file=None, optimizer="adamw", log_every=1,
           use_wandb=False, seed=0, base_path="./runs", components=None, return_engine=False,
-          generation_probe=False, resume_from=None, pixel_io="float32"):
+          generation_probe=False, resume_from=None, pixel_io="float32", resaved_loss_every=0):
     """pixel_io: "float32" hands the VLM fp32 pixel_values as the reference does; "model" lets
     the fused pair write them in model.dtype (the cast the vision tower's patch embedding applies
     first anyway) and read the half gradient directly - same numbers, half the traffic."""
@@ -245,6 +245,14 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
                    "resave_error_std": st["sigma_next"], "resave_error_mean": st["qerr_mean"],
                    "resave_error_l1": st["qerr_l1"], "adversarial_mean": st["x_mean"], "adversarial_std": st["x_std"],
                    "noise_sigma": st["sigma"], "sigma": sigma}
+            if resaved_loss_every > 0 and iteration % resaved_loss_every == 0:
+                # :375-379 - the loss of the image as a PNG of it would be seen (no noise); a whole
+                # extra VLM forward, so periodic here instead of every step
+                with torch.no_grad():
+                    probe_inputs = dict(inputs)
+                    probe_inputs["pixel_values"] = engine.resaved_pixel_values(local_batch)[0]
+                    rl = inputs_processor.get_loss(model(**probe_inputs).logits[:, :-1, :])
+                rec["loss_resaved"] = float(rl)
             history.append(rec)
             logger.log(rec)
         if rank == 0 and (iteration % save_steps == 0 or iteration == num_iterations - 1):  # :410-416 (Q10 naming)
@@ -314,6 +322,8 @@ def build_parser():
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--generation_probe", action="store_true", help="greedy-generate the test prompts at every save step")
     p.add_argument("--resume_from", type=str, default=None, help="state_iter_*.pt written by a previous run")
+    p.add_argument("--resaved_loss_every", type=int, default=0,
+                   help="log loss_resaved (the reference's second forward on the re-saved image) every N iterations; 0 = off")
     p.add_argument("--pixel_io", type=str, default="float32", choices=["float32", "model"],
                    help="dtype of pixel_values at the VLM boundary (model = the VLM's own half dtype)")
     return p

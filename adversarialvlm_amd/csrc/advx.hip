@@ -1123,6 +1123,12 @@ extern "C" int32_t advx_tanh_fwd(const float* p, float eps, float* x, int64_t n,
   LAUNCH_CHECK();
   return ADVX_OK;
 }
+extern "C" int32_t advx_quantise(const float* s, float* q, int64_t n, void* stream) {
+  REQUIRE(s && q && n > 0, ADVX_E_BADARG, "advx_quantise: bad argument");
+  hipLaunchKernelGGL(k_quantise, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, s, (long long)n, q);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
 extern "C" int32_t advx_tanh_bwd(const float* p, const float* gx, float eps, float* gp, int64_t n, void* stream) {
   REQUIRE(p && gx && gp && n > 0, ADVX_E_BADARG, "advx_tanh_bwd: bad argument");
   hipLaunchKernelGGL(k_tanh_bwd_plain, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, p, gx, eps, (long long)n, gp);

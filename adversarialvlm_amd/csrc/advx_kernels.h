@@ -264,6 +264,17 @@ __global__ void __launch_bounds__(kBlock) k_tanh_bwd(const float* __restrict__ p
   }
 }
 
+// the image as it comes back from the lossless PNG round trip of attack_model.py:368-371:
+// q = float(uint8(clamp(s,0,1)*255))/255 with C truncation (tensor2pil / pil_to_tensor,
+// llavaprocessor.py:151-161) - the arithmetic stat_accumulate applies, as an image
+__global__ void __launch_bounds__(kBlock) k_quantise(const float* __restrict__ s, long long n, float* __restrict__ q) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float cl = fminf(fmaxf(s[i], 0.0f), 1.0f);
+    q[i] = (float)(uint32_t)(cl * 255.0f) / 255.0f;
+  }
+}
+
 // plain tanh ops (unit tests / plugin-level autograd)
 __global__ void __launch_bounds__(kBlock) k_tanh_fwd(const float* __restrict__ p, float eps, long long n,
                                                      float* __restrict__ x) {

@@ -245,6 +245,16 @@ def profile_end():
     return {k: ((ms[i] / n[i]) if n[i] else 0.0, int(n[i])) for i, k in enumerate(("fwd", "bwd", "step"))}
 
 
+def quantise(s, out=None):
+    """The image after the lossless PNG round trip of attack_model.py:368-371 (uint8 truncation)."""
+    _require_cuda(s)
+    s = _f32c(s)
+    if out is None:
+        out = torch.empty_like(s)
+    L.check(L.load().advx_quantise(L.ptr(s), L.ptr(out), s.numel(), _stream(s)), "advx_quantise")
+    return out
+
+
 # ------------------------------------------------------------------------ single ops
 def tanh_fwd(p, epsilon):
     _require_cuda(p)

@@ -332,3 +332,16 @@ class PixelPGD:
     def image(self):
         """x0 + x of the most recent forward (what the reference checkpoints)."""
         return self.s
+
+    def resaved_pixel_values(self, batches):
+        """pixel_values of the re-saved image (attack_model.py:368-376): the image of the most
+        recent forward after the uint8 round trip, processed and repeated, WITHOUT noise - the
+        input of the reference's `loss_resaved` forward.  Log-only path, not pipelined."""
+        if not isinstance(batches, (list, tuple)):
+            batches = [batches] * len(self.plans)
+        q = ops.quantise(self.image())
+        outs = []
+        for pl, B in zip(self.plans, batches):
+            out = ops.emit(pl, q, B)
+            outs.append(out.view((B * pl.out_shape[0],) + pl.out_shape[1:]))
+        return outs

@@ -321,6 +321,11 @@ int32_t advx_fused_bwd_dp(advx_plan* plan, advx_comm* comm, const void* grad_out
 int32_t advx_profile_begin(int32_t max_launches, int32_t stride);
 int32_t advx_profile_end(double total_ms[3], int64_t launches[3]);
 
+/* The "re-saved" image of attack_model.py:366-371 (tensor2pil -> tmp.png -> pil_to_tensor; PNG is
+ * lossless, so the round trip IS the uint8 quantiser): q = float(uint8(clamp(s,0,1)*255))/255.
+ * Feeds the optional loss_resaved forward (:375-379) through advx_emit with no noise. */
+int32_t advx_quantise(const float* s, float* q, int64_t n, void* stream);
+
 /* ------------------------------------------------- single ops (unit tests)
  * Same kernels the calls above launch, exposed one by one. */
 int32_t advx_tanh_fwd(const float* p, float epsilon, float* x, int64_t n, void* stream);

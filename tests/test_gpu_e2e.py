@@ -171,3 +171,23 @@ def test_generation_probe_writes_reference_csv(tmp_path):
     assert rows[0] == ["question", "synthetic/tiny-llava"] and len(rows) == 1 + 8
     logged = [json.loads(l) for l in open(os.path.join(tmp, "probe", "metrics.jsonl"))]
     assert any("test_target_acc" in r for r in logged)
+
+
+def test_loss_resaved_is_the_forward_of_the_png_image(tmp_path):
+    """SURVEY a16 (attack_model.py:366-379): the optional second forward on the image as its PNG
+    would be read back - quantised, processed, repeated, NO noise.  The logged value must equal
+    the model's loss on pixel_values built by the oracle from the checkpointed image."""
+    from adversarialvlm_amd import attack_model
+    from oracle import pixel_ops as P
+    from oracle.processors import LlavaOracle
+    tmp = str(tmp_path)
+    eng, hist = attack_model.train(**_kw(tmp, "rs", 3, resaved_loss_every=2, return_engine=True))
+    assert "loss_resaved" in hist[0] and "loss_resaved" in hist[2] and "loss_resaved" not in hist[1]
+    assert all(np.isfinite(h["loss_resaved"]) for h in (hist[0], hist[2]))
+    # the engine's re-saved pixel_values against the oracle's processor on the quantised image
+    img = eng.image().cpu()
+    want = LlavaOracle(img.shape[1], img.shape[2]).process(P.quantise(img))["pixel_values"].repeat(4, 1, 1, 1)
+    got = eng.resaved_pixel_values(4)[0].cpu()
+    assert got.shape == want.shape and float((got - want).abs().max()) < 2e-6
+    # a noiseless forward of (nearly) the same image: close to, but not the same as, the training loss
+    assert abs(hist[2]["loss_resaved"] - hist[2]["ce_loss"]) < 0.5

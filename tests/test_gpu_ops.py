@@ -176,3 +176,16 @@ def test_image_fit_grad_golden(ops, dev):
     grad = torch.empty_like(p)
     ops.image_bwd(p, s, torch.zeros_like(p), float(g["fit_eps"]), 1.0, grad, scratch)
     assert rel_err(grad.cpu(), g["fit_p_grad"]) < TIGHT
+
+
+def test_quantise_is_uint8_truncation():
+    """advx_quantise = tensor2pil -> PNG -> pil_to_tensor (attack_model.py:368-371), bit-exact,
+    including the 256 lattice points and values outside [0, 1]."""
+    from adversarialvlm_amd import ops
+    from oracle import pixel_ops as P
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(5)
+    s = torch.cat([torch.rand(3 * 40 * 40, generator=gen) * 1.4 - 0.2, torch.arange(256, dtype=torch.float32) / 255,
+                   torch.tensor([-1.0, 0.0, 1.0, 2.0, 0.999999, 1e-9])])
+    got = ops.quantise(s.to(dev)).cpu()
+    assert torch.equal(got, P.quantise(s))
