@@ -26,10 +26,16 @@ def build_library(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libadvx_hip.so cannot be built (there is no CPU fallback)")
-    cmd = [hipcc] + FLAGS + ["-o", OUT] + SOURCES
+    # compile beside the target and rename: concurrent builders (one rank per GPU) can never
+    # leave a half-written library behind, and a process that has the old one mapped keeps it
+    tmp = f"{OUT}.{os.getpid()}.tmp"
+    cmd = [hipcc] + FLAGS + ["-o", tmp] + SOURCES
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, OUT)
     return OUT

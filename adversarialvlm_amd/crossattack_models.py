@@ -48,7 +48,7 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
           attack_norm=0.5, use_gaussian_blur=False, gblur_kernel_size=5, use_local_crop=False, crop_scale_min=0.6,
           crop_scale_max=1.0, crop_ratio_min=0.75, crop_ratio_max=1.33,
           questions_file=None, test_questions_file=None, answers_file=None, log_every=1, use_wandb=False, seed=0,
-          base_path="./runs", return_engine=False):
+          base_path="./runs", return_engine=False, resaved_loss_every=0):
     if clamp_method != "tanh":
         raise NotImplementedError("Clamping method except tanh are not implemented yet.")
     if mask_type == "random_square":
@@ -151,9 +151,10 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
         if use_local_crop:
             crop = random_resized_crop_params(H, W, (crop_scale_min, crop_scale_max), (crop_ratio_min, crop_ratio_max))
         pvs = engine.forward(local_batch, blur_sigma=blur_sigma, crop=crop)                 # :329-362 (HIP)
-        grads, losses = [], []
+        grads, losses, step_inputs = [], [], []
         for k, (model, ip, pv) in enumerate(zip(models, inputs_processors, pvs)):           # :352-384
             inputs = ip.get_inputs_train()
+            step_inputs.append(inputs)
             pv.requires_grad_(True)
             inputs["pixel_values"] = pv
             logits = model(**inputs).logits[:, :-1, :]
@@ -172,6 +173,17 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
             for k, i in enumerate(my_models):
                 rec[f"loss_{i}_{model_names[i].replace('/', '_')}"] = float(losses[k]) * model_weights[i] + st["img_loss"]
             rec["loss_per_iteration"] = float(np.mean([v for kk, v in rec.items() if kk.startswith("loss_")]))
+            if resaved_loss_every > 0 and iteration % resaved_loss_every == 0:
+                # :434-445 - every model's loss on the image as its PNG would be read back (no noise),
+                # averaged; one extra forward per model, so periodic here
+                with torch.no_grad():
+                    resaved = []
+                    for model, ip, inputs, pv in zip(models, inputs_processors, step_inputs,
+                                                     engine.resaved_pixel_values(local_batch)):
+                        probe_inputs = dict(inputs)
+                        probe_inputs["pixel_values"] = pv
+                        resaved.append(float(ip.get_loss(model(**probe_inputs).logits[:, :-1, :])))
+                rec["loss_resaved"] = float(np.mean(resaved))
             history.append(rec)
             logger.log(rec)
         if rank == 0 and (iteration % save_steps == 0 or iteration == num_iterations - 1):
@@ -230,6 +242,8 @@ def build_parser():
     p.add_argument("--log_every", type=int, default=1)
     p.add_argument("--use_wandb", action="store_true")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--resaved_loss_every", type=int, default=0,
+                   help="log loss_resaved (every model's forward on the re-saved image) every N iterations; 0 = off")
     return p
 
 

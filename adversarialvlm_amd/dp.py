@@ -72,7 +72,7 @@ class PeerExchange:
 
     MEM_NAMES = {1: "uncached", 2: "fine-grained", 3: "device"}
 
-    def __init__(self, floats, device, group=None, mem_kind=0, timeout_s=2.0):
+    def __init__(self, floats, device, group=None, mem_kind=0, timeout_s=5.0):
         import ctypes as C
 
         from . import _lib as L
@@ -189,7 +189,7 @@ def probe_peer_exchange(ex, group=None, rounds=3, seed=1234):
     return ok
 
 
-def make_exchange(floats, device, group=None, transport="auto", timeout_s=2.0):
+def make_exchange(floats, device, group=None, transport="auto", timeout_s=5.0):
     """transport: "rccl" -> None (torch.distributed all-reduce); "peer" -> PeerExchange or an
     error; "auto" -> PeerExchange if it can be set up AND passes the probe, else None."""
     if transport not in ("auto", "peer", "rccl"):

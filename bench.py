@@ -127,7 +127,10 @@ def main():
             torch.cuda.synchronize()
 
     from adversarialvlm_amd.build import build_library
-    build_library()
+    if rank == 0:
+        build_library()              # no-op when __graft_entry__.build() has run; one builder, not N
+    if world > 1:
+        torch.distributed.barrier()
     from adversarialvlm_amd.pgd import PixelPGD
     from adversarialvlm_amd.plan import Plan
 
