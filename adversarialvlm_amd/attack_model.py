@@ -128,7 +128,8 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
           # --- additions of this framework (defaults reproduce the reference behaviour)
           questions_file=None, test_questions_file=None, answers_file=None, optimizer="adamw", log_every=1,
           use_wandb=False, seed=0, base_path="./runs", components=None, return_engine=False,
-          generation_probe=False, resume_from=None, pixel_io="float32", resaved_loss_every=0):
+          generation_probe=False, resume_from=None, pixel_io="float32", resaved_loss_every=0,
+          noise_on_padding=True):
     """pixel_io: "float32" hands the VLM fp32 pixel_values as the reference does; "model" lets
     the fused pair write them in model.dtype (the cast the vision tower's patch embedding applies
     first anyway) and read the half gradient directly - same numbers, half the traffic."""
@@ -186,7 +187,8 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
                       scheduler_step_size=scheduler_step_size, scheduler_gamma=scheduler_gamma,
                       grad_accum_steps=grad_accum_steps, blur_kernel=gblur_kernel_size if use_gaussian_blur else None,
                       use_crop=use_local_crop, optimizer=optimizer, seed=seed + 7919 * rank,
-                      process_group=torch.distributed.group.WORLD if world > 1 else None)
+                      process_group=torch.distributed.group.WORLD if world > 1 else None,
+                      noise_on_padding=noise_on_padding)
     if pixel_io == "model" and engine.mode == "pair":
         model_dtype = next(model.parameters()).dtype
         if model_dtype in IO_DTYPES:
@@ -324,6 +326,9 @@ def build_parser():
     p.add_argument("--resume_from", type=str, default=None, help="state_iter_*.pt written by a previous run")
     p.add_argument("--resaved_loss_every", type=int, default=0,
                    help="log loss_resaved (the reference's second forward on the re-saved image) every N iterations; 0 = off")
+    p.add_argument("--no_noise_on_padding", dest="noise_on_padding", action="store_false",
+                   help="keep the constant padding tiles of Mllama / Phi-3.5 exact zeros instead of adding noise to them "
+                        "as the reference does (both models mask those tiles out)")
     p.add_argument("--pixel_io", type=str, default="float32", choices=["float32", "model"],
                    help="dtype of pixel_values at the VLM boundary (model = the VLM's own half dtype)")
     return p

@@ -48,7 +48,7 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
           attack_norm=0.5, use_gaussian_blur=False, gblur_kernel_size=5, use_local_crop=False, crop_scale_min=0.6,
           crop_scale_max=1.0, crop_ratio_min=0.75, crop_ratio_max=1.33,
           questions_file=None, test_questions_file=None, answers_file=None, log_every=1, use_wandb=False, seed=0,
-          base_path="./runs", return_engine=False, resaved_loss_every=0):
+          base_path="./runs", return_engine=False, resaved_loss_every=0, noise_on_padding=True):
     if clamp_method != "tanh":
         raise NotImplementedError("Clamping method except tanh are not implemented yet.")
     if mask_type == "random_square":
@@ -124,7 +124,8 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
                       grad_accum_steps=grad_accum_steps, blur_kernel=gblur_kernel_size if use_gaussian_blur else None,
                       use_crop=use_local_crop, model_weights=[model_weights[i] for i in my_models], cross_mode=True,
                       seed=seed + 7919 * rank, allow_fused=False,
-                      process_group=torch.distributed.group.WORLD if world > 1 else None, grad_prescale=prescale)
+                      process_group=torch.distributed.group.WORLD if world > 1 else None, grad_prescale=prescale,
+                      noise_on_padding=noise_on_padding)
     if world > 1:
         # every rank sees ONE of the n_models image-fit terms; scaled by 1/group_size the SUM
         # over all ranks restores "once per model"
@@ -242,6 +243,8 @@ def build_parser():
     p.add_argument("--log_every", type=int, default=1)
     p.add_argument("--use_wandb", action="store_true")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--no_noise_on_padding", dest="noise_on_padding", action="store_false",
+                   help="keep the constant padding tiles of Mllama / Phi-3.5 exact zeros (the reference adds noise there)")
     p.add_argument("--resaved_loss_every", type=int, default=0,
                    help="log loss_resaved (every model's forward on the re-saved image) every N iterations; 0 = off")
     return p

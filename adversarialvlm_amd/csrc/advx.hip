@@ -549,10 +549,31 @@ static void emit_slices(long long n4, int batch, int* gx, int* slices, int* b_pe
   *b_per_slice = bps;
 }
 
-extern "C" int32_t advx_emit(advx_plan* p, const float* argument, int32_t batch, const float* sigma_dev,
-                             const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset, float* out,
-                             float* ws, int64_t ws_floats, void* stream) {
+// span of flat indices the emits of a plan cover; what lies outside is constant padding
+static void plan_live_range(const advx_plan* p, long long* lo, long long* hi) {
+  *lo = p->info.out_numel;
+  *hi = 0;
+  for (int k = 0; k < p->dplan.n_emit; ++k) {
+    const DEmit& e = p->dplan.e[k];
+    *lo = std::min(*lo, e.out_begin);
+    *hi = std::max(*hi, e.out_begin + e.out_count);   // out_count includes the temporal copies (QWEN)
+  }
+}
+
+extern "C" int32_t advx_plan_live_range(const advx_plan* p, int64_t* lo, int64_t* hi) {
+  REQUIRE(p && lo && hi, ADVX_E_BADARG, "advx_plan_live_range: null argument");
+  long long a, b;
+  plan_live_range(p, &a, &b);
+  *lo = a;
+  *hi = b;
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_emit_ex(advx_plan* p, const float* argument, int32_t batch, const float* sigma_dev,
+                                const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset, float* out,
+                                float* ws, int64_t ws_floats, int32_t pad_mode, void* stream) {
   REQUIRE(p && argument && out && ws, ADVX_E_BADARG, "advx_emit: null argument");
+  REQUIRE(pad_mode == ADVX_PAD_NOISE || pad_mode == ADVX_PAD_KEEP, ADVX_E_BADARG, "advx_emit: unknown pad_mode");
   REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_emit: batch out of range");
   REQUIRE(ws_floats >= p->info.workspace_floats, ADVX_E_SHAPE, "advx_emit: workspace too small");
   REQUIRE(aligned16(out) && aligned16(ws) && (!unit_noise || aligned16(unit_noise)), ADVX_E_BADARG,
@@ -571,18 +592,30 @@ extern "C" int32_t advx_emit(advx_plan* p, const float* argument, int32_t batch,
                        ws + p->dplan.canvas_off[k]);
     LAUNCH_CHECK();
   }
-  long long n4 = (p->info.out_numel + 3) >> 2;
+  const long long n4 = (p->info.out_numel + 3) >> 2;
+  long long q_lo = 0, q_hi = n4, live_lo = 0, live_hi = n4 << 2;
+  if (pad_mode == ADVX_PAD_KEEP) {
+    plan_live_range(p, &live_lo, &live_hi);
+    q_lo = live_lo >> 2;
+    q_hi = (live_hi + 3) >> 2;
+  }
   int gx, slices, bps;
-  emit_slices(n4, batch, &gx, &slices, &bps);
+  emit_slices(q_hi - q_lo, batch, &gx, &slices, &bps);
   dim3 grid(gx, slices);
-  if (noise == 0)
-    hipLaunchKernelGGL(k_emit<0>, grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, offset, out);
-  else if (noise == 1)
-    hipLaunchKernelGGL(k_emit<1>, grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, offset, out);
-  else
-    hipLaunchKernelGGL(k_emit<2>, grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, offset, out);
+#define ADVX_EMIT(N)                                                                                                \
+  hipLaunchKernelGGL(k_emit<N>, grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, offset, \
+                     out, q_lo, q_hi, live_lo, live_hi)
+  if (noise == 0) ADVX_EMIT(0); else if (noise == 1) ADVX_EMIT(1); else ADVX_EMIT(2);
+#undef ADVX_EMIT
   LAUNCH_CHECK();
   return ADVX_OK;
+}
+
+extern "C" int32_t advx_emit(advx_plan* p, const float* argument, int32_t batch, const float* sigma_dev,
+                             const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset, float* out,
+                             float* ws, int64_t ws_floats, void* stream) {
+  return advx_emit_ex(p, argument, batch, sigma_dev, unit_noise, use_philox, seed, offset, out, ws, ws_floats, ADVX_PAD_NOISE,
+                      stream);
 }
 
 // [live_lo, live_hi): flat indices of a sample whose gradient is needed (defaults: all of it)
@@ -614,12 +647,8 @@ extern "C" int32_t advx_collect(advx_plan* p, const float* grad_out, int32_t bat
   const float* gsum = grad_out;
   if (batch > 1) {
     // the emits cover [lo, hi); what lies outside is constant padding whose gradient goes nowhere
-    long long lo = p->info.out_numel, hi = 0;
-    for (int k = 0; k < p->dplan.n_emit; ++k) {
-      const DEmit& e = p->dplan.e[k];
-      lo = std::min(lo, e.out_begin);
-      hi = std::max(hi, e.out_begin + e.out_count);   // out_count includes the temporal copies (QWEN)
-    }
+    long long lo, hi;
+    plan_live_range(p, &lo, &hi);
     rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st, lo, hi);
     if (rc) return rc;
     gsum = ws + p->dplan.gsum_off;

@@ -460,15 +460,22 @@ template <int NOISE>
 __global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restrict__ ws, int batch, int b_per_slice,
                                                  const float* __restrict__ sigma_dev, const float* __restrict__ unit_noise,
                                                  unsigned long long seed, unsigned long long offset,
-                                                 float* __restrict__ out) {
+                                                 float* __restrict__ out, long long q_lo, long long q_hi,
+                                                 long long live_lo, long long live_hi) {
+  // Only the float4 columns [q_lo, q_hi) are written.  The default is all of them, noise
+  // included on the constant padding tiles, as the reference does (attack_model.py:320 adds
+  // randn_like to the WHOLE tensor).  A caller that keeps `out` across steps with its padding
+  // zeroed once passes the columns the emits cover and [live_lo, live_hi) as their element
+  // range: elements outside it inside a boundary column are written as exact zeros.
   const long long n = pl.out_numel;
   const long long n4 = (n + 3) >> 2;
-  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= n4) return;
+  const long long q = q_lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= q_hi) return;
   const long long i0 = q << 2;
   float v[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? emit_value(pl, ws, i0 + k) : 0.0f;
+  const bool edge = (i0 < live_lo) || (i0 + 4 > live_hi);
   const float sigma = (NOISE != 0) ? sigma_dev[0] : 0.0f;
   const int b0 = blockIdx.y * b_per_slice;
   const int b1 = min(batch, b0 + b_per_slice);
@@ -486,6 +493,11 @@ __global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restri
     } else if (NOISE == 2) {
       float4 z = philox_normal4((unsigned long long)b * (unsigned long long)n4 + (unsigned long long)q, offset, seed);
       o[0] = v[0] + z.x * sigma; o[1] = v[1] + z.y * sigma; o[2] = v[2] + z.z * sigma; o[3] = v[3] + z.w * sigma;
+    }
+    if (edge) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i0 + k < live_lo || i0 + k >= live_hi) o[k] = 0.0f;
     }
     if (vec) {
       *reinterpret_cast<float4*>(out + (size_t)b * n + i0) = make_float4(o[0], o[1], o[2], o[3]);

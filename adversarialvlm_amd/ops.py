@@ -34,16 +34,20 @@ def _crop_arg(crop):
 
 
 # ------------------------------------------------------------------- processor level
-def emit(plan, argument, batch, sigma_dev=None, unit_noise=None, philox=None, workspace=None, out=None):
+def emit(plan, argument, batch, sigma_dev=None, unit_noise=None, philox=None, workspace=None, out=None, keep_padding=False):
     """process(argument) -> repeat(batch) -> + sigma*noise   (attack_model.py:314-321).
 
     philox = (seed, offset) switches on the in-kernel generator; unit_noise is the parity
-    mode (N(0,1) tensor supplied by the caller)."""
+    mode (N(0,1) tensor supplied by the caller).  keep_padding: `out` is a buffer the caller
+    keeps across steps whose padding tiles are already zero - only the covered elements are
+    written (ADVX_PAD_KEEP)."""
     _require_cuda(argument)
     argument = _f32c(argument)
     dev = argument.device
     if workspace is None:
         workspace = torch.empty(plan.workspace_floats, dtype=torch.float32, device=dev)
+    if keep_padding and (out is None or out.numel() != batch * plan.out_numel):
+        raise L.AdvxError("keep_padding needs the caller's persistent [batch, out_numel] buffer")
     if out is None:
         out = torch.empty((batch, plan.out_numel), dtype=torch.float32, device=dev)
     seed, offset = (philox if philox is not None else (0, 0))
@@ -51,9 +55,9 @@ def emit(plan, argument, batch, sigma_dev=None, unit_noise=None, philox=None, wo
         unit_noise = _f32c(unit_noise)
         if unit_noise.numel() != batch * plan.out_numel:
             raise L.AdvxError("unit_noise has the wrong number of elements")
-    L.check(L.load().advx_emit(plan.handle, L.ptr(argument), int(batch), L.ptr(sigma_dev), L.ptr(unit_noise),
-                               int(philox is not None), int(seed), int(offset), L.ptr(out), L.ptr(workspace),
-                               int(workspace.numel()), _stream(argument)), "advx_emit")
+    L.check(L.load().advx_emit_ex(plan.handle, L.ptr(argument), int(batch), L.ptr(sigma_dev), L.ptr(unit_noise),
+                                  int(philox is not None), int(seed), int(offset), L.ptr(out), L.ptr(workspace),
+                                  int(workspace.numel()), 1 if keep_padding else 0, _stream(argument)), "advx_emit_ex")
     return out
 
 

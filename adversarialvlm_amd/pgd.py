@@ -32,14 +32,19 @@ class PixelPGD:
                  scheduler_gamma=1.0, grad_accum_steps=1, blur_kernel=None, use_crop=False, model_weights=None,
                  optimizer="adamw", cross_mode=False, betas=(0.9, 0.999), adam_eps=1e-8, weight_decay=1e-2, seed=0,
                  process_group=None, allow_fused=True, fused_mode="auto", grad_prescale=None, force_exchange=False,
-                 io_dtype=torch.float32, exchange_transport="auto"):
+                 io_dtype=torch.float32, exchange_transport="auto", noise_on_padding=True):
         """io_dtype: dtype of the pixel_values handed to the VLM by the fused pair.  float32 is
         the reference's own boundary; float16 / bfloat16 emit the tensor already cast to the
         model's dtype (the cast the model's first layer would apply) and let backward_update
         read the half gradient directly.
         exchange_transport: how the data-parallel all-reduce of the image gradient travels -
         "peer" (advx_comm_*: IPC-mapped segments over xGMI, in-library kernels), "rccl"
-        (torch.distributed) or "auto" (peer if it sets up and passes its self-test here)."""
+        (torch.distributed) or "auto" (peer if it sets up and passes its self-test here).
+        noise_on_padding: True = the reference's tensor, noise also on the constant padding tiles
+        of Mllama / Phi-3.5 (which both models mask out); False = those tiles stay exact zeros in
+        pixel_values buffers the engine keeps across steps and rewrites only where an image is
+        (no generator work and no traffic for 3/4 resp. 2/7 of the tensor; the tensor returned by
+        forward() is then only valid until the next forward())."""
         if not x0.is_cuda:
             raise L.AdvxError("PixelPGD needs x0 on a ROCm device (there is no CPU fallback)")
         if not isinstance(plans, (list, tuple)):
@@ -130,6 +135,8 @@ class PixelPGD:
             self.garg = torch.empty_like(self.x0)
             self.img_scratch = ops.image_scratch(H, W, blur_kernel or 0, dev)
             self.workspaces = [torch.empty(pl.workspace_floats, dtype=torch.float32, device=dev) for pl in self.plans]
+            self.noise_on_padding = bool(noise_on_padding)
+            self._outs = [None] * len(self.plans)     # persistent pixel_values (noise_on_padding=False)
         self._last = None
         for pl in self.plans:
             pl.upload()
@@ -206,7 +213,14 @@ class PixelPGD:
         sigma = self.stats[L.STAT_SIGMA:L.STAT_SIGMA + 1]
         for i, (pl, B, z) in enumerate(zip(self.plans, batches, unit_noises)):
             ph = None if (z is not None or not use_philox) else (self.seed, self.iteration * len(self.plans) + i)
-            out = ops.emit(pl, arg, B, sigma_dev=sigma, unit_noise=z, philox=ph, workspace=self.workspaces[i])
+            keep = (not self.noise_on_padding) and z is None
+            buf = None
+            if keep:
+                if self._outs[i] is None or self._outs[i].shape[0] != B:
+                    self._outs[i] = torch.zeros((B, pl.out_numel), dtype=torch.float32, device=self.p.device)
+                buf = self._outs[i]
+            out = ops.emit(pl, arg, B, sigma_dev=sigma, unit_noise=z, philox=ph, workspace=self.workspaces[i], out=buf,
+                           keep_padding=keep)
             outs.append(out.view((B * pl.out_shape[0],) + pl.out_shape[1:]))
         self._last = dict(batches=list(batches), blur=blur, crop=crop)
         return outs

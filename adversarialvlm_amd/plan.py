@@ -84,6 +84,12 @@ class Plan:
     def fused_supported(self):
         return bool(L.load().advx_fused_supported(self._h))
 
+    def live_range(self):
+        """[lo, hi): flat indices of one sample that an image reaches; the rest is constant padding."""
+        lo, hi = C.c_int64(), C.c_int64()
+        L.check(L.load().advx_plan_live_range(self._h, C.byref(lo), C.byref(hi)), "advx_plan_live_range")
+        return int(lo.value), int(hi.value)
+
     def upload(self, stream=None):
         L.check(L.load().advx_plan_upload(self._h, stream), "advx_plan_upload")
 

@@ -130,6 +130,9 @@ int32_t advx_plan_taps(const advx_plan* plan, int32_t stage, int32_t axis, int32
  * (c, y, x) of `stage` is written to; returns how many (0, 1 or 2) in *n_idx. */
 int32_t advx_plan_out_index(const advx_plan* plan, int32_t stage, int32_t c, int32_t y, int32_t x,
                             int32_t* n_idx, int64_t idx[2]);
+/* [lo, hi): flat indices of one sample that the plan's emits cover.  What lies outside is the
+ * constant padding (zero tiles) of llama32processor.py:344-346 / phi3processor.py:232-235. */
+int32_t advx_plan_live_range(const advx_plan* plan, int64_t* lo, int64_t* hi);
 /* Host tap computation for an arbitrary 1-D resize (tests; also the crop window's tables). */
 int32_t advx_taps_compute(int32_t mode, int32_t in_size, int32_t out_size, int32_t transposed,
                           int32_t* n, int32_t* stride, int32_t* start, int32_t* count, float* weight);
@@ -148,6 +151,21 @@ int32_t advx_taps_compute(int32_t mode, int32_t in_size, int32_t out_size, int32
 int32_t advx_emit(advx_plan* plan, const float* argument, int32_t batch, const float* sigma_dev,
                   const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset,
                   float* out, float* workspace, int64_t workspace_floats, void* stream);
+/* The constant padding tiles of Mllama / Phi-3.5 (llama32processor.py:344-346,
+ * phi3processor.py:232-235) are 3/4 resp. 2/7 of `out`.  The reference adds noise to them too
+ * (randn_like of the whole tensor, attack_model.py:320) although both models mask those tiles
+ * out, so neither loss nor gradient can see them.
+ *   ADVX_PAD_NOISE : advx_emit's behaviour - the whole tensor is written, padding = 0 + noise.
+ *   ADVX_PAD_KEEP  : only the elements the plan's emits cover are written; the caller keeps
+ *                    `out` across steps and has zeroed its padding once (padding stays exactly
+ *                    0, what process() itself returns).  Noise of the covered elements is the
+ *                    same as with ADVX_PAD_NOISE (same counters). */
+#define ADVX_PAD_NOISE 0
+#define ADVX_PAD_KEEP 1
+int32_t advx_emit_ex(advx_plan* plan, const float* argument, int32_t batch, const float* sigma_dev,
+                     const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset,
+                     float* out, float* workspace, int64_t workspace_floats, int32_t pad_mode,
+                     void* stream);
 int32_t advx_collect(advx_plan* plan, const float* grad_out, int32_t batch, float* grad_argument,
                      int32_t accumulate, float* workspace, int64_t workspace_floats, void* stream);
 

@@ -234,3 +234,37 @@ def test_half_io_needs_the_pair(dev):
         PixelPGD(x0, [Plan.llava(64, 64, 32, 32)], io_dtype=torch.float16)          # generic chain
     with pytest.raises(L.AdvxError):
         PixelPGD(x0, [Plan.llava(64, 64, 64, 64)], io_dtype=torch.float64)
+
+
+@pytest.mark.parametrize("kind", ["mllama", "phi3"])
+def test_padding_tiles_kept_zero_is_the_same_attack(dev, kind):
+    """noise_on_padding=False: the constant padding tiles (llama32processor.py:344-346,
+    phi3processor.py:232-235) stay exact zeros in a buffer kept across steps; every element an
+    image reaches carries the same value AND the same noise as in the reference-shaped tensor,
+    and - the gradient of padding going nowhere - p evolves bit-identically."""
+    from adversarialvlm_amd.pgd import PixelPGD
+    Plan = _plans()
+    # mllama: an image that fits ONE 32-pixel tile of the four -> three padding tiles
+    H, W, B = (30, 27, 3) if kind == "mllama" else (70, 100, 3)
+    x0 = torch.rand(3, H, W, generator=torch.Generator().manual_seed(21)).to(dev)
+    mk = (lambda: Plan.mllama(H, W, tile=32)) if kind == "mllama" else (lambda: Plan.phi3(H, W))
+    engines = [PixelPGD(x0, [mk()], seed=5, noise_on_padding=flag) for flag in (True, False)]
+    pl = engines[0].plans[0]
+    gen = torch.Generator().manual_seed(22)
+    pad_seen = False
+    for t in range(3):
+        outs = [e.forward(B)[0].reshape(B, pl.out_numel) for e in engines]
+        ref, kept = outs
+        live = kept != 0
+        # padding: exact zeros when kept, pure noise in the reference-shaped tensor
+        assert torch.equal(ref[live], kept[live])
+        pad = ~live
+        if pad.any():
+            pad_seen = True
+            assert float(ref[pad].abs().max()) < 1e-1          # sigma * N(0,1) around zero
+        g = (torch.randn(B, pl.out_numel, generator=gen) * 0.01).to(dev)
+        for e in engines:
+            e.backward_update([g])
+        assert torch.equal(engines[0].p, engines[1].p)
+    assert pad_seen
+    assert engines[0].stats_dict() == engines[1].stats_dict()
