@@ -472,6 +472,9 @@ extern "C" int32_t advx_plan_out_index(const advx_plan* p, int32_t stage, int32_
     const DEmit& e = p->dplan.e[k];
     if (e.stage != stage) continue;
     long long i0 = emit_index(e, c, y, x);
+    // the backward kernel addresses the same element through the separable form of the map
+    REQUIRE(i0 == e.out_begin + (long long)emit_rowpart(e, c, y) + (long long)emit_colpart(e, x), ADVX_E_SHAPE,
+            "advx_plan_out_index: separable layout map disagrees with emit_index");
     for (int t = 0; t < emit_copies(e) && *n_idx < 2; ++t) idx[(*n_idx)++] = i0 + t * emit_copy_stride(e);
   }
   return ADVX_OK;

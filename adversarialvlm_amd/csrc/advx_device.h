@@ -89,6 +89,36 @@ __device__ __host__ inline long long emit_index(const DEmit& e, int c, int y, in
   return (long long)(base + row * row_len + col);
 }
 
+// emit_index is separable: emit_index(e,c,y,x) == out_begin + emit_rowpart(e,c,y) + emit_colpart(e,x).
+// A thread that visits a window of rows and columns pays the divisions once per row / column
+// instead of once per element (k_stage_bwd).
+__device__ __host__ inline unsigned emit_rowpart(const DEmit& e, int c, int y) {
+  if (e.kind == ADVX_EMIT_PLAIN) return ((unsigned)c * (unsigned)e.can_h + (unsigned)y) * (unsigned)e.can_w;
+  if (e.kind == ADVX_EMIT_TILES) {
+    unsigned T = (unsigned)e.tile;
+    unsigned tyi = (unsigned)y / T, ty = (unsigned)y - tyi * T;
+    return ((tyi * (unsigned)e.tiles_w * 3u + (unsigned)c) * T + ty) * T;
+  }
+  unsigned P = (unsigned)e.patch, M = (unsigned)e.merge;
+  unsigned gy = (unsigned)y / P, ph = (unsigned)y - gy * P;
+  unsigned by = gy / M, mh = gy - by * M;
+  unsigned row_len = 3u * (unsigned)e.temporal * P * P;
+  return ((by * ((unsigned)e.grid_w / M)) * M * M + mh * M) * row_len + ((unsigned)c * (unsigned)e.temporal * P + ph) * P;
+}
+__device__ __host__ inline unsigned emit_colpart(const DEmit& e, int x) {
+  if (e.kind == ADVX_EMIT_PLAIN) return (unsigned)x;
+  if (e.kind == ADVX_EMIT_TILES) {
+    unsigned T = (unsigned)e.tile;
+    unsigned txi = (unsigned)x / T, tx = (unsigned)x - txi * T;
+    return txi * 3u * T * T + tx;
+  }
+  unsigned P = (unsigned)e.patch, M = (unsigned)e.merge;
+  unsigned gx = (unsigned)x / P, pw = (unsigned)x - gx * P;
+  unsigned bx = gx / M, mw = gx - bx * M;
+  unsigned row_len = 3u * (unsigned)e.temporal * P * P;
+  return (bx * M * M + mw) * row_len + pw;
+}
+
 // stride between the temporal copies of one canvas element (QWEN), number of copies
 __device__ __host__ inline int emit_copies(const DEmit& e) { return e.kind == ADVX_EMIT_QWEN ? e.temporal : 1; }
 __device__ __host__ inline long long emit_copy_stride(const DEmit& e) { return (long long)e.patch * e.patch; }

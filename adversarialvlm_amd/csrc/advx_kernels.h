@@ -388,6 +388,8 @@ __device__ inline float canvas_grad_at(const DPlan& pl, int stage, const float* 
   return g;
 }
 
+constexpr int kBwdCols = 8;   // widest window the separable index path of k_stage_bwd keeps in registers
+
 // one thread per SOURCE element: transposed-tap gather (no atomics)
 __global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, DPlan pl, int stage, const float* __restrict__ gsum,
                                                       const float* __restrict__ dgrad, float* __restrict__ gsrc,
@@ -403,11 +405,50 @@ __global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, DPlan pl, int s
     const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
     const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
     float v = 0.0f;
-    for (int a = 0; a < oyc; ++a) {
-      float h = 0.0f;
-      for (int b = 0; b < oxc; ++b)
-        h += wx[b] * canvas_grad_at(pl, stage, gsum, dgrad, st.can_h, st.can_w, c, st.off_y + oy + a, st.off_x + ox + b);
-      v += wy[a] * h;
+    if (oxc <= kBwdCols) {
+      // the layout map is separable (row part + column part): the divisions are paid once per
+      // visited row / column of the window instead of once per element; same summation order
+      // as canvas_grad_at
+      unsigned colp[2][kBwdCols];
+      bool live[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        live[k] = (k < pl.n_emit) && (pl.e[k].stage == stage);
+#pragma unroll
+        for (int b = 0; b < kBwdCols; ++b)
+          colp[k][b] = (live[k] && b < oxc) ? (unsigned)pl.e[k].out_begin + emit_colpart(pl.e[k], st.off_x + ox + b) : 0u;
+      }
+      for (int a = 0; a < oyc; ++a) {
+        const int y = st.off_y + oy + a;
+        unsigned rowp[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) rowp[k] = live[k] ? emit_rowpart(pl.e[k], c, y) : 0u;
+        float h = 0.0f;
+#pragma unroll
+        for (int b = 0; b < kBwdCols; ++b) {
+          if (b < oxc) {
+            float g = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              if (!live[k]) continue;
+              const unsigned idx = rowp[k] + colp[k][b];
+              const int copies = emit_copies(pl.e[k]);
+              const unsigned cs = (unsigned)emit_copy_stride(pl.e[k]);
+              for (int t = 0; t < copies; ++t) g += gsum[idx + (unsigned)t * cs];
+            }
+            if (dgrad != nullptr) g += dgrad[((size_t)c * st.can_h + y) * st.can_w + st.off_x + ox + b];
+            h += wx[b] * g;
+          }
+        }
+        v += wy[a] * h;
+      }
+    } else {
+      for (int a = 0; a < oyc; ++a) {
+        float h = 0.0f;
+        for (int b = 0; b < oxc; ++b)
+          h += wx[b] * canvas_grad_at(pl, stage, gsum, dgrad, st.can_h, st.can_w, c, st.off_y + oy + a, st.off_x + ox + b);
+        v += wy[a] * h;
+      }
     }
     if (st.normalise) v = v / st.stdv[c];
     size_t o = (size_t)c * gsrc_cstride + (size_t)ys * gsrc_rstride + xs;
