@@ -164,10 +164,13 @@ def probe_peer_exchange(ex, group=None, rounds=3, seed=1234):
     dist = torch.distributed
     ok = True
     n = ex.floats
+    limit, ex.timeout_s = ex.timeout_s, min(ex.timeout_s, 2.0)    # a broken path should fail fast here
     for r in range(rounds):
         gen = torch.Generator().manual_seed(seed + 1000 * r + ex.rank)
         mine = torch.randn(n, generator=gen).to(ex.device)
         ex.send.copy_(mine)
+        if ex.world > 1:
+            dist.barrier(group=group)     # ranks enter the exchange together: the short limit is fair
         got = ex.all_reduce().clone()
         if ex.world > 1:
             # the reference sum comes over the host library (staged through the CPU for gloo)
@@ -182,6 +185,7 @@ def probe_peer_exchange(ex, group=None, rounds=3, seed=1234):
             want += q
         ok = ok and bool(torch.equal(got, want))
     ok = ok and not ex.timed_out()
+    ex.timeout_s = limit
     if ex.world > 1:
         flag = torch.tensor([1 if ok else 0], device=ex.device, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
@@ -199,16 +203,21 @@ def make_exchange(floats, device, group=None, transport="auto", timeout_s=5.0):
     dist = torch.distributed
     if dist.is_initialized() and dist.get_backend(group) == "gloo" and transport == "auto":
         return None          # CPU rehearsal groups keep the host all-reduce
-    try:
-        ex = PeerExchange(floats, device, group=group, timeout_s=timeout_s)
-    except Exception:
-        if transport == "peer":
-            raise
-        return None
-    if not probe_peer_exchange(ex, group):
+    # memory kinds in order of preference (include/advx.h ADVX_COMM_MEM_*): 0 = uncached if it can
+    # be exported, 2 = fine-grained.  Every rank sees every rank's errors (they are gathered in the
+    # constructor) and the probe's verdict is agreed, so all ranks walk this list in step.
+    last_error = None
+    for mem_kind in (0, 2):
+        try:
+            ex = PeerExchange(floats, device, group=group, mem_kind=mem_kind, timeout_s=timeout_s)
+        except Exception as e:  # set-up failed on at least one rank
+            last_error = e
+            continue
+        if probe_peer_exchange(ex, group):
+            return ex
         ex.close()
-        if transport == "peer":
-            from . import _lib as L
-            raise L.AdvxError("peer exchange failed its self-test on this machine")
-        return None
-    return ex
+        from . import _lib as L
+        last_error = L.AdvxError("peer exchange failed its self-test on this machine")
+    if transport == "peer":
+        raise last_error
+    return None
