@@ -663,7 +663,9 @@ extern "C" int32_t advx_collect(advx_plan* p, const float* grad_out, int32_t bat
     float* gsrc = (s.src == 0) ? grad_argument : ws + p->dplan.dgrad_off[s.src - 1];
     int acc = (s.src == 0) ? accumulate : 0;
     long long n = 3LL * D.src_h * D.src_w;
-    hipLaunchKernelGGL(k_stage_bwd, dim3(grid_for(n)), dim3(kBlock), 0, st, D, p->dplan, k, gsum, dgrad, gsrc,
+    (void)n;
+    const int rowblk = 128;   // two waves along x: little waste on the last chunk of a 336 / 512 / 672-wide row
+    hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D, p->dplan, k, gsum, dgrad, gsrc,
                        (long long)D.src_h * D.src_w, D.src_w, acc);
     LAUNCH_CHECK();
   }

@@ -390,16 +390,15 @@ __device__ inline float canvas_grad_at(const DPlan& pl, int stage, const float* 
 
 constexpr int kBwdCols = 8;   // widest window the separable index path of k_stage_bwd keeps in registers
 
-// one thread per SOURCE element: transposed-tap gather (no atomics)
+// one thread per SOURCE element: transposed-tap gather (no atomics).  Grid = (column chunks,
+// source rows, channels): the row of a workgroup is uniform, so its taps, weights and the row
+// part of the layout map are scalar work, and no thread divides to find its pixel.
 __global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, DPlan pl, int stage, const float* __restrict__ gsum,
                                                       const float* __restrict__ dgrad, float* __restrict__ gsrc,
                                                       long long gsrc_cstride, int gsrc_rstride, int accumulate) {
-  long long n = 3LL * st.src_h * st.src_w;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x) {
-    int c = (int)((unsigned)i / ((unsigned)st.src_h * (unsigned)st.src_w));
-    int rem = (int)((unsigned)i - (unsigned)c * (unsigned)st.src_h * (unsigned)st.src_w);
-    int ys = rem / st.src_w, xs = rem - ys * st.src_w;
+  const int c = blockIdx.z, ys = blockIdx.y;
+  const int xs = blockIdx.x * blockDim.x + threadIdx.x;
+  if (xs < st.src_w) {
     int oy = st.tth.start[ys], oyc = st.tth.count[ys];
     int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
     const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
