@@ -88,6 +88,12 @@ SIGNATURES = {
                                _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "advx_fused_step_rows": (_I32, [_P, _PI32, _PI32]),
     "advx_fused_step_flush": (_I32, [_P, _I32, _I32, _P, _P, _P]),
+    "advx_prepared_supported": (_I32, [_P]),
+    "advx_prepared_scratch_floats": (_I64, [_P]),
+    "advx_prepared_rows": (_I32, [_P, _PI32, _PI32]),
+    "advx_prepared_fwd": (_I32, [_P, _P, _P, _F, _I32, _P, _I32, _U64, _U64, _P, _P, _I32, _I32, _P, _P, _P, _I64, _I32, _P]),
+    "advx_prepared_bwd": (_I32, [_P, _P, _I32, _P, _P, _F, _F, _P, _P, _P, _P, C.POINTER(OptScalars), _P, _I32, _I32, _P, _P,
+                                 _P, _I64, _P]),
     "advx_comm_create": (_I32, [_I32, _I32, _I64, _I32, C.POINTER(_P)]),
     "advx_comm_export": (_I32, [_P, _P]),
     "advx_comm_connect": (_I32, [_P, _P]),

@@ -1417,3 +1417,127 @@ extern "C" int32_t advx_fused_bwd_dp(advx_plan* p, advx_comm* c, const void* g, 
   if (rc) return rc;
   return fused_update_impl(p, pp, m, v, recv, mask, x0, eps, opt, s_next, v_buf, scratch, &c->dev, stream);
 }
+
+// ------------------------------------------------- prepared chain (one-stage plans, 4 launches)
+// See k_plan_tail / k_plan_head.  scratch = [image rows set 0][image rows set 1][norm rows],
+// rows = one per 256 source pixels (or kMaxStatBlocks for the first, unprepared step).
+namespace {
+struct PreparedScratch {
+  double* img_rows[2];
+  double* norm_rows;
+  int tail_blocks, prep_blocks;
+};
+PreparedScratch carve_prepared(const advx_plan* p, float* scratch) {
+  PreparedScratch f;
+  const long long n = 3LL * p->info.in_h * p->info.in_w;
+  f.tail_blocks = (int)((n + kBlock - 1) / kBlock);
+  f.prep_blocks = grid_for(n, kMaxStatBlocks);
+  const size_t rows = (size_t)std::max(f.tail_blocks, f.prep_blocks);
+  double* d = reinterpret_cast<double*>(scratch);
+  f.img_rows[0] = d;
+  f.img_rows[1] = d + rows * kStatSlots;
+  f.norm_rows = d + 2 * rows * kStatSlots;
+  return f;
+}
+}  // namespace
+
+extern "C" int32_t advx_prepared_supported(const advx_plan* p) {
+  if (!p) return 0;
+  return (p->info.n_stage == 1 && p->st[0].info.src == 0) ? 1 : 0;
+}
+
+extern "C" int64_t advx_prepared_scratch_floats(const advx_plan* p) {
+  if (!p) return 0;
+  const long long n = 3LL * p->info.in_h * p->info.in_w;
+  const long long rows = std::max<long long>((n + kBlock - 1) / kBlock, grid_for(n, kMaxStatBlocks));
+  return 2 * (2 * rows * kStatSlots + rows) + 64;
+}
+
+extern "C" int32_t advx_prepared_rows(const advx_plan* p, int32_t* rows_after_prepare, int32_t* rows_after_bwd) {
+  REQUIRE(p && rows_after_prepare && rows_after_bwd, ADVX_E_BADARG, "advx_prepared_rows: null argument");
+  const long long n = 3LL * p->info.in_h * p->info.in_w;
+  *rows_after_prepare = grid_for(n, kMaxStatBlocks);
+  *rows_after_bwd = (int32_t)((n + kBlock - 1) / kBlock);
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_prepared_fwd(advx_plan* p, const float* pp, const float* x0, float eps, int32_t batch,
+                                     const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset, float* out,
+                                     float* s_buf, int32_t prepared, int32_t parity, float* stats, float* scratch, float* ws,
+                                     int64_t ws_floats, int32_t pad_mode, void* stream) {
+  REQUIRE(p && pp && x0 && out && s_buf && stats && scratch && ws, ADVX_E_BADARG, "advx_prepared_fwd: null argument");
+  REQUIRE(advx_prepared_supported(p), ADVX_E_UNSUPPORTED, "advx_prepared_fwd: the plan has more than one stage");
+  REQUIRE(parity == 0 || parity == 1, ADVX_E_BADARG, "advx_prepared_fwd: parity must be 0 or 1");
+  REQUIRE(pad_mode == ADVX_PAD_NOISE || pad_mode == ADVX_PAD_KEEP, ADVX_E_BADARG, "advx_prepared_fwd: unknown pad_mode");
+  REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_prepared_fwd: batch out of range");
+  REQUIRE(ws_floats >= p->info.workspace_floats, ADVX_E_SHAPE, "advx_prepared_fwd: workspace too small");
+  REQUIRE(aligned16(out) && aligned16(ws) && (!unit_noise || aligned16(unit_noise)), ADVX_E_BADARG,
+          "advx_prepared_fwd: pointers must be 16-byte aligned");
+  int32_t rc = advx_plan_upload(p, stream);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  PreparedScratch f = carve_prepared(p, scratch);
+  const DStage& D = p->dstage[0];
+  const long long n = 3LL * p->info.in_h * p->info.in_w;
+  if (!prepared) {
+    // first step, or p was changed elsewhere: s, its statistics partials and the canvas
+    hipLaunchKernelGGL(k_prep<true>, dim3(f.prep_blocks), dim3(kBlock), 0, st, pp, x0, eps, n, s_buf, f.img_rows[parity]);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_plan_head, dim3(grid_for(3LL * D.can_h * D.can_w)), dim3(kBlock), 0, st, D, (const float*)s_buf,
+                       (long long)D.src_h * D.src_w, D.src_w, ws + p->dplan.canvas_off[0], (const double*)nullptr, 0, stats);
+    LAUNCH_CHECK();
+  }
+  const int noise = unit_noise ? 1 : (use_philox ? 2 : 0);
+  const long long n4 = (p->info.out_numel + 3) >> 2;
+  long long q_lo = 0, q_hi = n4, live_lo = 0, live_hi = n4 << 2;
+  if (pad_mode == ADVX_PAD_KEEP) {
+    plan_live_range(p, &live_lo, &live_hi);
+    q_lo = live_lo >> 2;
+    q_hi = (live_hi + 3) >> 2;
+  }
+  int gx, slices, bps;
+  emit_slices(q_hi - q_lo, batch, &gx, &slices, &bps);
+  dim3 grid(gx, slices);
+  const float* sigma_dev = stats + ADVX_STAT_QERR_STD;   // quantise error of the PREVIOUS image (not yet rotated)
+#define ADVX_EMIT(N)                                                                                                \
+  hipLaunchKernelGGL(k_emit<N>, grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, offset, \
+                     out, q_lo, q_hi, live_lo, live_hi)
+  if (noise == 0) ADVX_EMIT(0); else if (noise == 1) ADVX_EMIT(1); else ADVX_EMIT(2);
+#undef ADVX_EMIT
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_prepared_bwd(advx_plan* p, const float* grad_out, int32_t batch, float* pp, const float* x0, float eps,
+                                     float imgfit_scale, const float* mask, float* m, float* v, float* grad_p,
+                                     const advx_opt_scalars* opt, float* s_next, int32_t rows_in, int32_t parity, float* stats,
+                                     float* scratch, float* ws, int64_t ws_floats, void* stream) {
+  REQUIRE(p && grad_out && pp && x0 && mask && grad_p && opt && s_next && stats && scratch && ws, ADVX_E_BADARG,
+          "advx_prepared_bwd: null argument");
+  REQUIRE(advx_prepared_supported(p), ADVX_E_UNSUPPORTED, "advx_prepared_bwd: the plan has more than one stage");
+  REQUIRE(parity == 0 || parity == 1, ADVX_E_BADARG, "advx_prepared_bwd: parity must be 0 or 1");
+  REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_prepared_bwd: batch out of range");
+  REQUIRE(ws_floats >= p->info.workspace_floats, ADVX_E_SHAPE, "advx_prepared_bwd: workspace too small");
+  REQUIRE(opt->apply, ADVX_E_UNSUPPORTED, "advx_prepared_bwd always takes the optimiser step (use the generic path to accumulate)");
+  int32_t rc = check_opt(opt, m, v);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  PreparedScratch f = carve_prepared(p, scratch);
+  REQUIRE(rows_in >= 0 && rows_in <= std::max(f.tail_blocks, f.prep_blocks), ADVX_E_BADARG, "advx_prepared_bwd: rows_in out of range");
+  const DStage& D = p->dstage[0];
+  const long long n = 3LL * p->info.in_h * p->info.in_w;
+  long long lo, hi;
+  plan_live_range(p, &lo, &hi);
+  rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st, lo, hi);
+  if (rc) return rc;
+  const float* gsum = ws + p->dplan.gsum_off;
+  hipLaunchKernelGGL(k_plan_tail, dim3(f.tail_blocks), dim3(kBlock), 0, st, D, p->dplan, gsum, pp, x0, eps,
+                     imgfit_scale / (float)n, mask, m, v, grad_p, to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows,
+                     (const double*)f.img_rows[parity], (int)rows_in, stats);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_plan_head, dim3(grid_for(3LL * D.can_h * D.can_w)), dim3(kBlock), 0, st, D, (const float*)s_next,
+                     (long long)D.src_h * D.src_w, D.src_w, ws + p->dplan.canvas_off[0], (const double*)f.norm_rows,
+                     f.tail_blocks, stats);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}

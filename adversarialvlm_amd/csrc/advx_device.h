@@ -168,15 +168,28 @@ __device__ __host__ inline void emit_inverse(const DEmit& e, long long idx, int&
 }
 
 // ------------------------------------------------------------------------- reductions
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-  return v;
+// Wave-wide sum by DPP moves (VALU, no LDS round trips: a __shfl of a double is two
+// ds_bpermute per step and the dependent chain of six steps dominated every per-block
+// reduction).  The TOTAL ends up in the LAST lane; the order of the additions is fixed.
+//   row_shr:1..3 -> every lane holds itself + its 3 predecessors of the 16-lane row,
+//   row_shr:4 / row_shr:8 (bank-masked) -> lane 15 of each row holds the row sum,
+//   row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3) -> lane 63 holds the wave sum.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ inline double dpp_or_zero(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, BANK_MASK, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, BANK_MASK, true);
+  return __hiloint2double(hi, lo);
 }
-__device__ inline float wave_sum(float v) {
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-  return v;
+__device__ inline double wave_sum_to_last_lane(double v) {
+  double s = v + dpp_or_zero<0x111, 0xf, 0xf>(v);
+  s += dpp_or_zero<0x112, 0xf, 0xf>(v);
+  s += dpp_or_zero<0x113, 0xf, 0xf>(v);
+  s += dpp_or_zero<0x114, 0xf, 0xe>(s);
+  s += dpp_or_zero<0x118, 0xf, 0xc>(s);
+  s += dpp_or_zero<0x142, 0xa, 0xf>(s);
+  s += dpp_or_zero<0x143, 0xc, 0xf>(s);
+  return s;
 }
 
 // Block-wide sum of NS doubles per thread; thread 0 writes the NS totals to dst.
@@ -186,8 +199,8 @@ __device__ inline void block_sum_store(const double (&acc)[NS], double* dst) {
   int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
-    double v = wave_sum(acc[k]);
-    if (lane == 0) red[wid][k] = v;
+    double v = wave_sum_to_last_lane(acc[k]);
+    if (lane == kWave - 1) red[wid][k] = v;
   }
   __syncthreads();
   if (threadIdx.x == 0) {

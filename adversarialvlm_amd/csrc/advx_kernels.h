@@ -331,6 +331,38 @@ __global__ void __launch_bounds__(kBlock) k_build_taps(TapBuild a0, TapBuild a1)
 
 // ========================================================================== stage fwd
 // canvas[c,y,x] = normalise(pad | sum_a wa sum_b wb src[...])  - one thread per canvas element
+__device__ inline float stage_fwd_value(const DStage& st, const float* __restrict__ src, long long src_cstride,
+                                        int src_rstride, int c, int y, int x) {
+  int ry = y - st.off_y, rx = x - st.off_x;
+  float v;
+  if (ry >= 0 && ry < st.res_h && rx >= 0 && rx < st.res_w) {
+    const float* sp = src + (size_t)c * src_cstride;
+    int ys = st.th.start[ry], yc = st.th.count[ry];
+    int xs = st.tw.start[rx], xc = st.tw.count[rx];
+    const float* wy = st.th.w + (size_t)ry * st.th.stride;
+    const float* wx = st.tw.w + (size_t)rx * st.tw.stride;
+    v = 0.0f;
+    if (!st.inner_axis_h) {
+      for (int a = 0; a < yc; ++a) {
+        const float* rowp = sp + (size_t)(ys + a) * src_rstride + xs;
+        float h = 0.0f;
+        for (int b = 0; b < xc; ++b) h += wx[b] * rowp[b];
+        v += wy[a] * h;
+      }
+    } else {
+      for (int b = 0; b < xc; ++b) {
+        float h = 0.0f;
+        for (int a = 0; a < yc; ++a) h += wy[a] * sp[(size_t)(ys + a) * src_rstride + xs + b];
+        v += wx[b] * h;
+      }
+    }
+  } else {
+    v = st.pad_value;
+  }
+  if (st.normalise) v = (v - st.mean[c]) / st.stdv[c];
+  return v;
+}
+
 __global__ void __launch_bounds__(kBlock) k_stage_fwd(DStage st, const float* __restrict__ src, long long src_cstride,
                                                       int src_rstride, float* __restrict__ canvas) {
   long long n = 3LL * st.can_h * st.can_w;
@@ -339,34 +371,7 @@ __global__ void __launch_bounds__(kBlock) k_stage_fwd(DStage st, const float* __
     int c = (int)((unsigned)i / ((unsigned)st.can_h * (unsigned)st.can_w));
     int rem = (int)((unsigned)i - (unsigned)c * (unsigned)st.can_h * (unsigned)st.can_w);
     int y = rem / st.can_w, x = rem - y * st.can_w;
-    int ry = y - st.off_y, rx = x - st.off_x;
-    float v;
-    if (ry >= 0 && ry < st.res_h && rx >= 0 && rx < st.res_w) {
-      const float* sp = src + (size_t)c * src_cstride;
-      int ys = st.th.start[ry], yc = st.th.count[ry];
-      int xs = st.tw.start[rx], xc = st.tw.count[rx];
-      const float* wy = st.th.w + (size_t)ry * st.th.stride;
-      const float* wx = st.tw.w + (size_t)rx * st.tw.stride;
-      v = 0.0f;
-      if (!st.inner_axis_h) {
-        for (int a = 0; a < yc; ++a) {
-          const float* rowp = sp + (size_t)(ys + a) * src_rstride + xs;
-          float h = 0.0f;
-          for (int b = 0; b < xc; ++b) h += wx[b] * rowp[b];
-          v += wy[a] * h;
-        }
-      } else {
-        for (int b = 0; b < xc; ++b) {
-          float h = 0.0f;
-          for (int a = 0; a < yc; ++a) h += wy[a] * sp[(size_t)(ys + a) * src_rstride + xs + b];
-          v += wx[b] * h;
-        }
-      }
-    } else {
-      v = st.pad_value;
-    }
-    if (st.normalise) v = (v - st.mean[c]) / st.stdv[c];
-    canvas[i] = v;
+    canvas[i] = stage_fwd_value(st, src, src_cstride, src_rstride, c, y, x);
   }
 }
 
@@ -390,15 +395,11 @@ __device__ inline float canvas_grad_at(const DPlan& pl, int stage, const float* 
 
 constexpr int kBwdCols = 8;   // widest window the separable index path of k_stage_bwd keeps in registers
 
-// one thread per SOURCE element: transposed-tap gather (no atomics).  Grid = (column chunks,
-// source rows, channels): the row of a workgroup is uniform, so its taps, weights and the row
-// part of the layout map are scalar work, and no thread divides to find its pixel.
-__global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, DPlan pl, int stage, const float* __restrict__ gsum,
-                                                      const float* __restrict__ dgrad, float* __restrict__ gsrc,
-                                                      long long gsrc_cstride, int gsrc_rstride, int accumulate) {
-  const int c = blockIdx.z, ys = blockIdx.y;
-  const int xs = blockIdx.x * blockDim.x + threadIdx.x;
-  if (xs < st.src_w) {
+// gradient of SOURCE element (c, ys, xs) of a stage: transposed-tap gather over the canvas
+// gradient (no atomics), divided by std where the stage normalises
+__device__ inline float stage_bwd_value(const DStage& st, const DPlan& pl, int stage, const float* __restrict__ gsum,
+                                        const float* __restrict__ dgrad, int c, int ys, int xs) {
+  {
     int oy = st.tth.start[ys], oyc = st.tth.count[ys];
     int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
     const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
@@ -450,6 +451,20 @@ __global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, DPlan pl, int s
       }
     }
     if (st.normalise) v = v / st.stdv[c];
+    return v;
+  }
+}
+
+// one thread per SOURCE element.  Grid = (column chunks, source rows, channels): the row of a
+// workgroup is uniform, so its taps, weights and the row part of the layout map are scalar
+// work, and no thread divides to find its pixel.
+__global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, DPlan pl, int stage, const float* __restrict__ gsum,
+                                                      const float* __restrict__ dgrad, float* __restrict__ gsrc,
+                                                      long long gsrc_cstride, int gsrc_rstride, int accumulate) {
+  const int c = blockIdx.z, ys = blockIdx.y;
+  const int xs = blockIdx.x * blockDim.x + threadIdx.x;
+  if (xs < st.src_w) {
+    float v = stage_bwd_value(st, pl, stage, gsum, dgrad, c, ys, xs);
     size_t o = (size_t)c * gsrc_cstride + (size_t)ys * gsrc_rstride + xs;
     gsrc[o] = accumulate ? (gsrc[o] + v) : v;
   }
@@ -513,13 +528,20 @@ __global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restri
   if (q >= q_hi) return;
   const long long i0 = q << 2;
   float v[4];
+  const bool vec = ((n & 3) == 0);
+  if (vec && pl.n_emit == 1 && pl.e[0].kind == ADVX_EMIT_PLAIN && pl.e[0].out_begin == 0 && pl.e[0].out_count == n &&
+      (pl.canvas_off[pl.e[0].stage] & 3) == 0) {
+    // the output IS the canvas (LLaVA): one 16-byte load instead of four inverse layout maps
+    const float4 c4 = *reinterpret_cast<const float4*>(ws + pl.canvas_off[pl.e[0].stage] + i0);
+    v[0] = c4.x; v[1] = c4.y; v[2] = c4.z; v[3] = c4.w;
+  } else {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? emit_value(pl, ws, i0 + k) : 0.0f;
+    for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? emit_value(pl, ws, i0 + k) : 0.0f;
+  }
   const bool edge = (i0 < live_lo) || (i0 + 4 > live_hi);
   const float sigma = (NOISE != 0) ? sigma_dev[0] : 0.0f;
   const int b0 = blockIdx.y * b_per_slice;
   const int b1 = min(batch, b0 + b_per_slice);
-  const bool vec = ((n & 3) == 0);
   for (int b = b0; b < b1; ++b) {
     float o[4] = {v[0], v[1], v[2], v[3]};
     if (NOISE == 1) {
@@ -540,7 +562,10 @@ __global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restri
         if (i0 + k < live_lo || i0 + k >= live_hi) o[k] = 0.0f;
     }
     if (vec) {
-      *reinterpret_cast<float4*>(out + (size_t)b * n + i0) = make_float4(o[0], o[1], o[2], o[3]);
+      // write-once stream: non-temporal, like the fused forward
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      f4v ov = {o[0], o[1], o[2], o[3]};
+      __builtin_nontemporal_store(ov, reinterpret_cast<f4v*>(out + (size_t)b * n + i0));
     } else {
       for (int k = 0; k < 4; ++k)
         if (i0 + k < n) out[(size_t)b * n + i0 + k] = o[k];
@@ -924,6 +949,79 @@ __global__ void __launch_bounds__(kBlock) k_fused_update(float* __restrict__ p, 
   }
   block_sum_store<1>(nacc, norm_partials + blockIdx.x);
   if (blockIdx.x == 0 && threadIdx.x == 0) hdr->norm_blocks = gridDim.x;
+}
+
+// ============================================== prepared chain (any one-stage plan, no blur/crop)
+// The fused pair's software pipelining for plans whose process() DOES resample (LLaVA from a
+// non-native image, Mllama, Qwen2-VL): the backward of step t leaves the canvas of step t+1 in
+// the plan workspace, so a step is four launches instead of nine:
+//   k_emit          out = canvas_t (+ sigma_t N(0,1)), sigma_t = slot QERR_STD (previous image)
+//   k_batch_reduce  gsum = sum_b grad_out (only the columns an image reaches)
+//   k_plan_tail     per SOURCE pixel: resize^T (/std), image-fit', tanh', mask, ||g|| partial,
+//                   optimiser -> p_{t+1}; s_{t+1} = x0 + eps*tanh(p_{t+1}) and its statistics
+//                   partials; block 0 reduces the statistics of s_t (rotating SIGMA <- QERR_STD)
+//   k_plan_head     canvas_{t+1} = resize(s_{t+1}), pad, normalise; block 0 reduces ||g||
+__global__ void __launch_bounds__(kBlock) k_plan_tail(DStage st, DPlan pl, const float* __restrict__ gsum,
+                                                      float* __restrict__ p, const float* __restrict__ x0, float eps,
+                                                      float c_fit, const float* __restrict__ mask, float* __restrict__ m,
+                                                      float* __restrict__ v, float* __restrict__ grad_p, OptScalars o,
+                                                      float* __restrict__ s_next, double* __restrict__ img_rows_out,
+                                                      double* __restrict__ norm_rows, const double* __restrict__ img_rows_in,
+                                                      int img_rows_in_count, float* __restrict__ stats) {
+  const unsigned plane = (unsigned)st.src_h * (unsigned)st.src_w;
+  const long long n = 3LL * plane;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && img_rows_in_count > 0) finalize_image_block<true>(img_rows_in, img_rows_in_count, n, stats);
+  double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
+  double nacc[1] = {0.0};
+  if (i < n) {
+    float pp = p[i];
+    const float xv = x0[i], mk = mask[i];
+    float mm = 0.f, vv = 0.f;
+    if (o.kind == 0) {
+      mm = m[i];
+      vv = v[i];
+    }
+    const int c = (int)((unsigned)i / plane);
+    const unsigned rem = (unsigned)i - (unsigned)c * plane;
+    const int ys = (int)(rem / (unsigned)st.src_w), xs = (int)(rem - (unsigned)ys * (unsigned)st.src_w);
+    const float t = tanhf(pp);
+    const float s = xv + eps * t;
+    const float gs = stage_bwd_value(st, pl, 0, gsum, nullptr, c, ys, xs);
+    float gp = ((gs + imgfit_grad(s, c_fit)) * eps) * (1.0f - t * t);
+    gp = gp * mk;
+    nacc[0] = (double)gp * (double)gp;
+    grad_p[i] = gp;
+    if (o.kind == 0) {
+      adamw_element(pp, mm, vv, gp, o);
+      p[i] = pp; m[i] = mm; v[i] = vv;
+    } else {
+      float sg = (gp > 0.0f) ? 1.0f : ((gp < 0.0f) ? -1.0f : 0.0f);
+      pp = pp - o.lr * sg;
+      p[i] = pp;
+    }
+    const float xn = eps * tanhf(pp);
+    const float sn = xv + xn;
+    s_next[i] = sn;
+    stat_accumulate(sn, xn, acc);
+  }
+  block_sum_store<kStatSlots>(acc, img_rows_out + (size_t)blockIdx.x * kStatSlots);
+  block_sum_store<1>(nacc, norm_rows + blockIdx.x);
+}
+
+__global__ void __launch_bounds__(kBlock) k_plan_head(DStage st, const float* __restrict__ src, long long src_cstride,
+                                                      int src_rstride, float* __restrict__ canvas,
+                                                      const double* __restrict__ norm_rows, int norm_count,
+                                                      float* __restrict__ stats) {
+  if (blockIdx.x == 0 && norm_count > 0) finalize_norm_block(norm_rows, norm_count, stats);
+  long long n = 3LL * st.can_h * st.can_w;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)((unsigned)i / ((unsigned)st.can_h * (unsigned)st.can_w));
+    int rem = (int)((unsigned)i - (unsigned)c * (unsigned)st.can_h * (unsigned)st.can_w);
+    int y = rem / st.can_w, x = rem - y * st.can_w;
+    canvas[i] = stage_fwd_value(st, src, src_cstride, src_rstride, c, y, x);
+  }
 }
 
 // ------------------------------------------------------------------- one launch per step

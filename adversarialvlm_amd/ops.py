@@ -249,6 +249,48 @@ def profile_end():
     return {k: ((ms[i] / n[i]) if n[i] else 0.0, int(n[i])) for i, k in enumerate(("fwd", "bwd", "step"))}
 
 
+# --------------------------------------------------------------------------- prepared
+def prepared_scratch(plan, device):
+    return torch.empty(int(L.load().advx_prepared_scratch_floats(plan.handle)), dtype=torch.float32, device=device)
+
+
+def prepared_rows(plan):
+    a, b = C.c_int32(), C.c_int32()
+    L.check(L.load().advx_prepared_rows(plan.handle, C.byref(a), C.byref(b)), "advx_prepared_rows")
+    return int(a.value), int(b.value)
+
+
+def prepared_fwd(plan, p, x0, epsilon, batch, stats, scratch, workspace, s_buf, prepared, parity, unit_noise=None,
+                 philox=None, out=None, keep_padding=False):
+    _require_cuda(p, x0, stats, scratch, workspace, s_buf)
+    if keep_padding and (out is None or out.numel() != batch * plan.out_numel):
+        raise L.AdvxError("keep_padding needs the caller's persistent [batch, out_numel] buffer")
+    if out is None:
+        out = torch.empty((batch, plan.out_numel), dtype=torch.float32, device=p.device)
+    if unit_noise is not None:
+        unit_noise = _f32c(unit_noise)
+        if unit_noise.numel() != batch * plan.out_numel:
+            raise L.AdvxError("unit_noise has the wrong number of elements")
+    seed, offset = (philox if philox is not None else (0, 0))
+    L.check(L.load().advx_prepared_fwd(plan.handle, L.ptr(p), L.ptr(x0), float(epsilon), int(batch), L.ptr(unit_noise),
+                                       int(philox is not None), int(seed), int(offset), L.ptr(out), L.ptr(s_buf),
+                                       int(bool(prepared)), int(parity), L.ptr(stats), L.ptr(scratch), L.ptr(workspace),
+                                       int(workspace.numel()), 1 if keep_padding else 0, _stream(p)), "advx_prepared_fwd")
+    return out
+
+
+def prepared_bwd(plan, grad_out, batch, p, x0, epsilon, imgfit_scale, mask, m, v, grad_p, opt, s_next, rows_in, parity,
+                 stats, scratch, workspace):
+    _require_cuda(grad_out, p, x0, mask, grad_p, s_next, stats, scratch, workspace)
+    grad_out = _f32c(grad_out)
+    if grad_out.numel() != batch * plan.out_numel:
+        raise L.AdvxError("grad_out has the wrong number of elements")
+    L.check(L.load().advx_prepared_bwd(plan.handle, L.ptr(grad_out), int(batch), L.ptr(p), L.ptr(x0), float(epsilon),
+                                       float(imgfit_scale), L.ptr(mask), L.ptr(m), L.ptr(v), L.ptr(grad_p), C.byref(opt),
+                                       L.ptr(s_next), int(rows_in), int(parity), L.ptr(stats), L.ptr(scratch),
+                                       L.ptr(workspace), int(workspace.numel()), _stream(p)), "advx_prepared_bwd")
+
+
 def quantise(s, out=None):
     """The image after the lossless PNG round trip of attack_model.py:368-371 (uint8 truncation)."""
     _require_cuda(s)

@@ -10,9 +10,12 @@ and `crossattack_models.py:329-406,425-432` (several models):
                        blur^T, tanh' -> grad_p ; [all-reduce over the DP group] ;
                        mask, ||g||, AdamW|sign, StepLR                   (HIP)
 
-Three kernel chains implement this, chosen at construction (`self.mode`):
+Four kernel chains implement this, chosen at construction (`self.mode`):
   * generic  - any plan(s), blur, crop, gradient accumulation (advx_image_* / advx_emit /
-               advx_collect / advx_update);
+               advx_collect / advx_update): nine launches per step;
+  * prepared - ONE one-stage plan (LLaVA from a non-native image, Mllama, Qwen2-VL) without
+               blur/crop/accumulation on one GPU: the backward leaves the next step's canvas
+               behind, four launches per step (advx_prepared_fwd / advx_prepared_bwd);
   * pair     - one identity-resize LLaVA plan without blur/crop/accumulation: two launches
                per step (advx_fused_fwd / advx_fused_bwd); the form data parallelism uses,
                with the gradient all-reduce between the backward and advx_update;
@@ -95,10 +98,21 @@ class PixelPGD:
         self.fused = bool(allow_fused and len(self.plans) == 1 and self.plans[0].fused_supported()
                           and blur_kernel is None and not self.use_crop and self.accum == 1)
         self.upd_scratch = ops.update_scratch(self.p.numel(), dev)
-        if fused_mode not in ("auto", "pair", "step"):
-            raise ValueError("fused_mode must be auto, pair or step")
-        if not self.fused:
-            self.mode = "generic"
+        if fused_mode not in ("auto", "pair", "step", "prepared"):
+            raise ValueError("fused_mode must be auto, pair, step or prepared")
+        # the prepared chain: any one-stage plan (it resamples), same restrictions otherwise; the
+        # gradient exchange of data parallelism stays on the generic chain
+        can_prepare = bool(allow_fused and len(self.plans) == 1 and self.plans[0].prepared_supported()
+                           and blur_kernel is None and not self.use_crop and self.accum == 1 and not self.exchange)
+        if fused_mode == "prepared":
+            if not can_prepare:
+                raise L.AdvxError("fused_mode='prepared' needs one one-stage plan, no blur / crop / accumulation / exchange")
+            self.fused = False
+            self.mode = "prepared"
+        elif not self.fused:
+            if fused_mode in ("pair", "step") and allow_fused:
+                raise L.AdvxError(f"fused_mode='{fused_mode}' needs an identity-resize LLaVA plan without blur / crop / accumulation")
+            self.mode = "prepared" if can_prepare else "generic"
         elif fused_mode == "auto":
             # measured on MI355X (profiles/r01): the two-launch pair is currently the faster
             # chain; the one-launch step is kept behind fused_mode="step"
@@ -137,6 +151,14 @@ class PixelPGD:
             self.workspaces = [torch.empty(pl.workspace_floats, dtype=torch.float32, device=dev) for pl in self.plans]
             self.noise_on_padding = bool(noise_on_padding)
             self._outs = [None] * len(self.plans)     # persistent pixel_values (noise_on_padding=False)
+            if self.mode == "prepared":
+                self.prep_scratch = ops.prepared_scratch(self.plans[0], dev)
+                self.rows_prepare, self.rows_bwd = ops.prepared_rows(self.plans[0])
+                self.s_bufs = [self.s, torch.empty_like(self.x0)]
+                self.s_cur = 0
+                self.par = 0
+                self.rows_in = 0
+                self.prepared = False
         self._last = None
         for pl in self.plans:
             pl.upload()
@@ -205,6 +227,27 @@ class PixelPGD:
                 self._out_next = None
             self.s = self.s_bufs[self.s_cur]
             outs.append(out.view(shape))
+            self._last = dict(batches=list(batches))
+            return outs
+        if self.mode == "prepared":
+            if crop is not None:
+                raise L.AdvxError("this engine was built for the prepared chain: construct with use_crop=True to crop")
+            pl, B, z = self.plans[0], batches[0], unit_noises[0]
+            ph = None if (z is not None or not use_philox) else (self.seed, self.iteration)
+            keep = (not self.noise_on_padding) and z is None
+            buf = None
+            if keep:
+                if self._outs[0] is None or self._outs[0].shape[0] != B:
+                    self._outs[0] = torch.zeros((B, pl.out_numel), dtype=torch.float32, device=self.p.device)
+                buf = self._outs[0]
+            out = ops.prepared_fwd(pl, self.p, self.x0, self.eps, B, self.stats, self.prep_scratch, self.workspaces[0],
+                                   self.s_bufs[self.s_cur], self.prepared, self.par, unit_noise=z, philox=ph, out=buf,
+                                   keep_padding=keep)
+            if not self.prepared:
+                self.rows_in = self.rows_prepare
+                self.prepared = True
+            self.s = self.s_bufs[self.s_cur]
+            outs.append(out.view((B * pl.out_shape[0],) + pl.out_shape[1:]))
             self._last = dict(batches=list(batches))
             return outs
         blur = (self.blur_kernel, blur_sigma) if self.blur_kernel is not None else None
@@ -276,6 +319,15 @@ class PixelPGD:
                 ops.fused_update(pl, self.p, self.m, self.v, self.grad, self.mask, self.x0, self.eps, opt,
                                  self.s_bufs[nxt], self.v_buf, self.fused_scratch)
             self.s_cur = nxt          # the next forward's image goes to the other buffer: image() stays valid
+        elif self.mode == "prepared":
+            pl, B = self.plans[0], st["batches"][0]
+            nxt = 1 - self.s_cur
+            ops.prepared_bwd(pl, grads[0], B, self.p, self.x0, self.eps, self.imgfit_scale(), self.mask, self.m, self.v,
+                             self.grad, opt, self.s_bufs[nxt], self.rows_in, self.par, self.stats, self.prep_scratch,
+                             self.workspaces[0])
+            self.par = 1 - self.par
+            self.rows_in = self.rows_bwd
+            self.s_cur = nxt
         else:
             for i, (pl, g, B) in enumerate(zip(self.plans, grads, st["batches"])):
                 ops.collect(pl, g.reshape(B, pl.out_numel), B, grad_argument=self.garg, accumulate=(i > 0),
@@ -342,6 +394,10 @@ class PixelPGD:
             self._out_next = None
             self.img_rows = self.norm_rows = 0
             self.fused_scratch.zero_()
+        if self.mode == "prepared":
+            self.prepared = False
+            self.par = 0
+            self.rows_in = 0
 
     def image(self):
         """x0 + x of the most recent forward (what the reference checkpoints)."""

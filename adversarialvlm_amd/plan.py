@@ -84,6 +84,9 @@ class Plan:
     def fused_supported(self):
         return bool(L.load().advx_fused_supported(self._h))
 
+    def prepared_supported(self):
+        return bool(L.load().advx_prepared_supported(self._h))
+
     def live_range(self):
         """[lo, hi): flat indices of one sample that an image reaches; the rest is constant padding."""
         lo, hi = C.c_int64(), C.c_int64()

@@ -287,6 +287,38 @@ int32_t advx_fused_step_rows(const advx_plan* plan, int32_t* rows_after_fwd, int
 int32_t advx_fused_step_flush(advx_plan* plan, int32_t parity, int32_t norm_rows, float* stats,
                               float* scratch, void* stream);
 
+/* ------------------------------ prepared chain: the same pipelining for plans that DO resample
+ * Any one-stage plan (LLaVA from a non-native image such as the reference's 512x512 gray.png,
+ * Mllama, Qwen2-VL) without blur, crop or gradient accumulation: the backward of step t leaves
+ * s_{t+1}, its statistics partials and the processed canvas of step t+1 behind, so a step of
+ * attack_model.py:300-346,366-373 is four launches (emit | batch-reduce, tail, head) instead of
+ * the nine of advx_image_* + advx_emit + advx_collect + advx_update.
+ *   advx_prepared_fwd : out[B, out_numel] = canvas (+ sigma*noise), sigma = stats[QERR_STD] of the
+ *                       previous image; prepared == 0 (first step / p changed elsewhere) first
+ *                       builds s (s_buf), its partials (row set `parity`) and the canvas.
+ *   advx_prepared_bwd : grad_out -> sum_b -> resize^T, /std, image-fit', tanh', mask, ||g||,
+ *                       optimiser -> p; s_next = x0 + eps*tanh(p_new); reduces the statistics of
+ *                       the CURRENT image from row set `parity` (rows_in rows; rotates SIGMA <-
+ *                       QERR_STD first), leaves those of s_next in the other set, the next
+ *                       canvas in the workspace and the gradient norm in slot 7.  After it every
+ *                       slot refers to the step just taken.
+ * Row counts: advx_prepared_rows (after a preparing forward / after a backward).  `workspace` is
+ * the plan workspace (advx_plan_describe), kept by the caller across steps; `scratch`
+ * (advx_prepared_scratch_floats) needs no initialisation. */
+int32_t advx_prepared_supported(const advx_plan* plan);
+int64_t advx_prepared_scratch_floats(const advx_plan* plan);
+int32_t advx_prepared_rows(const advx_plan* plan, int32_t* rows_after_prepare, int32_t* rows_after_bwd);
+int32_t advx_prepared_fwd(advx_plan* plan, const float* p, const float* x0, float epsilon, int32_t batch,
+                          const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset,
+                          float* out, float* s_buf, int32_t prepared, int32_t parity, float* stats,
+                          float* scratch, float* workspace, int64_t workspace_floats, int32_t pad_mode,
+                          void* stream);
+int32_t advx_prepared_bwd(advx_plan* plan, const float* grad_out, int32_t batch, float* p, const float* x0,
+                          float epsilon, float imgfit_scale, const float* mask, float* m, float* v,
+                          float* grad_p, const advx_opt_scalars* opt, float* s_next, int32_t rows_in,
+                          int32_t parity, float* stats, float* scratch, float* workspace,
+                          int64_t workspace_floats, void* stream);
+
 /* -------------------------------------------------- data-parallel exchange
  * The reference has no data parallelism (one process, one model per GPU:
  * crossattack_models.py:244-258); the exchange added here is ONE all-reduce(sum) per step of the

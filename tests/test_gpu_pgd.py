@@ -268,3 +268,69 @@ def test_padding_tiles_kept_zero_is_the_same_attack(dev, kind):
         assert torch.equal(engines[0].p, engines[1].p)
     assert pad_seen
     assert engines[0].stats_dict() == engines[1].stats_dict()
+
+
+@pytest.mark.parametrize("kind", ["llava-down", "llava-up", "llava-identity", "mllama", "qwen2vl", "llava-sign"])
+def test_prepared_chain_matches_oracle(dev, kind):
+    """The four-launch chain for plans that resample (advx_prepared_fwd / advx_prepared_bwd):
+    same trajectory as the oracle's step, statistics included, for down- and up-sampling LLaVA
+    (the reference's own 512x512 -> 336 case in miniature), Mllama tiles and Qwen2-VL patches."""
+    Plan = _plans()
+    torch.manual_seed(31)
+    kw = dict(fused_mode="prepared", gamma=0.7, step_size=2)
+    if kind == "llava-down":
+        H, W = 96, 80
+        x0 = torch.rand(3, H, W) * 1.2 - 0.1
+        _trajectory(dev, x0, [LlavaOracle(48, 48)], [Plan.llava(H, W, 48, 48)], [5], 5,
+                    mask=P.create_mask("corner", 40, (3, H, W)), **kw)
+    elif kind == "llava-up":
+        x0 = torch.rand(3, 40, 52)
+        _trajectory(dev, x0, [LlavaOracle(64, 64)], [Plan.llava(40, 52, 64, 64)], [3], 4, **kw)
+    elif kind == "llava-identity":
+        x0 = torch.rand(3, 64, 64)
+        _trajectory(dev, x0, [LlavaOracle(64, 64)], [Plan.llava(64, 64, 64, 64)], [4], 4, **kw)
+    elif kind == "mllama":
+        H, W = 70, 100
+        x0 = torch.rand(3, H, W)
+        _trajectory(dev, x0, [MllamaOracle(tile=32)], [Plan.mllama(H, W, tile=32)], [4], 4,
+                    mask=P.create_mask("bottom_lines", 20, (3, H, W)), **kw)
+    elif kind == "qwen2vl":
+        H, W = 60, 90
+        x0 = torch.rand(3, H, W)
+        _trajectory(dev, x0, [Qwen2VLOracle(min_pixels=28 * 28 * 4, max_pixels=28 * 28 * 64)],
+                    [Plan.qwen2vl(H, W, min_pixels=28 * 28 * 4, max_pixels=28 * 28 * 64)], [3], 4, **kw)
+    else:
+        x0 = torch.rand(3, 50, 50)
+        _trajectory(dev, x0, [LlavaOracle(32, 32)], [Plan.llava(50, 50, 32, 32)], [2], 4, optimizer="sign", lr=1e-3,
+                    fused_mode="prepared")
+
+
+def test_prepared_is_the_default_for_one_stage_plans_and_agrees_with_generic(dev):
+    from adversarialvlm_amd import _lib as L
+    from adversarialvlm_amd.pgd import PixelPGD
+    Plan = _plans()
+    H, W, B = 96, 80, 4
+    x0 = torch.rand(3, H, W, generator=torch.Generator().manual_seed(41)).to(dev)
+    g = (torch.randn(B, 3 * 48 * 48, generator=torch.Generator().manual_seed(42)) * 0.01).to(dev)
+    engines = {}
+    for name, kw in (("prepared", {}), ("generic", dict(allow_fused=False))):
+        eng = PixelPGD(x0, [Plan.llava(H, W, 48, 48)], seed=9, **kw)
+        assert eng.mode == name
+        outs = []
+        for _ in range(4):
+            outs.append(eng.forward(B)[0].clone())
+            eng.backward_update([g])
+        engines[name] = (eng, outs)
+    a, b = engines["prepared"], engines["generic"]
+    for oa, ob in zip(a[1], b[1]):
+        assert rel_err(oa.cpu(), ob.cpu()) < 1e-6              # same Philox counters, same canvas
+    assert rel_err(a[0].p.cpu(), b[0].p.cpu()) < 1e-6
+    sa, sb = a[0].stats_dict(), b[0].stats_dict()
+    for k in sa:
+        assert sa[k] == pytest.approx(sb[k], rel=1e-5, abs=1e-12), k
+    # a two-stage plan, blur, crop or accumulation keep the generic chain
+    assert PixelPGD(x0, [Plan.phi3(H, W)]).mode == "generic"
+    assert PixelPGD(x0, [Plan.llava(H, W, 48, 48)], blur_kernel=5).mode == "generic"
+    assert PixelPGD(x0, [Plan.llava(H, W, 48, 48)], grad_accum_steps=2).mode == "generic"
+    with pytest.raises(L.AdvxError):
+        PixelPGD(x0, [Plan.phi3(H, W)], fused_mode="prepared")
