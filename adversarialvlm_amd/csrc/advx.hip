@@ -630,7 +630,12 @@ static int32_t launch_batch_reduce(const float* g, int batch, long long n, float
     long long q_lo = live_lo >> 2, q_hi = (live_hi + 3) >> 2;
     if (q_hi <= q_lo) return ADVX_OK;
     int blocks = (int)((q_hi - q_lo + kWave - 1) / kWave);
-    hipLaunchKernelGGL(k_batch_reduce, dim3(blocks), dim3(kBlock), 0, st, g, batch, n, out, q_lo, q_hi);
+    // what is read here, B x (live columns) x 16 bytes: beyond the Infinity Cache it is streamed past it
+    const double read_bytes = (double)batch * (double)(q_hi - q_lo) * 16.0;
+    if (read_bytes > 256.0 * 1024 * 1024)
+      hipLaunchKernelGGL(k_batch_reduce<3>, dim3(blocks), dim3(kBlock), 0, st, g, batch, n, out, q_lo, q_hi);
+    else
+      hipLaunchKernelGGL(k_batch_reduce<0>, dim3(blocks), dim3(kBlock), 0, st, g, batch, n, out, q_lo, q_hi);
   } else {
     // rows are not 16-byte aligned: scalar columns (test-sized inputs only)
     hipLaunchKernelGGL(k_batch_reduce_scalar, dim3(grid_for(n)), dim3(kBlock), 0, st, g, batch, n, out);
