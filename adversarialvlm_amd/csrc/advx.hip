@@ -1436,7 +1436,9 @@ PreparedScratch carve_prepared(const advx_plan* p, float* scratch) {
   PreparedScratch f;
   const long long n = 3LL * p->info.in_h * p->info.in_w;
   f.tail_blocks = (int)((n + kBlock - 1) / kBlock);
-  f.prep_blocks = grid_for(n, kMaxStatBlocks);
+  // the preparing launch uses the row partition of k_plan_tail (one row per 256 pixels): a run
+  // that re-prepares (first step, resume) then sums exactly what an uninterrupted run sums
+  f.prep_blocks = f.tail_blocks;
   const size_t rows = (size_t)std::max(f.tail_blocks, f.prep_blocks);
   double* d = reinterpret_cast<double*>(scratch);
   f.img_rows[0] = d;
@@ -1461,7 +1463,7 @@ extern "C" int64_t advx_prepared_scratch_floats(const advx_plan* p) {
 extern "C" int32_t advx_prepared_rows(const advx_plan* p, int32_t* rows_after_prepare, int32_t* rows_after_bwd) {
   REQUIRE(p && rows_after_prepare && rows_after_bwd, ADVX_E_BADARG, "advx_prepared_rows: null argument");
   const long long n = 3LL * p->info.in_h * p->info.in_w;
-  *rows_after_prepare = grid_for(n, kMaxStatBlocks);
+  *rows_after_prepare = (int32_t)((n + kBlock - 1) / kBlock);
   *rows_after_bwd = (int32_t)((n + kBlock - 1) / kBlock);
   return ADVX_OK;
 }

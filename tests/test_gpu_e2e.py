@@ -79,7 +79,7 @@ def test_two_pgd_steps_loss_and_grad_parity(batch, chain):
 
 
 def _gray(tmp_path, size=56):
-    path = os.path.join(tmp_path, "gray.png")
+    path = os.path.join(tmp_path, f"gray{size}.png")
     Image.fromarray(np.full((size, size, 3), 128, np.uint8)).save(path)
     return path
 
@@ -150,18 +150,22 @@ def _kw(tmp, name, iters, **extra):
     return kw
 
 
-def test_resume_continues_bit_for_bit(tmp_path):
+@pytest.mark.parametrize("size,mode", [(56, "pair"), (70, "prepared")])
+def test_resume_continues_bit_for_bit(tmp_path, size, mode):
     """optimiser moments, schedule, RNG streams and noise counters are saved, so
-    4 iterations + resume + 3 more equal 7 iterations in one go, bit for bit."""
+    4 iterations + resume + 3 more equal 7 iterations in one go, bit for bit - in the fused pair
+    (native-size image) and in the prepared chain (70x70 image resized to the model's 56x56)."""
     from adversarialvlm_amd import attack_model
     tmp = str(tmp_path)
-    attack_model.train(**_kw(tmp, "full", 7))
-    attack_model.train(**_kw(tmp, "part", 4))
+    img = _gray(tmp, size)
+    eng, _ = attack_model.train(**_kw(tmp, "full", 7, img_orig=img, return_engine=True))
+    assert eng.mode == mode
+    attack_model.train(**_kw(tmp, "part", 4, img_orig=img))
     # iteration 3 (save_steps=3) wrote state_iter_4.pt: resume from it and run iterations 4..6
-    attack_model.train(**_kw(tmp, "rest", 7, resume_from=os.path.join(tmp, "part", "state_iter_4.pt")))
+    attack_model.train(**_kw(tmp, "rest", 7, img_orig=img, resume_from=os.path.join(tmp, "part", "state_iter_4.pt")))
     a = np.fromfile(os.path.join(tmp, "full", "optimized_image_iter_final.bin"), dtype=np.float32)
     b = np.fromfile(os.path.join(tmp, "rest", "optimized_image_iter_final.bin"), dtype=np.float32)
-    assert np.array_equal(a, b)
+    assert a.size == 3 * size * size and np.array_equal(a, b)
 
 
 def test_generation_probe_writes_reference_csv(tmp_path):
