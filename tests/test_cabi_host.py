@@ -172,3 +172,32 @@ def test_layout_index_maps_vs_reference_permutes(lib):
         (i,) = p.out_index(0, c, y, x)
         assert i >= T and int(local[i - T]) == int(canvas[c, y, x])
     assert p.out_index(1, 2, 335, 335) == [T - 1]
+
+
+@pytest.mark.parametrize("kind,hw", [("mllama", (336, 336)), ("mllama", (300, 700)), ("phi3", (336, 336)), ("phi3", (500, 900)),
+                                     ("llava", (96, 80)), ("qwen2vl", (120, 200))])
+def test_live_range_is_where_the_oracle_output_is_not_padding(lib, kind, hw):
+    """advx_plan_live_range: outside [lo, hi) the processors return their constant zero tiles
+    (llama32processor.py:344-346, phi3processor.py:232-235) - whose gradient the batch
+    reduction skips and which ADVX_PAD_KEEP never rewrites; inside it an image (or the padding
+    of its canvas, which is normalised and therefore not zero) is written."""
+    from adversarialvlm_amd.plan import Plan
+    from oracle.processors import LlavaOracle, MllamaOracle, Phi3Oracle, Qwen2VLOracle
+    H, W = hw
+    x = torch.rand(3, H, W, generator=torch.Generator().manual_seed(H + W)) * 0.8 + 0.1
+    if kind == "mllama":
+        plan, out = Plan.mllama(H, W), MllamaOracle().process(x)["pixel_values"]
+    elif kind == "phi3":
+        plan, out = Plan.phi3(H, W), Phi3Oracle().process(x)["pixel_values"]
+    elif kind == "llava":
+        plan, out = Plan.llava(H, W, 48, 48), LlavaOracle(48, 48).process(x)["pixel_values"]
+    else:
+        plan = Plan.qwen2vl(H, W, min_pixels=28 * 28 * 4, max_pixels=28 * 28 * 64)
+        out = Qwen2VLOracle(min_pixels=28 * 28 * 4, max_pixels=28 * 28 * 64).process(x)["pixel_values"]
+    flat = out.reshape(-1)
+    lo, hi = plan.live_range()
+    assert flat.numel() == plan.out_numel and 0 <= lo < hi <= plan.out_numel
+    assert not bool((flat[:lo] != 0).any()) and not bool((flat[hi:] != 0).any())
+    assert float((flat[lo:hi] != 0).float().mean()) > 0.99
+    if kind in ("llava", "qwen2vl"):
+        assert (lo, hi) == (0, plan.out_numel)
