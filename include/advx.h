@@ -328,8 +328,10 @@ int32_t advx_prepared_bwd(advx_plan* plan, const float* grad_out, int32_t batch,
  *   - every rank creates ONE exchange segment in uncached device memory
  *     [flags | send | recv], exports its HIP IPC handle (64 bytes; the caller carries the
  *     handles between the processes) and maps the segments of all peers over xGMI;
- *   - advx_comm_allreduce = one reduce launch + the consumer's wait, all with constant
- *     arguments: the reduce kernel meets its peers on entry ("send complete"), rank r sums the
+ *   - advx_comm_allreduce = one reduce launch + the consumer's wait (the exchange number
+ *     travels as a kernel argument, so these launches are NOT graph-capturable; every rank must
+ *     make the same sequence of calls): the reduce kernel meets its peers on entry ("send
+ *     complete"), rank r sums the
  *     r-th slice of all send buffers IN RANK ORDER (every replica gets the same bits), posts
  *     the sum into the recv buffer of every peer and signals "slices posted"; whoever reads
  *     recv waits for that signal first (advx_fused_bwd_dp: inside the update kernel; plain
