@@ -699,9 +699,21 @@ struct CropTables {
   DStage st;
 };
 
+// The backward of a step needs the tables its forward built: same window, same scratch, same
+// stream.  The host remembers the last build and advx_image_bwd skips the launch when it matches
+// (the tables sit right behind the statistics partials in both calls, so nothing in between
+// overwrites them).
+struct CropCache {
+  const float* where = nullptr;
+  int H = 0, W = 0, crop[4] = {0, 0, 0, 0};
+  hipStream_t stream = nullptr;
+};
+thread_local CropCache g_crop_cache;
+
 // carve the crop's tap tables out of scratch and launch their device-side construction
-int32_t build_crop_stage(int H, int W, const int32_t* crop, Bump& b, hipStream_t stq, DStage* out) {
+int32_t build_crop_stage(int H, int W, const int32_t* crop, Bump& b, hipStream_t stq, DStage* out, bool may_reuse = false) {
   int ci = crop[0], cj = crop[1], ch = crop[2], cw = crop[3];
+  const float* where = b.base + b.used;
   REQUIRE(ch > 0 && cw > 0 && ci >= 0 && cj >= 0 && ci + ch <= H && cj + cw <= W, ADVX_E_BADARG, "crop window outside the image");
   int sh = tap_stride(ADVX_MODE_AA_BILINEAR, ch, H), sw = tap_stride(ADVX_MODE_AA_BILINEAR, cw, W);
   auto tbound = [](int in_size, int out_size) {
@@ -727,9 +739,16 @@ int32_t build_crop_stage(int H, int W, const int32_t* crop, Bump& b, hipStream_t
     f[ax] = DevTaps{outs[ax], strides[ax], a[ax].start, a[ax].count, a[ax].w};
     t[ax] = DevTaps{ins[ax], tstrides[ax], a[ax].tstart, a[ax].tcount, a[ax].tw};
   }
-  int rows = std::max(H + ch, W + cw);
-  hipLaunchKernelGGL(k_build_taps, dim3((rows + kBlock - 1) / kBlock, 2), dim3(kBlock), 0, stq, a[0], a[1]);
-  LAUNCH_CHECK();
+  CropCache& cc = g_crop_cache;
+  const bool same = may_reuse && cc.where == where && cc.H == H && cc.W == W && cc.stream == stq && cc.crop[0] == ci &&
+                    cc.crop[1] == cj && cc.crop[2] == ch && cc.crop[3] == cw;
+  if (!same) {
+    int rows = std::max(H + ch, W + cw);
+    hipLaunchKernelGGL(k_build_taps, dim3((rows + kBlock - 1) / kBlock, 2), dim3(kBlock), 0, stq, a[0], a[1]);
+    LAUNCH_CHECK();
+    cc.where = where; cc.H = H; cc.W = W; cc.stream = stq;
+    cc.crop[0] = ci; cc.crop[1] = cj; cc.crop[2] = ch; cc.crop[3] = cw;
+  }
   DStage D;
   std::memset(&D, 0, sizeof(D));
   D.mode = ADVX_MODE_AA_BILINEAR; D.src_h = ch; D.src_w = cw; D.res_h = H; D.res_w = W; D.can_h = H; D.can_w = W;
@@ -769,6 +788,11 @@ extern "C" int32_t advx_image_fwd(const float* p, const float* x0, int32_t H, in
   const long long n = 3LL * H * W;
   Bump b{scratch};
   double* partials = reinterpret_cast<double*>(b.take(partial_floats(H, W)));
+  DStage crop_stage;
+  if (crop) {
+    int32_t rc = build_crop_stage(H, W, crop, b, st, &crop_stage);
+    if (rc) return rc;
+  }
   int nblk;
   if (blur_k > 0) {
     int32_t rc = check_blur(H, W, blur_k, blur_sigma);
@@ -788,11 +812,8 @@ extern "C" int32_t advx_image_fwd(const float* p, const float* x0, int32_t H, in
   hipLaunchKernelGGL(k_finalize_image, dim3(1), dim3(kBlock), 0, st, partials, nblk, n, stats);
   LAUNCH_CHECK();
   if (crop) {
-    DStage D;
-    int32_t rc = build_crop_stage(H, W, crop, b, st, &D);
-    if (rc) return rc;
     const float* src = s + (size_t)crop[0] * W + crop[1];
-    hipLaunchKernelGGL(k_stage_fwd, dim3(grid_for(n)), dim3(kBlock), 0, st, D, src, (long long)H * W, W, argument);
+    hipLaunchKernelGGL(k_stage_fwd, dim3(grid_for(n)), dim3(kBlock), 0, st, crop_stage, src, (long long)H * W, W, argument);
     LAUNCH_CHECK();
   } else if (argument && argument != s) {
     HIP_TRY(hipMemcpyAsync(argument, s, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
@@ -812,14 +833,12 @@ extern "C" int32_t advx_image_bwd(const float* p, const float* s, const float* g
   (void)b.take(partial_floats(H, W));
   const float* gs = garg;
   if (crop) {
-    float* gsbuf = b.take(n);
     DStage D;
-    int32_t rc = build_crop_stage(H, W, crop, b, st, &D);
+    int32_t rc = build_crop_stage(H, W, crop, b, st, &D, /*may_reuse=*/true);   // the forward's tables, if still there
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(gsbuf, 0, sizeof(float) * n, st));
-    float* dst = gsbuf + (size_t)crop[0] * W + crop[1];
-    hipLaunchKernelGGL(k_resize_bwd_plain, dim3(grid_for(3LL * crop[2] * crop[3])), dim3(kBlock), 0, st, D, garg, dst,
-                       (long long)H * W, W);
+    float* gsbuf = b.take(n);
+    // gradient of the whole image: transposed resize inside the window, exact zeros outside
+    hipLaunchKernelGGL(k_crop_bwd, dim3(grid_for(n)), dim3(kBlock), 0, st, D, garg, gsbuf, H, W, crop[0], crop[1]);
     LAUNCH_CHECK();
     gs = gsbuf;
   }
@@ -1217,9 +1236,8 @@ extern "C" int32_t advx_crop_resize_bwd(const float* gdst, int32_t H, int32_t W,
   DStage D;
   int32_t rc = build_crop_stage(H, W, crop, b, (hipStream_t)stream, &D);
   if (rc) return rc;
-  HIP_TRY(hipMemsetAsync(gsrc, 0, sizeof(float) * 3 * (size_t)H * W, (hipStream_t)stream));
-  hipLaunchKernelGGL(k_resize_bwd_plain, dim3(grid_for(3LL * crop[2] * crop[3])), dim3(kBlock), 0, (hipStream_t)stream, D,
-                     gdst, gsrc + (size_t)crop[0] * W + crop[1], (long long)H * W, W);
+  hipLaunchKernelGGL(k_crop_bwd, dim3(grid_for(3LL * H * W)), dim3(kBlock), 0, (hipStream_t)stream, D, gdst, gsrc, H, W,
+                     crop[0], crop[1]);
   LAUNCH_CHECK();
   return ADVX_OK;
 }

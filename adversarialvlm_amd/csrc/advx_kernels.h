@@ -470,28 +470,33 @@ __global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, DPlan pl, int s
   }
 }
 
-// plain-canvas variants used by the crop (no layout, gradient given in canvas order)
-__global__ void __launch_bounds__(kBlock) k_resize_bwd_plain(DStage st, const float* __restrict__ gcan,
-                                                             float* __restrict__ gsrc, long long gsrc_cstride,
-                                                             int gsrc_rstride) {
-  long long n = 3LL * st.src_h * st.src_w;
+// adjoint of the random-resized crop (attack_model.py:307-310): the gradient arrives in the
+// canvas order of the resized window (H x W); one thread per pixel of the WHOLE image writes the
+// transposed resize inside the window (ci, cj, src_h, src_w) and exact zeros outside it
+__global__ void __launch_bounds__(kBlock) k_crop_bwd(DStage st, const float* __restrict__ gcan, float* __restrict__ gimg,
+                                                     int H, int W, int ci, int cj) {
+  const unsigned plane = (unsigned)H * (unsigned)W;
+  const long long n = 3LL * plane;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
-    int c = (int)((unsigned)i / ((unsigned)st.src_h * (unsigned)st.src_w));
-    int rem = (int)((unsigned)i - (unsigned)c * (unsigned)st.src_h * (unsigned)st.src_w);
-    int ys = rem / st.src_w, xs = rem - ys * st.src_w;
-    int oy = st.tth.start[ys], oyc = st.tth.count[ys];
-    int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
-    const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
-    const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
-    const float* gp = gcan + (size_t)c * st.can_h * st.can_w;
+    const int c = (int)((unsigned)i / plane);
+    const unsigned rem = (unsigned)i - (unsigned)c * plane;
+    const int y = (int)(rem / (unsigned)W), x = (int)(rem - (unsigned)y * (unsigned)W);
+    const int ys = y - ci, xs = x - cj;
     float v = 0.0f;
-    for (int a = 0; a < oyc; ++a) {
-      float h = 0.0f;
-      for (int b = 0; b < oxc; ++b) h += wx[b] * gp[(size_t)(oy + a) * st.can_w + ox + b];
-      v += wy[a] * h;
+    if (ys >= 0 && ys < st.src_h && xs >= 0 && xs < st.src_w) {
+      int oy = st.tth.start[ys], oyc = st.tth.count[ys];
+      int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
+      const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
+      const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
+      const float* gp = gcan + (size_t)c * st.can_h * st.can_w;
+      for (int a = 0; a < oyc; ++a) {
+        float h = 0.0f;
+        for (int b = 0; b < oxc; ++b) h += wx[b] * gp[(size_t)(oy + a) * st.can_w + ox + b];
+        v += wy[a] * h;
+      }
     }
-    gsrc[(size_t)c * gsrc_cstride + (size_t)ys * gsrc_rstride + xs] = v;
+    gimg[i] = v;
   }
 }
 

@@ -179,7 +179,10 @@ int32_t advx_collect(advx_plan* plan, const float* grad_out, int32_t batch, floa
  *   scratch: float[advx_image_scratch_floats(H,W,blur_k)].
  * advx_image_bwd : the autograd of the above (attack_model.py:332): grad_argument ->
  *     grad wrt p, plus imgfit_scale * d(image_fit_loss)/dp; written (or accumulated)
- *     into grad_p UNMASKED (the mask is applied by advx_update, attack_model.py:336). */
+ *     into grad_p UNMASKED (the mask is applied by advx_update, attack_model.py:336).
+ *     Called with the scratch, stream and crop window of the preceding advx_image_fwd it reuses
+ *     the crop's tap tables that call left in `scratch` (any other combination rebuilds them):
+ *     leave `scratch` alone between the two calls of a step. */
 int64_t advx_image_scratch_floats(int32_t H, int32_t W, int32_t blur_k);
 int32_t advx_image_fwd(const float* p, const float* x0, int32_t H, int32_t W, float epsilon,
                        int32_t blur_k, float blur_sigma, const int32_t* crop_ijhw,
