@@ -129,7 +129,7 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
           questions_file=None, test_questions_file=None, answers_file=None, optimizer="adamw", log_every=1,
           use_wandb=False, seed=0, base_path="./runs", components=None, return_engine=False,
           generation_probe=False, resume_from=None, pixel_io="float32", resaved_loss_every=0,
-          noise_on_padding=True):
+          noise_on_padding=True, suffix_only_ce=False):
     """pixel_io: "float32" hands the VLM fp32 pixel_values as the reference does; "model" lets
     the fused pair write them in model.dtype (the cast the vision tower's patch embedding applies
     first anyway) and read the half gradient directly - same numbers, half the traffic."""
@@ -228,9 +228,13 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
                                       crop=crop)[0]                                         # :300-321 (HIP)
         pixel_values.requires_grad_(True)
         inputs["pixel_values"] = pixel_values
-        outputs = model(**inputs)                                                           # :324 (PyTorch-ROCm)
-        logits = outputs.logits[:, :-1, :]
-        loss = inputs_processor.get_loss(logits)                                            # :327
+        if suffix_only_ce:
+            # same loss, the VLM computes the logits of the target positions only (HIP log-softmax + NLL)
+            loss = inputs_processor.get_loss_suffix_only(model, inputs)
+        else:
+            outputs = model(**inputs)                                                       # :324 (PyTorch-ROCm)
+            logits = outputs.logits[:, :-1, :]
+            loss = inputs_processor.get_loss(logits)                                        # :327
         loss = -loss if refuse_flag else loss
         (loss * engine.loss_scale(0)).backward()                                            # :330-332
         stepped = engine.backward_update([pixel_values.grad])                               # :335-346, 366-373 (HIP)
@@ -329,6 +333,9 @@ def build_parser():
     p.add_argument("--no_noise_on_padding", dest="noise_on_padding", action="store_false",
                    help="keep the constant padding tiles of Mllama / Phi-3.5 exact zeros instead of adding noise to them "
                         "as the reference does (both models mask those tiles out)")
+    p.add_argument("--suffix_only_ce", action="store_true",
+                   help="compute the logits of the target positions only (logits_to_keep) and their cross entropy in "
+                        "the HIP library: same loss, no [B, S, V] logits tensor")
     p.add_argument("--pixel_io", type=str, default="float32", choices=["float32", "model"],
                    help="dtype of pixel_values at the VLM boundary (model = the VLM's own half dtype)")
     return p

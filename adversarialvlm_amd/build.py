@@ -6,7 +6,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = [os.path.join(CSRC, "advx.hip")]
-HEADERS = [os.path.join(CSRC, f) for f in ("advx_taps.h", "advx_device.h", "advx_kernels.h", "advx_comm.h")] + [
+HEADERS = [os.path.join(CSRC, f) for f in ("advx_taps.h", "advx_device.h", "advx_kernels.h", "advx_comm.h", "advx_ce.h")] + [
     os.path.join(os.path.dirname(_HERE), "include", "advx.h")]
 OUT = os.path.join(_HERE, "libadvx_hip.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]

@@ -13,6 +13,7 @@
 
 #include "../../include/advx.h"
 #include "advx_kernels.h"
+#include "advx_ce.h"
 
 using namespace advx;
 
@@ -1563,6 +1564,46 @@ extern "C" int32_t advx_prepared_bwd(advx_plan* p, const float* grad_out, int32_
   hipLaunchKernelGGL(k_plan_head, dim3(grid_for(3LL * D.can_h * D.can_w)), dim3(kBlock), 0, st, D, (const float*)s_next,
                      (long long)D.src_h * D.src_w, D.src_w, ws + p->dplan.canvas_off[0], (const double*)f.norm_rows,
                      f.tail_blocks, stats);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
+// ------------------------------------------------------ suffix-only cross entropy (advx_ce.h)
+extern "C" int32_t advx_ce_fwd(const void* logits, int32_t io_dtype, int64_t batch_stride, int64_t row_stride, int32_t T,
+                               const int64_t* targets, int64_t rows, int64_t vocab, float* row_loss, float* row_lse,
+                               float* mean_and_n, void* stream) {
+  REQUIRE(logits && targets && row_loss && row_lse && mean_and_n, ADVX_E_BADARG, "advx_ce_fwd: null argument");
+  REQUIRE(io_dtype >= 0 && io_dtype <= 2, ADVX_E_BADARG, "advx_ce_fwd: io_dtype must be ADVX_IO_F32 / F16 / BF16");
+  REQUIRE(T >= 1 && rows >= 1 && rows % T == 0 && rows < (1LL << 31) && vocab >= 1, ADVX_E_SHAPE, "advx_ce_fwd: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const long long* tg = reinterpret_cast<const long long*>(targets);
+#define ADVX_CE(IO)                                                                                               \
+  hipLaunchKernelGGL(k_ce_fwd<IO>, dim3((unsigned)rows), dim3(kBlock), 0, st, logits, (long long)batch_stride,    \
+                     (long long)row_stride, (int)T, tg, (long long)vocab, row_loss, row_lse)
+  if (io_dtype == 0) ADVX_CE(0); else if (io_dtype == 1) ADVX_CE(1); else ADVX_CE(2);
+#undef ADVX_CE
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_ce_mean, dim3(1), dim3(kBlock), 0, st, (const float*)row_loss, tg, (long long)rows, (long long)vocab,
+                     mean_and_n);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_ce_bwd(const void* logits, int32_t io_dtype, int64_t batch_stride, int64_t row_stride, int32_t T,
+                               int32_t K, const int64_t* targets, int64_t rows, int64_t vocab, const float* row_lse,
+                               const float* mean_and_n, const float* upstream, void* grad, void* stream) {
+  REQUIRE(logits && targets && row_lse && mean_and_n && upstream && grad, ADVX_E_BADARG, "advx_ce_bwd: null argument");
+  REQUIRE(io_dtype >= 0 && io_dtype <= 2, ADVX_E_BADARG, "advx_ce_bwd: io_dtype must be ADVX_IO_F32 / F16 / BF16");
+  REQUIRE(T >= 1 && K >= T && rows >= 1 && rows % T == 0 && (rows / T) * K < (1LL << 31) && vocab >= 1, ADVX_E_SHAPE,
+          "advx_ce_bwd: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const long long* tg = reinterpret_cast<const long long*>(targets);
+  const unsigned blocks = (unsigned)((rows / T) * K);
+#define ADVX_CE(IO)                                                                                              \
+  hipLaunchKernelGGL(k_ce_bwd<IO>, dim3(blocks), dim3(kBlock), 0, st, logits, (long long)batch_stride,            \
+                     (long long)row_stride, (int)T, (int)K, tg, (long long)vocab, row_lse, mean_and_n, upstream, grad)
+  if (io_dtype == 0) ADVX_CE(0); else if (io_dtype == 1) ADVX_CE(1); else ADVX_CE(2);
+#undef ADVX_CE
   LAUNCH_CHECK();
   return ADVX_OK;
 }

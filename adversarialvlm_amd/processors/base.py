@@ -134,6 +134,15 @@ class AdvInputsBase:
         suffix = logits[:, -self.suffix_length:-self.shift, :].permute(0, 2, 1)
         return F.cross_entropy(suffix, self.target)
 
+    def get_loss_suffix_only(self, model, inputs) -> torch.Tensor:
+        """The same loss without the [B, S, V] logits tensor: the model computes
+        its last suffix_length + 1 positions only (left-padded batches end with the target), and
+        the supervised ones - positions [-suffix_length-1, -shift-1) of the full sequence, i.e.
+        the first suffix_length - shift kept ones - go through the HIP log-softmax + NLL."""
+        from ..ce import suffix_cross_entropy
+        out = model(**inputs, logits_to_keep=self.suffix_length + 1)
+        return suffix_cross_entropy(out.logits, self.target)
+
     # ---- cached batch assembly (replaces llavaprocessor.py:80-108)
     def _sample(self, question: str) -> dict:
         key = (question, self.target_text)

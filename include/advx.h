@@ -366,6 +366,23 @@ int32_t advx_fused_bwd_dp(advx_plan* plan, advx_comm* comm, const void* grad_out
                           float* s_next, float* v_buf, float* stats, float* scratch, double timeout_s,
                           void* stream);
 
+/* ------------------------------------ suffix-only cross entropy
+ * The loss of attack_model.py:324-328 / llavaprocessor.py:73-78 (`logits[:, -suffix:-shift]`
+ * against the target tokens, mean reduction) on the logits of the TARGET positions only: the
+ * host asks the VLM for its last K = suffix_len + 1 positions (`logits_to_keep`), so the
+ * [B, S, V] logits tensor of the reference never exists.  logits: [B, K, V] in the model's
+ * dtype (element strides batch_stride / row_stride), the first T positions of every row block
+ * supervised by targets[B*T] (int64; values outside [0, V) are ignored).
+ *   advx_ce_fwd : row_loss[B*T], row_lse[B*T], mean_and_n = {mean loss, number of valid rows}.
+ *   advx_ce_bwd : grad[B, K, V] = (softmax - onehot) * upstream[0] / n_valid on the T supervised
+ *                 positions, zeros on the others; same layout as logits, may alias it. */
+int32_t advx_ce_fwd(const void* logits, int32_t io_dtype, int64_t batch_stride, int64_t row_stride, int32_t T,
+                    const int64_t* targets, int64_t rows, int64_t vocab, float* row_loss, float* row_lse,
+                    float* mean_and_n, void* stream);
+int32_t advx_ce_bwd(const void* logits, int32_t io_dtype, int64_t batch_stride, int64_t row_stride, int32_t T,
+                    int32_t K, const int64_t* targets, int64_t rows, int64_t vocab, const float* row_lse,
+                    const float* mean_and_n, const float* upstream, void* grad, void* stream);
+
 /* ---------------------------------------------------------------- profiling
  * Per-kernel device time of the B*P_out movers (k_fused_fwd, k_fused_bwd, k_fused_step):
  * between begin and end each of their launches carries its own start/stop HIP event pair on

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--micro", type=int, default=8)
     ap.add_argument("--model", type=str, default="synthetic/llava-1.5-7b")
+    ap.add_argument("--suffix-only-ce", action="store_true", help="logits of the target positions only + HIP cross entropy")
+    ap.add_argument("--pixel-io", default="float32", choices=["float32", "model"])
     args = ap.parse_args()
     from adversarialvlm_amd.pgd import PixelPGD
     from adversarialvlm_amd.processors import load_components
@@ -41,7 +43,8 @@ def main():
     size = proc.image_processor.crop_size["height"]
     ap_ = DiffProc(proc.image_processor, dev)
     x0 = torch.rand(3, size, size, generator=torch.Generator().manual_seed(0)).to(dev)
-    eng = PixelPGD(x0, [ap_.plan_for(size, size)], seed=1)
+    eng = PixelPGD(x0, [ap_.plan_for(size, size)], seed=1,
+                   io_dtype=model.dtype if args.pixel_io == "model" else torch.float32)
     qs = [" ".join(f"w{random.Random(i).randint(0, 9999)}" for _ in range(30)) for i in range(97)]
     ip = AdvInputs(questions=qs, test_questions=["t"], batch_size=args.batch, original_image=None, processor=proc,
                    device=dev, target_text="a b c d e f g h", rng=random.Random(0))
@@ -59,10 +62,13 @@ def main():
         tgt_full = ip.target
         for i in range(0, B, mb):
             chunk = pv[i:i + mb].detach().requires_grad_(True)
-            out = model(input_ids=inputs["input_ids"][i:i + mb], attention_mask=inputs["attention_mask"][i:i + mb],
-                        pixel_values=chunk.to(model.dtype))
+            mb_inputs = dict(input_ids=inputs["input_ids"][i:i + mb], attention_mask=inputs["attention_mask"][i:i + mb],
+                             pixel_values=chunk.to(model.dtype))
             ip.target = tgt_full[i:i + mb]
-            loss = ip.get_loss(out.logits[:, :-1, :].float())
+            if args.suffix_only_ce:
+                loss = ip.get_loss_suffix_only(model, mb_inputs)
+            else:
+                loss = ip.get_loss(model(**mb_inputs).logits[:, :-1, :].float())
             ip.target = tgt_full
             (loss * (mb / B) * eng.loss_scale(0)).backward()        # mean over the whole batch
             grad[i:i + mb] = chunk.grad
@@ -82,7 +88,8 @@ def main():
     flops = 4.0 * n_params * B * S          # fwd 2*P*T + bwd-to-input 2*P*T (weights frozen), attention excluded
     print(json.dumps({"e2e_steps_per_s": round(1.0 / dt, 4), "e2e_prompt_steps_per_s": round(B / dt, 2),
                       "s_per_step": round(dt, 3), "batch": B, "micro_batch": mb, "seq_len": S, "params": n_params,
-                      "model": args.model, "dtype": str(model.dtype), "approx_model_tflops": round(flops / dt / 1e12, 1),
+                      "model": args.model, "dtype": str(model.dtype), "suffix_only_ce": bool(args.suffix_only_ce),
+                      "pixel_io": args.pixel_io, "approx_model_tflops": round(flops / dt / 1e12, 1),
                       "losses": [round(v, 4) for v in losses], "load_s": round(t_load, 1),
                       "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
 
