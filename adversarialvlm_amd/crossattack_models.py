@@ -48,7 +48,8 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
           attack_norm=0.5, use_gaussian_blur=False, gblur_kernel_size=5, use_local_crop=False, crop_scale_min=0.6,
           crop_scale_max=1.0, crop_ratio_min=0.75, crop_ratio_max=1.33,
           questions_file=None, test_questions_file=None, answers_file=None, log_every=1, use_wandb=False, seed=0,
-          base_path="./runs", return_engine=False, resaved_loss_every=0, noise_on_padding=True):
+          base_path="./runs", return_engine=False, resaved_loss_every=0, noise_on_padding=True,
+          suffix_only_ce=False):
     if clamp_method != "tanh":
         raise NotImplementedError("Clamping method except tanh are not implemented yet.")
     if mask_type == "random_square":
@@ -158,8 +159,11 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
             step_inputs.append(inputs)
             pv.requires_grad_(True)
             inputs["pixel_values"] = pv
-            logits = model(**inputs).logits[:, :-1, :]
-            model_loss = ip.get_loss(logits)
+            if suffix_only_ce:
+                model_loss = ip.get_loss_suffix_only(model, inputs)      # logits of the target positions only
+            else:
+                logits = model(**inputs).logits[:, :-1, :]
+                model_loss = ip.get_loss(logits)
             (model_loss * engine.loss_scale(k)).backward()
             grads.append(pv.grad)
             losses.append(model_loss.detach())
@@ -245,6 +249,8 @@ def build_parser():
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no_noise_on_padding", dest="noise_on_padding", action="store_false",
                    help="keep the constant padding tiles of Mllama / Phi-3.5 exact zeros (the reference adds noise there)")
+    p.add_argument("--suffix_only_ce", action="store_true",
+                   help="logits of the target positions only (logits_to_keep) + HIP cross entropy: same loss, no [B,S,V] tensor")
     p.add_argument("--resaved_loss_every", type=int, default=0,
                    help="log loss_resaved (every model's forward on the re-saved image) every N iterations; 0 = off")
     return p
