@@ -94,6 +94,10 @@ SIGNATURES = {
     "advx_prepared_fwd": (_I32, [_P, _P, _P, _F, _I32, _P, _I32, _U64, _U64, _P, _P, _I32, _I32, _P, _P, _P, _I64, _I32, _P]),
     "advx_prepared_bwd": (_I32, [_P, _P, _I32, _P, _P, _F, _F, _P, _P, _P, _P, C.POINTER(OptScalars), _P, _I32, _I32, _P, _P,
                                  _P, _I64, _P]),
+    "advx_prepared_bwd_grad": (_I32, [_P, _P, _I32, _P, _P, _F, _F, _P, _I32, _I32, _P, _P, _P, _I64, _P]),
+    "advx_prepared_update": (_I32, [_P, _P, _P, _P, _P, _P, _P, _F, C.POINTER(OptScalars), _P, _I32, _P, _P, _P, _I64, _P]),
+    "advx_prepared_bwd_dp": (_I32, [_P, _P, _P, _I32, _P, _P, _F, _F, _P, _P, _P, C.POINTER(OptScalars), _P, _I32, _I32, _P,
+                                    _P, _P, _I64, C.c_double, _P]),
     "advx_comm_create": (_I32, [_I32, _I32, _I64, _I32, C.POINTER(_P)]),
     "advx_comm_export": (_I32, [_P, _P]),
     "advx_comm_connect": (_I32, [_P, _P]),

@@ -1568,6 +1568,101 @@ extern "C" int32_t advx_prepared_bwd(advx_plan* p, const float* grad_out, int32_
   return ADVX_OK;
 }
 
+// Data-parallel forms of the prepared backward (the tail split around the exchange):
+//   advx_prepared_bwd_grad   batch-reduce + this rank's unmasked image gradient -> grad_p
+//   advx_prepared_update     mask, ||g||, optimiser, s_next + partials, next canvas   (after an
+//                            all-reduce of grad_p by the caller, e.g. RCCL)
+//   advx_prepared_bwd_dp     both around the peer exchange of `comm`, one call
+static int32_t prepared_grad_impl(advx_plan* p, const float* grad_out, int32_t batch, const float* pp, const float* x0,
+                                  float eps, float imgfit_scale, float* grad_p, int32_t rows_in, int32_t parity, float* stats,
+                                  float* scratch, float* ws, int64_t ws_floats, hipStream_t st) {
+  REQUIRE(p && grad_out && pp && x0 && grad_p && stats && scratch && ws, ADVX_E_BADARG, "advx_prepared_bwd_grad: null argument");
+  REQUIRE(advx_prepared_supported(p), ADVX_E_UNSUPPORTED, "advx_prepared_bwd_grad: the plan has more than one stage");
+  REQUIRE(parity == 0 || parity == 1, ADVX_E_BADARG, "advx_prepared_bwd_grad: parity must be 0 or 1");
+  REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_prepared_bwd_grad: batch out of range");
+  REQUIRE(ws_floats >= p->info.workspace_floats, ADVX_E_SHAPE, "advx_prepared_bwd_grad: workspace too small");
+  PreparedScratch f = carve_prepared(p, scratch);
+  REQUIRE(rows_in >= 0 && rows_in <= std::max(f.tail_blocks, f.prep_blocks), ADVX_E_BADARG,
+          "advx_prepared_bwd_grad: rows_in out of range");
+  const DStage& D = p->dstage[0];
+  const long long n = 3LL * p->info.in_h * p->info.in_w;
+  long long lo, hi;
+  plan_live_range(p, &lo, &hi);
+  int32_t rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st, lo, hi);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_plan_tail_grad, dim3(f.tail_blocks), dim3(kBlock), 0, st, D, p->dplan,
+                     (const float*)(ws + p->dplan.gsum_off), pp, x0, eps, imgfit_scale / (float)n, grad_p,
+                     (const double*)f.img_rows[parity], (int)rows_in, stats);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
+static int32_t prepared_update_impl(advx_plan* p, float* pp, float* m, float* v, float* grad_p, const float* mask,
+                                    const float* x0, float eps, const advx_opt_scalars* opt, float* s_next, int32_t parity,
+                                    float* stats, float* scratch, float* ws, int64_t ws_floats, const CommDev* comm,
+                                    hipStream_t st) {
+  REQUIRE(p && pp && grad_p && mask && x0 && opt && s_next && stats && scratch && ws, ADVX_E_BADARG,
+          "advx_prepared_update: null argument");
+  REQUIRE(advx_prepared_supported(p), ADVX_E_UNSUPPORTED, "advx_prepared_update: the plan has more than one stage");
+  REQUIRE(parity == 0 || parity == 1, ADVX_E_BADARG, "advx_prepared_update: parity must be 0 or 1");
+  REQUIRE(ws_floats >= p->info.workspace_floats, ADVX_E_SHAPE, "advx_prepared_update: workspace too small");
+  REQUIRE(opt->apply, ADVX_E_UNSUPPORTED, "advx_prepared_update always takes the optimiser step");
+  int32_t rc = check_opt(opt, m, v);
+  if (rc) return rc;
+  PreparedScratch f = carve_prepared(p, scratch);
+  const DStage& D = p->dstage[0];
+  const long long n = 3LL * p->info.in_h * p->info.in_w;
+  if (comm) {
+    hipLaunchKernelGGL(k_plan_update<true>, dim3(f.tail_blocks), dim3(kBlock), 0, st, pp, m, v, grad_p, mask, x0, eps, n,
+                       to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows, *comm);
+  } else {
+    CommDev none;
+    std::memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL(k_plan_update<false>, dim3(f.tail_blocks), dim3(kBlock), 0, st, pp, m, v, grad_p, mask, x0, eps, n,
+                       to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows, none);
+  }
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_plan_head, dim3(grid_for(3LL * D.can_h * D.can_w)), dim3(kBlock), 0, st, D, (const float*)s_next,
+                     (long long)D.src_h * D.src_w, D.src_w, ws + p->dplan.canvas_off[0], (const double*)f.norm_rows,
+                     f.tail_blocks, stats);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_prepared_bwd_grad(advx_plan* p, const float* grad_out, int32_t batch, const float* pp, const float* x0,
+                                          float eps, float imgfit_scale, float* grad_p, int32_t rows_in, int32_t parity,
+                                          float* stats, float* scratch, float* ws, int64_t ws_floats, void* stream) {
+  return prepared_grad_impl(p, grad_out, batch, pp, x0, eps, imgfit_scale, grad_p, rows_in, parity, stats, scratch, ws,
+                            ws_floats, (hipStream_t)stream);
+}
+
+extern "C" int32_t advx_prepared_update(advx_plan* p, float* pp, float* m, float* v, float* grad_p, const float* mask,
+                                        const float* x0, float eps, const advx_opt_scalars* opt, float* s_next,
+                                        int32_t parity, float* stats, float* scratch, float* ws, int64_t ws_floats,
+                                        void* stream) {
+  return prepared_update_impl(p, pp, m, v, grad_p, mask, x0, eps, opt, s_next, parity, stats, scratch, ws, ws_floats, nullptr,
+                              (hipStream_t)stream);
+}
+
+extern "C" int32_t advx_prepared_bwd_dp(advx_plan* p, advx_comm* c, const float* grad_out, int32_t batch, float* pp,
+                                        const float* x0, float eps, float imgfit_scale, const float* mask, float* m, float* v,
+                                        const advx_opt_scalars* opt, float* s_next, int32_t rows_in, int32_t parity,
+                                        float* stats, float* scratch, float* ws, int64_t ws_floats, double timeout_s,
+                                        void* stream) {
+  REQUIRE(p && c && opt, ADVX_E_BADARG, "advx_prepared_bwd_dp: null argument");
+  const long long n = 3LL * p->info.in_h * p->info.in_w;
+  const long long n_x = (n + 3) / 4 * 4;   // the exchange moves whole float4 columns (the pad is never read back)
+  REQUIRE(n_x <= c->floats, ADVX_E_SHAPE, "advx_prepared_bwd_dp: the exchange segment is smaller than the image");
+  hipStream_t st = (hipStream_t)stream;
+  int32_t rc = prepared_grad_impl(p, grad_out, batch, pp, x0, eps, imgfit_scale, advx_comm_send_buffer(c), rows_in, parity,
+                                  stats, scratch, ws, ws_floats, st);
+  if (rc) return rc;
+  rc = comm_allreduce_launch(c, n_x, timeout_s, false, st);
+  if (rc) return rc;
+  return prepared_update_impl(p, pp, m, v, advx_comm_recv_buffer(c), mask, x0, eps, opt, s_next, parity, stats, scratch, ws,
+                              ws_floats, &c->dev, st);
+}
+
 // ------------------------------------------------------ suffix-only cross entropy (advx_ce.h)
 extern "C" int32_t advx_ce_fwd(const void* logits, int32_t io_dtype, int64_t batch_stride, int64_t row_stride, int32_t T,
                                const int64_t* targets, int64_t rows, int64_t vocab, float* row_loss, float* row_lse,

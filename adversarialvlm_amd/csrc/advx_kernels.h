@@ -1023,6 +1023,69 @@ __global__ void __launch_bounds__(kBlock) k_plan_tail(DStage st, DPlan pl, const
   block_sum_store<1>(nacc, norm_rows + blockIdx.x);
 }
 
+// Data parallelism splits the tail around the exchange of the image gradient:
+//   k_plan_tail_grad : resize^T (/std), image-fit', tanh' -> this rank's UNMASKED gradient
+//                      (block 0 still reduces the statistics of the current image);
+//   <all-reduce>
+//   k_plan_update    : mask, ||g|| partial, optimiser, s_next and its statistics partials.
+__global__ void __launch_bounds__(kBlock) k_plan_tail_grad(DStage st, DPlan pl, const float* __restrict__ gsum,
+                                                           const float* __restrict__ p, const float* __restrict__ x0,
+                                                           float eps, float c_fit, float* __restrict__ grad_p,
+                                                           const double* __restrict__ img_rows_in, int img_rows_in_count,
+                                                           float* __restrict__ stats) {
+  const unsigned plane = (unsigned)st.src_h * (unsigned)st.src_w;
+  const long long n = 3LL * plane;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && img_rows_in_count > 0) finalize_image_block<true>(img_rows_in, img_rows_in_count, n, stats);
+  if (i < n) {
+    const int c = (int)((unsigned)i / plane);
+    const unsigned rem = (unsigned)i - (unsigned)c * plane;
+    const int ys = (int)(rem / (unsigned)st.src_w), xs = (int)(rem - (unsigned)ys * (unsigned)st.src_w);
+    const float t = tanhf(p[i]);
+    const float s = x0[i] + eps * t;
+    const float gs = stage_bwd_value(st, pl, 0, gsum, nullptr, c, ys, xs);
+    grad_p[i] = ((gs + imgfit_grad(s, c_fit)) * eps) * (1.0f - t * t);
+  }
+}
+
+template <bool COMM>   // COMM: `grad` is the recv buffer of the peer exchange (advx_comm.h)
+__global__ void __launch_bounds__(kBlock) k_plan_update(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                        float* __restrict__ grad, const float* __restrict__ mask,
+                                                        const float* __restrict__ x0, float eps, long long n, OptScalars o,
+                                                        float* __restrict__ s_next, double* __restrict__ img_rows_out,
+                                                        double* __restrict__ norm_rows, CommDev comm) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
+  double nacc[1] = {0.0};
+  float mk = 0.f, pp = 0.f, xv = 0.f;
+  if (i < n) {
+    mk = mask[i];
+    pp = p[i];
+    xv = x0[i];
+  }
+  if (COMM) comm_wait_b(comm);
+  if (i < n) {
+    const float gp = (COMM ? comm_load1(grad + i) : grad[i]) * mk;
+    grad[i] = gp;
+    nacc[0] = (double)gp * (double)gp;
+    if (o.kind == 0) {
+      float mm = m[i], vv = v[i];
+      adamw_element(pp, mm, vv, gp, o);
+      p[i] = pp; m[i] = mm; v[i] = vv;
+    } else {
+      float sg = (gp > 0.0f) ? 1.0f : ((gp < 0.0f) ? -1.0f : 0.0f);
+      pp = pp - o.lr * sg;
+      p[i] = pp;
+    }
+    const float xn = eps * tanhf(pp);
+    const float sn = xv + xn;
+    s_next[i] = sn;
+    stat_accumulate(sn, xn, acc);
+  }
+  block_sum_store<kStatSlots>(acc, img_rows_out + (size_t)blockIdx.x * kStatSlots);
+  block_sum_store<1>(nacc, norm_rows + blockIdx.x);
+}
+
 __global__ void __launch_bounds__(kBlock) k_plan_head(DStage st, const float* __restrict__ src, long long src_cstride,
                                                       int src_rstride, float* __restrict__ canvas,
                                                       const double* __restrict__ norm_rows, int norm_count,

@@ -291,6 +291,42 @@ def prepared_bwd(plan, grad_out, batch, p, x0, epsilon, imgfit_scale, mask, m, v
                                        L.ptr(workspace), int(workspace.numel()), _stream(p)), "advx_prepared_bwd")
 
 
+def prepared_bwd_grad(plan, grad_out, batch, p, x0, epsilon, imgfit_scale, grad_p, rows_in, parity, stats, scratch,
+                      workspace):
+    """Data-parallel first half: batch-reduce and this rank's unmasked image gradient -> grad_p."""
+    _require_cuda(grad_out, p, x0, grad_p, stats, scratch, workspace)
+    grad_out = _f32c(grad_out)
+    if grad_out.numel() != batch * plan.out_numel:
+        raise L.AdvxError("grad_out has the wrong number of elements")
+    L.check(L.load().advx_prepared_bwd_grad(plan.handle, L.ptr(grad_out), int(batch), L.ptr(p), L.ptr(x0), float(epsilon),
+                                            float(imgfit_scale), L.ptr(grad_p), int(rows_in), int(parity), L.ptr(stats),
+                                            L.ptr(scratch), L.ptr(workspace), int(workspace.numel()), _stream(p)),
+            "advx_prepared_bwd_grad")
+
+
+def prepared_update(plan, p, m, v, grad_p, mask, x0, epsilon, opt, s_next, parity, stats, scratch, workspace):
+    """Data-parallel second half (after the all-reduce of grad_p): mask, ||g||, optimiser, next step."""
+    _require_cuda(p, grad_p, mask, x0, s_next, stats, scratch, workspace)
+    L.check(L.load().advx_prepared_update(plan.handle, L.ptr(p), L.ptr(m), L.ptr(v), L.ptr(grad_p), L.ptr(mask), L.ptr(x0),
+                                          float(epsilon), C.byref(opt), L.ptr(s_next), int(parity), L.ptr(stats),
+                                          L.ptr(scratch), L.ptr(workspace), int(workspace.numel()), _stream(p)),
+            "advx_prepared_update")
+
+
+def prepared_bwd_dp(plan, exchange, grad_out, batch, p, x0, epsilon, imgfit_scale, mask, m, v, opt, s_next, rows_in, parity,
+                    stats, scratch, workspace):
+    """Both halves around the peer exchange (dp.PeerExchange) in one call."""
+    _require_cuda(grad_out, p, x0, mask, s_next, stats, scratch, workspace)
+    grad_out = _f32c(grad_out)
+    if grad_out.numel() != batch * plan.out_numel:
+        raise L.AdvxError("grad_out has the wrong number of elements")
+    L.check(L.load().advx_prepared_bwd_dp(plan.handle, exchange.handle, L.ptr(grad_out), int(batch), L.ptr(p), L.ptr(x0),
+                                          float(epsilon), float(imgfit_scale), L.ptr(mask), L.ptr(m), L.ptr(v),
+                                          C.byref(opt), L.ptr(s_next), int(rows_in), int(parity), L.ptr(stats),
+                                          L.ptr(scratch), L.ptr(workspace), int(workspace.numel()),
+                                          float(exchange.timeout_s), _stream(p)), "advx_prepared_bwd_dp")
+
+
 def quantise(s, out=None):
     """The image after the lossless PNG round trip of attack_model.py:368-371 (uint8 truncation)."""
     _require_cuda(s)

@@ -14,8 +14,10 @@ Four kernel chains implement this, chosen at construction (`self.mode`):
   * generic  - any plan(s), blur, crop, gradient accumulation (advx_image_* / advx_emit /
                advx_collect / advx_update): nine launches per step;
   * prepared - ONE one-stage plan (LLaVA from a non-native image, Mllama, Qwen2-VL) without
-               blur/crop/accumulation on one GPU: the backward leaves the next step's canvas
-               behind, four launches per step (advx_prepared_fwd / advx_prepared_bwd);
+               blur/crop/accumulation: the backward leaves the next step's canvas behind, four
+               launches per step (advx_prepared_fwd / advx_prepared_bwd); under data parallelism
+               the tail is split around the gradient exchange (advx_prepared_bwd_dp, or
+               advx_prepared_bwd_grad + all-reduce + advx_prepared_update);
   * pair     - one identity-resize LLaVA plan without blur/crop/accumulation: two launches
                per step (advx_fused_fwd / advx_fused_bwd); the form data parallelism uses,
                with the gradient all-reduce between the backward and advx_update;
@@ -100,13 +102,12 @@ class PixelPGD:
         self.upd_scratch = ops.update_scratch(self.p.numel(), dev)
         if fused_mode not in ("auto", "pair", "step", "prepared"):
             raise ValueError("fused_mode must be auto, pair, step or prepared")
-        # the prepared chain: any one-stage plan (it resamples), same restrictions otherwise; the
-        # gradient exchange of data parallelism stays on the generic chain
+        # the prepared chain: any one-stage plan (it resamples), same restrictions otherwise
         can_prepare = bool(allow_fused and len(self.plans) == 1 and self.plans[0].prepared_supported()
-                           and blur_kernel is None and not self.use_crop and self.accum == 1 and not self.exchange)
+                           and blur_kernel is None and not self.use_crop and self.accum == 1)
         if fused_mode == "prepared":
             if not can_prepare:
-                raise L.AdvxError("fused_mode='prepared' needs one one-stage plan, no blur / crop / accumulation / exchange")
+                raise L.AdvxError("fused_mode='prepared' needs one one-stage plan, no blur / crop / accumulation")
             self.fused = False
             self.mode = "prepared"
         elif not self.fused:
@@ -125,7 +126,7 @@ class PixelPGD:
         if io_dtype != torch.float32 and self.mode != "pair":
             raise L.AdvxError(f"io_dtype={io_dtype} needs the fused pair; this engine runs the {self.mode} chain")
         self.io_dtype = io_dtype
-        if self.peer is not None and self.mode == "pair":
+        if self.peer is not None and self.mode in ("pair", "prepared"):
             # the masked, all-reduced gradient of the last step lives in the exchange's recv buffer
             self.grad = self.peer.recv[:self.x0.numel()].view_as(self.x0)
         if self.fused:
@@ -322,9 +323,20 @@ class PixelPGD:
         elif self.mode == "prepared":
             pl, B = self.plans[0], st["batches"][0]
             nxt = 1 - self.s_cur
-            ops.prepared_bwd(pl, grads[0], B, self.p, self.x0, self.eps, self.imgfit_scale(), self.mask, self.m, self.v,
-                             self.grad, opt, self.s_bufs[nxt], self.rows_in, self.par, self.stats, self.prep_scratch,
-                             self.workspaces[0])
+            if not self.exchange:
+                ops.prepared_bwd(pl, grads[0], B, self.p, self.x0, self.eps, self.imgfit_scale(), self.mask, self.m, self.v,
+                                 self.grad, opt, self.s_bufs[nxt], self.rows_in, self.par, self.stats, self.prep_scratch,
+                                 self.workspaces[0])
+            elif self.peer is not None:
+                ops.prepared_bwd_dp(pl, self.peer, grads[0], B, self.p, self.x0, self.eps, self.imgfit_scale(), self.mask,
+                                    self.m, self.v, opt, self.s_bufs[nxt], self.rows_in, self.par, self.stats,
+                                    self.prep_scratch, self.workspaces[0])
+            else:
+                ops.prepared_bwd_grad(pl, grads[0], B, self.p, self.x0, self.eps, self.imgfit_scale(), self.grad,
+                                      self.rows_in, self.par, self.stats, self.prep_scratch, self.workspaces[0])
+                dp.allreduce_image_grad_(self.grad, self.pg)
+                ops.prepared_update(pl, self.p, self.m, self.v, self.grad, self.mask, self.x0, self.eps, opt,
+                                    self.s_bufs[nxt], self.par, self.stats, self.prep_scratch, self.workspaces[0])
             self.par = 1 - self.par
             self.rows_in = self.rows_bwd
             self.s_cur = nxt

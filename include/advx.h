@@ -322,6 +322,26 @@ int32_t advx_prepared_bwd(advx_plan* plan, const float* grad_out, int32_t batch,
                           int32_t parity, float* stats, float* scratch, float* workspace,
                           int64_t workspace_floats, void* stream);
 
+/* Data-parallel forms of advx_prepared_bwd: the tail is split around the all-reduce of the image
+ * gradient.  advx_prepared_bwd_grad leaves this rank's UNMASKED gradient in grad_p (and reduces
+ * the current image's statistics); after the caller's all-reduce (e.g. RCCL) advx_prepared_update
+ * masks it, takes the optimiser step and prepares the next step.  advx_prepared_bwd_dp does both
+ * around the peer exchange of `comm` (below) in one call. */
+int32_t advx_prepared_bwd_grad(advx_plan* plan, const float* grad_out, int32_t batch, const float* p, const float* x0,
+                               float epsilon, float imgfit_scale, float* grad_p, int32_t rows_in, int32_t parity,
+                               float* stats, float* scratch, float* workspace, int64_t workspace_floats,
+                               void* stream);
+int32_t advx_prepared_update(advx_plan* plan, float* p, float* m, float* v, float* grad_p, const float* mask,
+                             const float* x0, float epsilon, const advx_opt_scalars* opt, float* s_next,
+                             int32_t parity, float* stats, float* scratch, float* workspace,
+                             int64_t workspace_floats, void* stream);
+struct advx_comm;
+int32_t advx_prepared_bwd_dp(advx_plan* plan, struct advx_comm* comm, const float* grad_out, int32_t batch, float* p,
+                             const float* x0, float epsilon, float imgfit_scale, const float* mask, float* m,
+                             float* v, const advx_opt_scalars* opt, float* s_next, int32_t rows_in,
+                             int32_t parity, float* stats, float* scratch, float* workspace,
+                             int64_t workspace_floats, double timeout_s, void* stream);
+
 /* -------------------------------------------------- data-parallel exchange
  * The reference has no data parallelism (one process, one model per GPU:
  * crossattack_models.py:244-258); the exchange added here is ONE all-reduce(sum) per step of the

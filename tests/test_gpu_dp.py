@@ -34,10 +34,10 @@ def _rank(rank, world, port, chain, out, transport="rccl"):
     gs = [torch.randn(B, 3, H, H, generator=gen) * 0.01 for _ in range(3)]
     local = B // world
     sl = slice(rank * local, (rank + 1) * local)
-    kw = dict(allow_fused=False) if chain == "generic" else dict(fused_mode="pair")
+    kw = {"generic": dict(allow_fused=False), "pair": dict(fused_mode="pair"), "prepared": dict(fused_mode="prepared")}[chain]
     eng = PixelPGD(x0.to(dev), [Plan.llava(H, H, H, H)], lr=1e-2, process_group=torch.distributed.group.WORLD,
                    exchange_transport=transport, **kw)
-    assert eng.world == world
+    assert eng.world == world and eng.mode == chain
     assert (eng.peer is not None) == (transport == "peer")
     for t in range(3):
         eng.forward(local, [zs[t][sl].to(dev)])
@@ -49,7 +49,8 @@ def _rank(rank, world, port, chain, out, transport="rccl"):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("chain,transport", [("pair", "rccl"), ("generic", "rccl"), ("pair", "peer"), ("generic", "peer")])
+@pytest.mark.parametrize("chain,transport", [("pair", "rccl"), ("generic", "rccl"), ("pair", "peer"), ("generic", "peer"),
+                                             ("prepared", "rccl"), ("prepared", "peer")])
 def test_two_ranks_match_single_process(chain, transport):
     from adversarialvlm_amd.pgd import PixelPGD
     from adversarialvlm_amd.plan import Plan
@@ -75,7 +76,7 @@ def test_two_ranks_match_single_process(chain, transport):
     assert n0 == pytest.approx(rst["grad_norm"], rel=1e-5) and s0 == pytest.approx(rst["sigma_next"], rel=1e-6)
 
 
-def _rccl_single(rank, port, out, transport):
+def _rccl_single(rank, port, out, transport, fused_mode="auto"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
@@ -90,7 +91,7 @@ def _rccl_single(rank, port, out, transport):
     res = []
     for force in (True, False):
         eng = PixelPGD(x0, [Plan.llava(64, 64, 64, 64)], process_group=torch.distributed.group.WORLD, force_exchange=force,
-                       exchange_transport=transport)
+                       exchange_transport=transport, fused_mode=fused_mode)
         assert (eng.peer is not None) == (force and transport == "peer")
         for t in range(3):
             eng.forward(4, [zs[t]])
@@ -103,14 +104,14 @@ def _rccl_single(rank, port, out, transport):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("transport", ["rccl", "peer"])
-def test_rccl_exchange_chain_single_rank(transport):
+@pytest.mark.parametrize("transport,fused_mode", [("rccl", "auto"), ("peer", "auto"), ("rccl", "prepared"), ("peer", "prepared")])
+def test_rccl_exchange_chain_single_rank(transport, fused_mode):
     """backend "nccl" IS RCCL on ROCm: a one-rank group drives the real data-parallel chain
     (fused_bwd grad-only -> RCCL all-reduce -> fused_update -> prepared forward) on the GPU and
     must reproduce the single-launch update bit for bit."""
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
-    mp.spawn(_rccl_single, args=(_free_port(), out, transport), nprocs=1, join=True)
+    mp.spawn(_rccl_single, args=(_free_port(), out, transport, fused_mode), nprocs=1, join=True)
     assert out["same_p"]
     a, b = out["stats"]
     for k in a:
