@@ -124,7 +124,7 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
                       scheduler_step_size=scheduler_step_size, scheduler_gamma=scheduler_gamma,
                       grad_accum_steps=grad_accum_steps, blur_kernel=gblur_kernel_size if use_gaussian_blur else None,
                       use_crop=use_local_crop, model_weights=[model_weights[i] for i in my_models], cross_mode=True,
-                      seed=seed + 7919 * rank, allow_fused=False,
+                      seed=seed + 7919 * rank, allow_fused=(len(plans) == 1),   # one model on this rank: pipelined chains
                       process_group=torch.distributed.group.WORLD if world > 1 else None, grad_prescale=prescale,
                       noise_on_padding=noise_on_padding)
     if world > 1:

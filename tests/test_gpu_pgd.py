@@ -334,3 +334,35 @@ def test_prepared_is_the_default_for_one_stage_plans_and_agrees_with_generic(dev
     assert PixelPGD(x0, [Plan.llava(H, W, 48, 48)], grad_accum_steps=2).mode == "generic"
     with pytest.raises(L.AdvxError):
         PixelPGD(x0, [Plan.phi3(H, W)], fused_mode="prepared")
+
+
+@pytest.mark.parametrize("kind", ["qwen2vl", "llava-identity"])
+def test_cross_mode_single_plan_pipelined_chains_agree_with_generic(dev, kind):
+    """A rank of the cross-model trainer that holds ONE model (crossattack_models.py with one
+    model per GPU group) may take the pipelined chains: with cross-mode scaling (image-fit term
+    counted per model, weights on the loss) they must follow the generic chain's trajectory."""
+    from adversarialvlm_amd.pgd import PixelPGD
+    Plan = _plans()
+    if kind == "qwen2vl":
+        H, W = 60, 90
+        mk = lambda: Plan.qwen2vl(H, W, min_pixels=28 * 28 * 4, max_pixels=28 * 28 * 64)
+        want_mode = "prepared"
+    else:
+        H = W = 64
+        mk = lambda: Plan.llava(H, W, H, W)
+        want_mode = "pair"
+    B = 3
+    x0 = torch.rand(3, H, W, generator=torch.Generator().manual_seed(51)).to(dev)
+    res = {}
+    for name, kw in (("fast", {}), ("generic", dict(allow_fused=False))):
+        eng = PixelPGD(x0, [mk()], cross_mode=True, model_weights=[0.7], epsilon=0.4, seed=2, grad_prescale=0.5, **kw)
+        assert eng.mode == (want_mode if name == "fast" else "generic")
+        gen = torch.Generator().manual_seed(52)
+        for _ in range(3):
+            eng.forward(B)
+            g = (torch.randn(B, eng.plans[0].out_numel, generator=gen) * 0.01).to(dev)
+            eng.backward_update([g * eng.loss_scale(0)])
+        res[name] = (eng.p.cpu().clone(), eng.stats_dict())
+    assert rel_err(res["fast"][0], res["generic"][0]) < 2e-6
+    for k, v in res["fast"][1].items():
+        assert v == pytest.approx(res["generic"][1][k], rel=1e-5, abs=1e-12), k
