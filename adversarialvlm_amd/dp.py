@@ -193,6 +193,30 @@ def probe_peer_exchange(ex, group=None, rounds=3, seed=1234):
     return ok
 
 
+def _peer_is_competitive(ex, group=None, iters=20, slack=1.25):
+    """"auto" keeps the peer path only if it is not slower than the host library's all-reduce of
+    the same tensor on THIS machine (worst rank decides; `slack` allows for the launches the
+    fused one-call form saves).  All ranks return the same answer."""
+    import time
+    dist = torch.distributed
+    buf = torch.zeros(ex.floats, dtype=torch.float32, device=ex.device)
+    times = []
+    for fn in (ex.all_reduce, lambda: dist.all_reduce(buf, group=group)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(ex.device)
+        dist.barrier(group=group)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize(ex.device)
+        times.append(time.perf_counter() - t0)
+    t = torch.tensor(times, device=ex.device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    ex.peer_vs_host_seconds = (float(t[0]) / iters, float(t[1]) / iters)
+    return bool(t[0] <= slack * t[1]) and not ex.timed_out()
+
+
 def make_exchange(floats, device, group=None, transport="auto", timeout_s=5.0):
     """transport: "rccl" -> None (torch.distributed all-reduce); "peer" -> PeerExchange or an
     error; "auto" -> PeerExchange if it can be set up AND passes the probe, else None."""
@@ -214,6 +238,9 @@ def make_exchange(floats, device, group=None, transport="auto", timeout_s=5.0):
             last_error = e
             continue
         if probe_peer_exchange(ex, group):
+            if transport == "auto" and ex.world > 1 and not _peer_is_competitive(ex, group):
+                ex.close()
+                return None      # correct but slower than the host library on this machine
             return ex
         ex.close()
         from . import _lib as L
