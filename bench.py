@@ -145,6 +145,9 @@ def main():
         exchange = "none (single rank)"
     else:
         exchange = f"peer ({eng.peer.mem_kind} IPC segments)" if eng.peer is not None else f"{args.backend} all-reduce"
+        timing = getattr(eng.peer, "peer_vs_host_seconds", None)
+        if timing is not None:
+            exchange += f"; at start-up peer {timing[0] * 1e6:.1f} us vs {args.backend} {timing[1] * 1e6:.1f} us per all-reduce"
     # every rank pre-scales its share so that the SUM all-reduce is the DP average
     gs = (g * eng.loss_scale(0)).to(io_dtype)
 
