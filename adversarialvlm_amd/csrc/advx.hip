@@ -1469,7 +1469,10 @@ PreparedScratch carve_prepared(const advx_plan* p, float* scratch) {
 
 extern "C" int32_t advx_prepared_supported(const advx_plan* p) {
   if (!p) return 0;
-  return (p->info.n_stage == 1 && p->st[0].info.src == 0) ? 1 : 0;
+  // stage 0 resamples the image; a second stage may resample stage 0's canvas (Phi-3.5)
+  if (p->st[0].info.src != 0) return 0;
+  if (p->info.n_stage == 1) return 1;
+  return (p->info.n_stage == 2 && p->st[1].info.src == 1) ? 1 : 0;
 }
 
 extern "C" int64_t advx_prepared_scratch_floats(const advx_plan* p) {
@@ -1487,12 +1490,42 @@ extern "C" int32_t advx_prepared_rows(const advx_plan* p, int32_t* rows_after_pr
   return ADVX_OK;
 }
 
+// backward of the stages above stage 0 (Phi-3.5's global view) into their dgrad buffers; returns
+// the gradient that reaches canvas 0 from them (null for one-stage plans)
+static const float* prepared_upper_bwd(advx_plan* p, const float* gsum, float* ws, hipStream_t st) {
+  for (int k = p->info.n_stage - 1; k >= 1; --k) {
+    const DStage& D = p->dstage[k];
+    const advx_stage_info& s = p->st[k].info;
+    const float* dgrad = (p->dplan.dgrad_off[k] >= 0) ? ws + p->dplan.dgrad_off[k] : nullptr;
+    float* gsrc = ws + p->dplan.dgrad_off[s.src - 1];
+    const int rowblk = 128;
+    hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D, p->dplan, k, gsum,
+                       dgrad, gsrc, (long long)D.src_h * D.src_w, D.src_w, 0);
+  }
+  return (p->dplan.dgrad_off[0] >= 0) ? ws + p->dplan.dgrad_off[0] : nullptr;
+}
+
+// canvases of the next step from s: head (stage 0, with the pending ||g|| reduction) + later stages
+static void prepared_canvases(advx_plan* p, const float* s_img, float* ws, const double* norm_rows, int norm_count,
+                              float* stats, hipStream_t st) {
+  const DStage& D0 = p->dstage[0];
+  hipLaunchKernelGGL(k_plan_head, dim3(grid_for(3LL * D0.can_h * D0.can_w)), dim3(kBlock), 0, st, D0, s_img,
+                     (long long)D0.src_h * D0.src_w, D0.src_w, ws + p->dplan.canvas_off[0], norm_rows, norm_count, stats);
+  for (int k = 1; k < p->info.n_stage; ++k) {
+    const DStage& D = p->dstage[k];
+    const advx_stage_info& s = p->st[k].info;
+    const float* src = ws + p->dplan.canvas_off[s.src - 1];
+    hipLaunchKernelGGL(k_stage_fwd, dim3(grid_for(3LL * D.can_h * D.can_w)), dim3(kBlock), 0, st, D, src,
+                       (long long)D.src_h * D.src_w, D.src_w, ws + p->dplan.canvas_off[k]);
+  }
+}
+
 extern "C" int32_t advx_prepared_fwd(advx_plan* p, const float* pp, const float* x0, float eps, int32_t batch,
                                      const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset, float* out,
                                      float* s_buf, int32_t prepared, int32_t parity, float* stats, float* scratch, float* ws,
                                      int64_t ws_floats, int32_t pad_mode, void* stream) {
   REQUIRE(p && pp && x0 && out && s_buf && stats && scratch && ws, ADVX_E_BADARG, "advx_prepared_fwd: null argument");
-  REQUIRE(advx_prepared_supported(p), ADVX_E_UNSUPPORTED, "advx_prepared_fwd: the plan has more than one stage");
+  REQUIRE(advx_prepared_supported(p), ADVX_E_UNSUPPORTED, "advx_prepared_fwd: unsupported stage graph");
   REQUIRE(parity == 0 || parity == 1, ADVX_E_BADARG, "advx_prepared_fwd: parity must be 0 or 1");
   REQUIRE(pad_mode == ADVX_PAD_NOISE || pad_mode == ADVX_PAD_KEEP, ADVX_E_BADARG, "advx_prepared_fwd: unknown pad_mode");
   REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_prepared_fwd: batch out of range");
@@ -1509,8 +1542,7 @@ extern "C" int32_t advx_prepared_fwd(advx_plan* p, const float* pp, const float*
     // first step, or p was changed elsewhere: s, its statistics partials and the canvas
     hipLaunchKernelGGL(k_prep<true>, dim3(f.prep_blocks), dim3(kBlock), 0, st, pp, x0, eps, n, s_buf, f.img_rows[parity]);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_plan_head, dim3(grid_for(3LL * D.can_h * D.can_w)), dim3(kBlock), 0, st, D, (const float*)s_buf,
-                       (long long)D.src_h * D.src_w, D.src_w, ws + p->dplan.canvas_off[0], (const double*)nullptr, 0, stats);
+    prepared_canvases(p, s_buf, ws, nullptr, 0, stats, st);
     LAUNCH_CHECK();
   }
   const int noise = unit_noise ? 1 : (use_philox ? 2 : 0);
@@ -1540,7 +1572,7 @@ extern "C" int32_t advx_prepared_bwd(advx_plan* p, const float* grad_out, int32_
                                      float* scratch, float* ws, int64_t ws_floats, void* stream) {
   REQUIRE(p && grad_out && pp && x0 && mask && grad_p && opt && s_next && stats && scratch && ws, ADVX_E_BADARG,
           "advx_prepared_bwd: null argument");
-  REQUIRE(advx_prepared_supported(p), ADVX_E_UNSUPPORTED, "advx_prepared_bwd: the plan has more than one stage");
+  REQUIRE(advx_prepared_supported(p), ADVX_E_UNSUPPORTED, "advx_prepared_bwd: unsupported stage graph");
   REQUIRE(parity == 0 || parity == 1, ADVX_E_BADARG, "advx_prepared_bwd: parity must be 0 or 1");
   REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_prepared_bwd: batch out of range");
   REQUIRE(ws_floats >= p->info.workspace_floats, ADVX_E_SHAPE, "advx_prepared_bwd: workspace too small");
@@ -1557,13 +1589,13 @@ extern "C" int32_t advx_prepared_bwd(advx_plan* p, const float* grad_out, int32_
   rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st, lo, hi);
   if (rc) return rc;
   const float* gsum = ws + p->dplan.gsum_off;
-  hipLaunchKernelGGL(k_plan_tail, dim3(f.tail_blocks), dim3(kBlock), 0, st, D, p->dplan, gsum, pp, x0, eps,
+  const float* dgrad0 = prepared_upper_bwd(p, gsum, ws, st);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_plan_tail, dim3(f.tail_blocks), dim3(kBlock), 0, st, D, p->dplan, gsum, dgrad0, pp, x0, eps,
                      imgfit_scale / (float)n, mask, m, v, grad_p, to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows,
                      (const double*)f.img_rows[parity], (int)rows_in, stats);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_plan_head, dim3(grid_for(3LL * D.can_h * D.can_w)), dim3(kBlock), 0, st, D, (const float*)s_next,
-                     (long long)D.src_h * D.src_w, D.src_w, ws + p->dplan.canvas_off[0], (const double*)f.norm_rows,
-                     f.tail_blocks, stats);
+  prepared_canvases(p, s_next, ws, f.norm_rows, f.tail_blocks, stats, st);
   LAUNCH_CHECK();
   return ADVX_OK;
 }
@@ -1577,7 +1609,7 @@ static int32_t prepared_grad_impl(advx_plan* p, const float* grad_out, int32_t b
                                   float eps, float imgfit_scale, float* grad_p, int32_t rows_in, int32_t parity, float* stats,
                                   float* scratch, float* ws, int64_t ws_floats, hipStream_t st) {
   REQUIRE(p && grad_out && pp && x0 && grad_p && stats && scratch && ws, ADVX_E_BADARG, "advx_prepared_bwd_grad: null argument");
-  REQUIRE(advx_prepared_supported(p), ADVX_E_UNSUPPORTED, "advx_prepared_bwd_grad: the plan has more than one stage");
+  REQUIRE(advx_prepared_supported(p), ADVX_E_UNSUPPORTED, "advx_prepared_bwd_grad: unsupported stage graph");
   REQUIRE(parity == 0 || parity == 1, ADVX_E_BADARG, "advx_prepared_bwd_grad: parity must be 0 or 1");
   REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_prepared_bwd_grad: batch out of range");
   REQUIRE(ws_floats >= p->info.workspace_floats, ADVX_E_SHAPE, "advx_prepared_bwd_grad: workspace too small");
@@ -1590,8 +1622,10 @@ static int32_t prepared_grad_impl(advx_plan* p, const float* grad_out, int32_t b
   plan_live_range(p, &lo, &hi);
   int32_t rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st, lo, hi);
   if (rc) return rc;
+  const float* dgrad0 = prepared_upper_bwd(p, ws + p->dplan.gsum_off, ws, st);
+  LAUNCH_CHECK();
   hipLaunchKernelGGL(k_plan_tail_grad, dim3(f.tail_blocks), dim3(kBlock), 0, st, D, p->dplan,
-                     (const float*)(ws + p->dplan.gsum_off), pp, x0, eps, imgfit_scale / (float)n, grad_p,
+                     (const float*)(ws + p->dplan.gsum_off), dgrad0, pp, x0, eps, imgfit_scale / (float)n, grad_p,
                      (const double*)f.img_rows[parity], (int)rows_in, stats);
   LAUNCH_CHECK();
   return ADVX_OK;
@@ -1603,7 +1637,7 @@ static int32_t prepared_update_impl(advx_plan* p, float* pp, float* m, float* v,
                                     hipStream_t st) {
   REQUIRE(p && pp && grad_p && mask && x0 && opt && s_next && stats && scratch && ws, ADVX_E_BADARG,
           "advx_prepared_update: null argument");
-  REQUIRE(advx_prepared_supported(p), ADVX_E_UNSUPPORTED, "advx_prepared_update: the plan has more than one stage");
+  REQUIRE(advx_prepared_supported(p), ADVX_E_UNSUPPORTED, "advx_prepared_update: unsupported stage graph");
   REQUIRE(parity == 0 || parity == 1, ADVX_E_BADARG, "advx_prepared_update: parity must be 0 or 1");
   REQUIRE(ws_floats >= p->info.workspace_floats, ADVX_E_SHAPE, "advx_prepared_update: workspace too small");
   REQUIRE(opt->apply, ADVX_E_UNSUPPORTED, "advx_prepared_update always takes the optimiser step");
@@ -1622,9 +1656,7 @@ static int32_t prepared_update_impl(advx_plan* p, float* pp, float* m, float* v,
                        to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows, none);
   }
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_plan_head, dim3(grid_for(3LL * D.can_h * D.can_w)), dim3(kBlock), 0, st, D, (const float*)s_next,
-                     (long long)D.src_h * D.src_w, D.src_w, ws + p->dplan.canvas_off[0], (const double*)f.norm_rows,
-                     f.tail_blocks, stats);
+  prepared_canvases(p, s_next, ws, f.norm_rows, f.tail_blocks, stats, st);
   LAUNCH_CHECK();
   return ADVX_OK;
 }

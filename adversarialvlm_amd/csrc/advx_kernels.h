@@ -965,7 +965,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_update(float* __restrict__ p, 
   if (blockIdx.x == 0 && threadIdx.x == 0) hdr->norm_blocks = gridDim.x;
 }
 
-// ============================================== prepared chain (any one-stage plan, no blur/crop)
+// ================================================== prepared chain (any plan, no blur/crop)
 // The fused pair's software pipelining for plans whose process() DOES resample (LLaVA from a
 // non-native image, Mllama, Qwen2-VL): the backward of step t leaves the canvas of step t+1 in
 // the plan workspace, so a step is four launches instead of nine:
@@ -975,8 +975,11 @@ __global__ void __launch_bounds__(kBlock) k_fused_update(float* __restrict__ p, 
 //                   optimiser -> p_{t+1}; s_{t+1} = x0 + eps*tanh(p_{t+1}) and its statistics
 //                   partials; block 0 reduces the statistics of s_t (rotating SIGMA <- QERR_STD)
 //   k_plan_head     canvas_{t+1} = resize(s_{t+1}), pad, normalise; block 0 reduces ||g||
+// A plan with a second stage fed by the first canvas (Phi-3.5: bicubic global view of the HD
+// canvas) adds k_stage_bwd of that stage before the tail (its gradient reaches the tail through
+// `dgrad`) and k_stage_fwd of it after the head.
 __global__ void __launch_bounds__(kBlock) k_plan_tail(DStage st, DPlan pl, const float* __restrict__ gsum,
-                                                      float* __restrict__ p, const float* __restrict__ x0, float eps,
+                                                      const float* __restrict__ dgrad, float* __restrict__ p, const float* __restrict__ x0, float eps,
                                                       float c_fit, const float* __restrict__ mask, float* __restrict__ m,
                                                       float* __restrict__ v, float* __restrict__ grad_p, OptScalars o,
                                                       float* __restrict__ s_next, double* __restrict__ img_rows_out,
@@ -1001,7 +1004,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_tail(DStage st, DPlan pl, const
     const int ys = (int)(rem / (unsigned)st.src_w), xs = (int)(rem - (unsigned)ys * (unsigned)st.src_w);
     const float t = tanhf(pp);
     const float s = xv + eps * t;
-    const float gs = stage_bwd_value(st, pl, 0, gsum, nullptr, c, ys, xs);
+    const float gs = stage_bwd_value(st, pl, 0, gsum, dgrad, c, ys, xs);
     float gp = ((gs + imgfit_grad(s, c_fit)) * eps) * (1.0f - t * t);
     gp = gp * mk;
     nacc[0] = (double)gp * (double)gp;
@@ -1029,7 +1032,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_tail(DStage st, DPlan pl, const
 //   <all-reduce>
 //   k_plan_update    : mask, ||g|| partial, optimiser, s_next and its statistics partials.
 __global__ void __launch_bounds__(kBlock) k_plan_tail_grad(DStage st, DPlan pl, const float* __restrict__ gsum,
-                                                           const float* __restrict__ p, const float* __restrict__ x0,
+                                                           const float* __restrict__ dgrad, const float* __restrict__ p, const float* __restrict__ x0,
                                                            float eps, float c_fit, float* __restrict__ grad_p,
                                                            const double* __restrict__ img_rows_in, int img_rows_in_count,
                                                            float* __restrict__ stats) {
@@ -1043,7 +1046,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_tail_grad(DStage st, DPlan pl, 
     const int ys = (int)(rem / (unsigned)st.src_w), xs = (int)(rem - (unsigned)ys * (unsigned)st.src_w);
     const float t = tanhf(p[i]);
     const float s = x0[i] + eps * t;
-    const float gs = stage_bwd_value(st, pl, 0, gsum, nullptr, c, ys, xs);
+    const float gs = stage_bwd_value(st, pl, 0, gsum, dgrad, c, ys, xs);
     grad_p[i] = ((gs + imgfit_grad(s, c_fit)) * eps) * (1.0f - t * t);
   }
 }

@@ -13,7 +13,7 @@ and `crossattack_models.py:329-406,425-432` (several models):
 Four kernel chains implement this, chosen at construction (`self.mode`):
   * generic  - any plan(s), blur, crop, gradient accumulation (advx_image_* / advx_emit /
                advx_collect / advx_update): nine launches per step;
-  * prepared - ONE one-stage plan (LLaVA from a non-native image, Mllama, Qwen2-VL) without
+  * prepared - ONE plan (LLaVA from a non-native image, Mllama, Qwen2-VL, Phi-3.5) without
                blur/crop/accumulation: the backward leaves the next step's canvas behind, four
                launches per step (advx_prepared_fwd / advx_prepared_bwd); under data parallelism
                the tail is split around the gradient exchange (advx_prepared_bwd_dp, or

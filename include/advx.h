@@ -291,8 +291,9 @@ int32_t advx_fused_step_flush(advx_plan* plan, int32_t parity, int32_t norm_rows
                               float* scratch, void* stream);
 
 /* ------------------------------ prepared chain: the same pipelining for plans that DO resample
- * Any one-stage plan (LLaVA from a non-native image such as the reference's 512x512 gray.png,
- * Mllama, Qwen2-VL) without blur, crop or gradient accumulation: the backward of step t leaves
+ * Any single plan (LLaVA from a non-native image such as the reference's 512x512 gray.png,
+ * Mllama, Qwen2-VL; Phi-3.5, whose second stage resamples the first canvas, with one extra
+ * launch each way) without blur, crop or gradient accumulation: the backward of step t leaves
  * s_{t+1}, its statistics partials and the processed canvas of step t+1 behind, so a step of
  * attack_model.py:300-346,366-373 is four launches (emit | batch-reduce, tail, head) instead of
  * the nine of advx_image_* + advx_emit + advx_collect + advx_update.

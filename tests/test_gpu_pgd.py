@@ -270,7 +270,8 @@ def test_padding_tiles_kept_zero_is_the_same_attack(dev, kind):
     assert engines[0].stats_dict() == engines[1].stats_dict()
 
 
-@pytest.mark.parametrize("kind", ["llava-down", "llava-up", "llava-identity", "mllama", "qwen2vl", "llava-sign"])
+@pytest.mark.parametrize("kind", ["llava-down", "llava-up", "llava-identity", "mllama", "qwen2vl", "phi3", "phi3-tall",
+                                  "llava-sign"])
 def test_prepared_chain_matches_oracle(dev, kind):
     """The four-launch chain for plans that resample (advx_prepared_fwd / advx_prepared_bwd):
     same trajectory as the oracle's step, statistics included, for down- and up-sampling LLaVA
@@ -299,6 +300,12 @@ def test_prepared_chain_matches_oracle(dev, kind):
         x0 = torch.rand(3, H, W)
         _trajectory(dev, x0, [Qwen2VLOracle(min_pixels=28 * 28 * 4, max_pixels=28 * 28 * 64)],
                     [Plan.qwen2vl(H, W, min_pixels=28 * 28 * 4, max_pixels=28 * 28 * 64)], [3], 4, **kw)
+    elif kind in ("phi3", "phi3-tall"):
+        # two stages: the bicubic global view is resampled from the HD canvas (its gradient reaches
+        # the tail through the first canvas); the tall image takes the transposed frame
+        H, W = (60, 90) if kind == "phi3" else (100, 64)
+        x0 = torch.rand(3, H, W)
+        _trajectory(dev, x0, [Phi3Oracle()], [Plan.phi3(H, W)], [2], 3, **kw)
     else:
         x0 = torch.rand(3, 50, 50)
         _trajectory(dev, x0, [LlavaOracle(32, 32)], [Plan.llava(50, 50, 32, 32)], [2], 4, optimizer="sign", lr=1e-3,
@@ -328,12 +335,13 @@ def test_prepared_is_the_default_for_one_stage_plans_and_agrees_with_generic(dev
     sa, sb = a[0].stats_dict(), b[0].stats_dict()
     for k in sa:
         assert sa[k] == pytest.approx(sb[k], rel=1e-5, abs=1e-12), k
-    # a two-stage plan, blur, crop or accumulation keep the generic chain
-    assert PixelPGD(x0, [Plan.phi3(H, W)]).mode == "generic"
+    # Phi-3.5's two stages are prepared too; blur, crop, accumulation or several plans keep the generic chain
+    assert PixelPGD(x0, [Plan.phi3(H, W)]).mode == "prepared"
     assert PixelPGD(x0, [Plan.llava(H, W, 48, 48)], blur_kernel=5).mode == "generic"
     assert PixelPGD(x0, [Plan.llava(H, W, 48, 48)], grad_accum_steps=2).mode == "generic"
+    assert PixelPGD(x0, [Plan.llava(H, W, 48, 48), Plan.phi3(H, W)]).mode == "generic"
     with pytest.raises(L.AdvxError):
-        PixelPGD(x0, [Plan.phi3(H, W)], fused_mode="prepared")
+        PixelPGD(x0, [Plan.llava(H, W, 48, 48)], blur_kernel=5, fused_mode="prepared")
 
 
 @pytest.mark.parametrize("kind", ["qwen2vl", "llava-identity"])

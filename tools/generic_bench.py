@@ -52,6 +52,8 @@ if __name__ == "__main__":
     run("mllama 336 B=32", [Plan.mllama(336, 336)], 336, 336, 32)
     run("phi3 512", [Plan.phi3(512, 512)], 512, 512, 64)
     run("phi3 512, padding kept zero", [Plan.phi3(512, 512)], 512, 512, 64, pad_noise=False)
+    run("phi3 512", [Plan.phi3(512, 512)], 512, 512, 64, prepared=True)
+    run("phi3 512, padding kept zero", [Plan.phi3(512, 512)], 512, 512, 64, pad_noise=False, prepared=True)
     run("qwen2vl 512", [Plan.qwen2vl(512, 512)], 512, 512, 64)
     run("qwen2vl 512", [Plan.qwen2vl(512, 512)], 512, 512, 64, prepared=True)
     run("cross phi3+qwen+mllama 336 blur5", [Plan.phi3(336, 336), Plan.qwen2vl(336, 336), Plan.mllama(336, 336)], 336, 336,
