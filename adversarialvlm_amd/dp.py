@@ -67,8 +67,9 @@ class _DevicePointer:
 class PeerExchange:
     """All-reduce(sum) of the image gradient by peer access over xGMI (advx_comm_* of
     include/advx.h): every rank exports one uncached exchange segment through HIP IPC, maps the
-    others', and an all-reduce is barrier -> rank-ordered slice sums -> barrier on the caller's
-    stream.  torch.distributed is used ONCE, to carry the 64-byte handles between processes."""
+    others', and an all-reduce is one reduce kernel (meets the peers on entry, sums its slice of
+    all send buffers in rank order, posts it to every recv buffer) plus the consumer's wait, on
+    the caller's stream.  torch.distributed is used ONCE, to carry the 64-byte handles between processes."""
 
     MEM_NAMES = {1: "uncached", 2: "fine-grained", 3: "device"}
 
