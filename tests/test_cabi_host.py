@@ -201,3 +201,11 @@ def test_live_range_is_where_the_oracle_output_is_not_padding(lib, kind, hw):
     assert float((flat[lo:hi] != 0).float().mean()) > 0.99
     if kind in ("llava", "qwen2vl"):
         assert (lo, hi) == (0, plan.out_numel)
+
+
+def test_header_is_plain_c():
+    """include/advx.h is the drop-in boundary: it must compile as C99 on its own (no torch, no
+    C++), so that cgo / JNI / ctypes / a C caller can bind it."""
+    res = subprocess.run(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror",
+                          os.path.join(ROOT, "include", "advx.h")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
