@@ -11,9 +11,10 @@ stored.  The reference tree does not exist on the GPU box - nothing at test time
 
 Importability notes: llavaprocessor imports directly; qwen2VLprocessor /
 phi3processor have unused torchvision imports, so a bare stub module is registered after
-transformers' symbols are resolved; llama32processor cannot be imported with
-transformers 5.15 (no fixture from it - see mllama_restated.npz, which is produced by
-the oracle's restatement and pinned only by the transformers canvas helpers).
+transformers' symbols are resolved; llama32processor additionally imports three integer
+helpers from a transformers module that needs torchvision - the installed transformers ships
+the same helpers in its PIL-backend module, which is registered under the expected name
+(import_reference_mllama).  mllama_restated.npz (oracle output) is kept as a regression file.
 """
 import os
 import sys
@@ -74,6 +75,21 @@ def import_reference():
     import processors.qwen2VLprocessor as qwen
     import processors.phi3processor as phi3
     return llava, qwen, phi3
+
+
+def import_reference_mllama():
+    """llama32processor imports three integer helpers from
+    transformers.models.mllama.image_processing_mllama, a module that itself needs torchvision
+    and therefore cannot be imported here; the SAME helpers (get_optimal_tiled_canvas,
+    get_image_size_fit_to_canvas, pack_images) ship in the installed transformers under
+    image_processing_pil_mllama.  Registering that installed module under the name the reference
+    asks for (plus the bare torchvision stub: the reference imports torchvision and never calls
+    it) makes `DifferentiableMllamaImageProcessor` importable.  Call after import_reference()."""
+    import importlib
+    from transformers import AutoProcessor, MllamaConfig, MllamaForConditionalGeneration, MllamaImageProcessor  # noqa: F401
+    pil = importlib.import_module("transformers.models.mllama.image_processing_pil_mllama")
+    sys.modules.setdefault("transformers.models.mllama.image_processing_mllama", pil)
+    return importlib.import_module("processors.llama32processor")
 
 
 def golden_llava(llava):
@@ -233,6 +249,45 @@ def golden_closed_form():
     save("closed_form.npz", **arrays)
 
 
+def golden_mllama_reference(mllama):
+    """Captures from the reference's own DifferentiableMllamaImageProcessor
+    (llama32processor.py:219-405): pixel_values, num_tiles and image.grad for a seeded upstream
+    gradient over geometries that reach 1, 2, 3 and 4 tiles in every arrangement, plus one
+    capture at the model's real tile size (560), stored as checksums and sampled entries."""
+    arrays = {}
+    cases = [("one", (3, 30, 27), 32), ("wide3", (3, 20, 90), 32), ("tall4", (3, 120, 25), 32), ("two_by_two", (3, 70, 100), 32),
+             ("wide2", (3, 40, 75), 32), ("tall2", (3, 60, 33), 32), ("up", (3, 10, 12), 32)]
+    for k, (name, ishape, tile) in enumerate(cases):
+        op = SimpleNamespace(image_mean=CLIP_MEAN, image_std=CLIP_STD, do_convert_rgb=True, do_normalize=True,
+                             size={"height": tile, "width": tile}, max_image_tiles=4, rescale_factor=1 / 255)
+        proc = mllama.DifferentiableMllamaImageProcessor(op, "cpu")
+        torch.manual_seed(300 + k)
+        img = torch.rand(ishape, requires_grad=True)
+        out = proc.process(img)
+        pv = out["pixel_values"]
+        up = lcg_tensor(pv.shape, 31 + k)
+        pv.backward(up)
+        arrays.update({f"{name}_image": img, f"{name}_tile": np.array(tile), f"{name}_pixel_values": pv,
+                       f"{name}_image_grad": img.grad, f"{name}_salt": np.array(31 + k),
+                       f"{name}_num_tiles": np.array(int(out["num_tiles"]))})
+    op = SimpleNamespace(image_mean=CLIP_MEAN, image_std=CLIP_STD, do_convert_rgb=True, do_normalize=True,
+                         size={"height": 560, "width": 560}, max_image_tiles=4, rescale_factor=1 / 255)
+    proc = mllama.DifferentiableMllamaImageProcessor(op, "cpu")
+    img = lcg_tensor((3, 512, 512), 77) + 0.5
+    img.requires_grad_(True)
+    out = proc.process(img)
+    pv = out["pixel_values"]
+    up = lcg_tensor(pv.shape, 76)
+    pv.backward(up)
+    idx = np.arange(0, pv.numel(), 4999)
+    gidx = np.arange(0, img.numel(), 1499)
+    arrays.update(full_salt_image=np.array(77), full_salt_up=np.array(76), full_num_tiles=np.array(int(out["num_tiles"])),
+                  full_shape=np.array(pv.shape), full_pv_sum=pv.detach().double().sum(),
+                  full_pv_sumsq=(pv.detach().double() ** 2).sum(), full_pv_idx=idx, full_pv_val=pv.detach().flatten()[idx],
+                  full_grad_sum=img.grad.double().sum(), full_grad_idx=gidx, full_grad_val=img.grad.flatten()[gidx])
+    save("mllama_reference.npz", **arrays)
+
+
 def golden_mllama_restated():
     """NOT a reference capture: produced by the oracle's restatement of
     llama32processor.py:360-405 (module not importable here)."""
@@ -261,6 +316,7 @@ def main():
     golden_qwen(qwen)
     golden_phi3(phi3)
     golden_mllama_helpers()
+    golden_mllama_reference(import_reference_mllama())
     golden_closed_form()
     golden_mllama_restated()
 

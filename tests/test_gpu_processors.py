@@ -85,6 +85,34 @@ def test_phi3_reference_capture(dev, name):
     assert torch.count_nonzero(pv[0, n_real:]) == 0            # padding tiles are exact zeros
 
 
+@pytest.mark.parametrize("name", ["one", "wide3", "tall4", "two_by_two", "wide2", "tall2", "up"])
+def test_mllama_reference_capture(dev, name):
+    """HIP path against captures from the reference's own DifferentiableMllamaImageProcessor."""
+    from adversarialvlm_amd.plan import Plan
+    g = load_golden("mllama_reference.npz")
+    img = torch.tensor(g[f"{name}_image"])
+    plan = Plan.mllama(img.shape[1], img.shape[2], tile=int(g[f"{name}_tile"]), max_tiles=4)
+    assert plan.info.num_tiles == int(g[f"{name}_num_tiles"])
+    ref = g[f"{name}_pixel_values"]
+    pv, grad = _run(plan, img, lcg_tensor(ref.shape, int(g[f"{name}_salt"])), dev)
+    assert rel_err(pv, ref) < TIGHT
+    assert rel_err(grad, g[f"{name}_image_grad"]) < TIGHT
+    assert torch.count_nonzero(pv[0, 0, plan.info.num_tiles:]) == 0
+
+
+def test_mllama_full_size_512_to_560_tiles(dev):
+    from adversarialvlm_amd.plan import Plan
+    g = load_golden("mllama_reference.npz")
+    img = lcg_tensor((3, 512, 512), int(g["full_salt_image"])) + 0.5
+    plan = Plan.mllama(512, 512)
+    shape = tuple(int(v) for v in g["full_shape"])
+    assert plan.info.num_tiles == int(g["full_num_tiles"])
+    pv, grad = _run(plan, img, lcg_tensor(shape, int(g["full_salt_up"])), dev)
+    assert abs(float(pv.double().sum()) - float(g["full_pv_sum"])) < 1e-5 * abs(float(g["full_pv_sum"]))
+    assert rel_err(pv.flatten()[g["full_pv_idx"]], g["full_pv_val"]) < TIGHT
+    assert rel_err(grad.flatten()[g["full_grad_idx"]], g["full_grad_val"]) < TIGHT
+
+
 @pytest.mark.parametrize("name", ["a", "b", "c"])
 def test_mllama_restated_fixture(dev, name):
     from adversarialvlm_amd.plan import Plan

@@ -156,3 +156,33 @@ def test_random_resized_crop_params_in_bounds():
     for _ in range(50):
         i, j, h, w = P.random_resized_crop_params(336, 336, (0.6, 1.0), (0.75, 1.33), gen)
         assert 0 <= i and i + h <= 336 and 0 <= j and j + w <= 336 and h > 0 and w > 0
+
+
+MLLAMA_CASES = ["one", "wide3", "tall4", "two_by_two", "wide2", "tall2", "up"]
+
+
+@pytest.mark.parametrize("name", MLLAMA_CASES)
+def test_mllama_reference_capture(name):
+    """The restatement of llama32processor.py:255-405 against captures from the reference's own
+    DifferentiableMllamaImageProcessor (tests/golden/make_golden.py: import_reference_mllama)."""
+    g = load_golden("mllama_reference.npz")
+    img = torch.tensor(g[f"{name}_image"], requires_grad=True)
+    out = MllamaOracle(tile=int(g[f"{name}_tile"]), max_tiles=4).process(img)
+    pv = out["pixel_values"]
+    assert int(out["num_tiles"]) == int(g[f"{name}_num_tiles"])
+    assert pv.shape == g[f"{name}_pixel_values"].shape
+    assert rel_err(pv.detach(), g[f"{name}_pixel_values"]) <= TOL
+    pv.backward(lcg_tensor(pv.shape, int(g[f"{name}_salt"])))
+    assert rel_err(img.grad, g[f"{name}_image_grad"]) <= TOL
+
+
+def test_mllama_full_size_checksums():
+    g = load_golden("mllama_reference.npz")
+    img = (lcg_tensor((3, 512, 512), int(g["full_salt_image"])) + 0.5).requires_grad_(True)
+    out = MllamaOracle(tile=560, max_tiles=4).process(img)
+    pv = out["pixel_values"]
+    assert tuple(pv.shape) == tuple(int(v) for v in g["full_shape"]) and int(out["num_tiles"]) == int(g["full_num_tiles"])
+    pv.backward(lcg_tensor(pv.shape, int(g["full_salt_up"])))
+    assert abs(float(pv.detach().double().sum()) - float(g["full_pv_sum"])) <= 1e-6 * abs(float(g["full_pv_sum"]))
+    assert rel_err(pv.detach().flatten()[g["full_pv_idx"]], g["full_pv_val"]) <= TOL
+    assert rel_err(img.grad.flatten()[g["full_grad_idx"]], g["full_grad_val"]) <= TOL
