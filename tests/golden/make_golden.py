@@ -249,6 +249,43 @@ def golden_closed_form():
     save("closed_form.npz", **arrays)
 
 
+def import_reference_trainer():
+    """attack_model.py imports wandb (absent), two torchvision transform classes and names a
+    wandb type in a signature; none of them is touched by the two pure helpers captured here
+    (`image_fit_loss` :86-106, `create_mask` :66-84), so empty placeholders with those names are
+    enough to import the module.  Call after import_reference() / import_reference_mllama()
+    (processors/__init__ pulls every plugin in)."""
+    import importlib
+    tvt = sys.modules["torchvision.transforms"]
+    for name in ("RandomResizedCrop", "GaussianBlur"):
+        if not hasattr(tvt, name):
+            setattr(tvt, name, type(name, (), {}))
+    if "wandb" not in sys.modules:
+        w = types.ModuleType("wandb")
+        w.Table = type("Table", (), {})
+        sys.modules["wandb"] = w
+    return importlib.import_module("attack_model")
+
+
+def golden_trainer_helpers(am):
+    """Outputs of the reference trainer's own helper functions (not restatements)."""
+    arrays = {}
+    for k, (shape, lo, hi) in enumerate([((3, 9, 11), -0.6, 0.6), ((3, 16, 16), -1.0, 1.0), ((3, 5, 7), -0.05, 0.05)]):
+        torch.manual_seed(500 + k)
+        x0 = torch.rand(shape)
+        x = (torch.rand(shape) * (hi - lo) + lo).requires_grad_(True)
+        loss = am.image_fit_loss(x0, x, 0, 1)                       # the call attack_model.py:329 makes
+        loss.backward()
+        arrays.update({f"fit{k}_x0": x0, f"fit{k}_x": x.detach(), f"fit{k}_loss": loss.detach(), f"fit{k}_x_grad": x.grad})
+    for k, (mt, ms, shape) in enumerate([("corner", 4, (3, 9, 11)), ("corner", 100, (3, 336, 336)), ("bottom_lines", 3, (3, 9, 11)),
+                                         ("bottom_lines", 20, (3, 70, 100))]):
+        m = am.create_mask(mt, ms, shape, "cpu")
+        arrays.update({f"mask{k}_type": np.array(0 if mt == "corner" else 1), f"mask{k}_size": np.array(ms),
+                       f"mask{k}_shape": np.array(shape), f"mask{k}_sum": m.double().sum(),
+                       f"mask{k}_idx": torch.nonzero(m.flatten())[:: max(1, int(m.sum()) // 64)].flatten()})
+    save("trainer_helpers.npz", **arrays)
+
+
 def golden_mllama_reference(mllama):
     """Captures from the reference's own DifferentiableMllamaImageProcessor
     (llama32processor.py:219-405): pixel_values, num_tiles and image.grad for a seeded upstream
@@ -317,6 +354,7 @@ def main():
     golden_phi3(phi3)
     golden_mllama_helpers()
     golden_mllama_reference(import_reference_mllama())
+    golden_trainer_helpers(import_reference_trainer())
     golden_closed_form()
     golden_mllama_restated()
 

@@ -186,3 +186,29 @@ def test_mllama_full_size_checksums():
     assert abs(float(pv.detach().double().sum()) - float(g["full_pv_sum"])) <= 1e-6 * abs(float(g["full_pv_sum"]))
     assert rel_err(pv.detach().flatten()[g["full_pv_idx"]], g["full_pv_val"]) <= TOL
     assert rel_err(img.grad.flatten()[g["full_grad_idx"]], g["full_grad_val"]) <= TOL
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_image_fit_loss_against_the_reference_function(k):
+    """oracle.pixel_ops.image_fit_loss vs outputs of the reference's own image_fit_loss
+    (attack_model.py:86-106, called as at :329), value and gradient."""
+    g = load_golden("trainer_helpers.npz")
+    x0 = torch.tensor(g[f"fit{k}_x0"])
+    x = torch.tensor(g[f"fit{k}_x"], requires_grad=True)
+    loss = P.image_fit_loss(x0, x)
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g[f"fit{k}_loss"]), rel=1e-6, abs=1e-12)
+    assert rel_err(x.grad, g[f"fit{k}_x_grad"]) <= TOL if float(np.abs(g[f"fit{k}_x_grad"]).max()) > 0 else not bool(x.grad.any())
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_create_mask_against_the_reference_function(k):
+    """oracle and product `create_mask` vs the reference's own (attack_model.py:66-84)."""
+    from adversarialvlm_amd.attack_model import create_mask as product_mask
+    g = load_golden("trainer_helpers.npz")
+    mt = "corner" if int(g[f"mask{k}_type"]) == 0 else "bottom_lines"
+    shape = tuple(int(v) for v in g[f"mask{k}_shape"])
+    for m in (P.create_mask(mt, int(g[f"mask{k}_size"]), shape), product_mask(mt, int(g[f"mask{k}_size"]), shape, "cpu")):
+        assert float(m.double().sum()) == float(g[f"mask{k}_sum"])
+        assert bool((m.flatten()[torch.tensor(g[f"mask{k}_idx"])] == 1).all())
+        assert set(m.unique().tolist()) <= {0.0, 1.0}
