@@ -286,6 +286,33 @@ def golden_trainer_helpers(am):
     save("trainer_helpers.npz", **arrays)
 
 
+def golden_suffix_loss(llava):
+    """AdvLlavaInputs.update_target_tokens + get_loss (llavaprocessor.py:64-78) called on an
+    instance whose constructor is bypassed (it needs a downloaded HF processor): the tokenizer is
+    a two-line fake that returns fixed ids, everything else is the reference's own code.
+    Captures the loss and d loss / d logits for [B, S, V] logits."""
+    arrays = {}
+    for k, (B, S, V, ids, shift) in enumerate([(3, 14, 50, [7, 11, 3, 29, 2], 1), (2, 20, 97, [5, 9, 9, 4, 31, 8, 2], 2),
+                                               (4, 9, 33, [1, 2], 1)]):
+        inst = object.__new__(llava.AdvLlavaInputs)
+        inst.device = "cpu"
+        inst.batch_size = B
+        inst.shift = shift
+        inst.extra_token = ""
+        inst.target_text = "t"
+        inst.processor = SimpleNamespace(tokenizer=lambda text, return_tensors, add_special_tokens, _ids=ids:
+                                         SimpleNamespace(input_ids=torch.tensor([_ids])))
+        inst.update_target_tokens()
+        torch.manual_seed(600 + k)
+        logits = (torch.randn(B, S, V) * 2.0).requires_grad_(True)
+        loss = inst.get_loss(logits[:, :-1, :])                      # attack_model.py:325-327
+        loss.backward()
+        arrays.update({f"ce{k}_logits": logits.detach(), f"ce{k}_ids": np.array(ids), f"ce{k}_shift": np.array(shift),
+                       f"ce{k}_target": inst.target, f"ce{k}_suffix_length": np.array(inst.suffix_length),
+                       f"ce{k}_loss": loss.detach(), f"ce{k}_logits_grad": logits.grad})
+    save("suffix_loss.npz", **arrays)
+
+
 def golden_mllama_reference(mllama):
     """Captures from the reference's own DifferentiableMllamaImageProcessor
     (llama32processor.py:219-405): pixel_values, num_tiles and image.grad for a seeded upstream
@@ -352,6 +379,7 @@ def main():
     golden_llava(llava)
     golden_qwen(qwen)
     golden_phi3(phi3)
+    golden_suffix_loss(llava)
     golden_mllama_helpers()
     golden_mllama_reference(import_reference_mllama())
     golden_trainer_helpers(import_reference_trainer())

@@ -71,3 +71,25 @@ def test_trainer_suffix_only_ce_equals_the_default_path(tmp_path):
     (p0, l0), (p1, l1) = runs[False], runs[True]
     assert l0 == pytest.approx(l1, rel=2e-3)                   # fp16 model: the default path rounds the loss in half
     assert float((p0 - p1).norm() / p0.norm()) < 2e-2
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_suffix_ce_against_the_reference_method(k):
+    """The HIP suffix-only path on the last suffix_length + 1 positions against the loss and
+    logits gradient the reference's own get_loss produced for the full [B, S, V] tensor
+    (tests/golden/suffix_loss.npz): same loss, same gradient where it is non-zero, and the
+    reference's gradient is zero everywhere the suffix-only path does not even compute logits."""
+    from conftest import load_golden
+    from adversarialvlm_amd.ce import suffix_cross_entropy
+    dev = torch.device("cuda:0")
+    g = load_golden("suffix_loss.npz")
+    logits = torch.tensor(g[f"ce{k}_logits"])
+    target = torch.tensor(g[f"ce{k}_target"])
+    K = int(g[f"ce{k}_suffix_length"]) + 1
+    kept = logits[:, -K:, :].to(dev).clone().requires_grad_(True)
+    loss = suffix_cross_entropy(kept, target.to(dev))
+    loss.backward()
+    ref_grad = torch.tensor(g[f"ce{k}_logits_grad"])
+    assert float(loss.detach()) == pytest.approx(float(g[f"ce{k}_loss"]), rel=1e-6)
+    assert float((kept.grad.cpu() - ref_grad[:, -K:, :]).abs().max()) < 1e-7
+    assert not bool(ref_grad[:, :-K, :].any())

@@ -1,6 +1,7 @@
 """CPU tier: host-side logic above the C ABI - plugin registry, prompt-batch assembly and the
 suffix loss (a18/a11 of SURVEY 8a), CLI defaults (App. C), DP scale factors."""
 import random
+import types
 
 import pytest
 import torch
@@ -116,3 +117,26 @@ def test_dp_scales():
     assert dp.shard_batch(256, 8) == 32
     with pytest.raises(ValueError):
         dp.shard_batch(10, 4)
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_get_loss_against_the_reference_method(k):
+    """AdvInputsBase.get_loss (host side of a11) vs outputs of the reference's own
+    AdvLlavaInputs.update_target_tokens + get_loss (llavaprocessor.py:64-78): the supervised
+    window, the target repeat, the loss and d loss / d logits."""
+    import numpy as np
+    from conftest import load_golden
+    from adversarialvlm_amd.processors.llavaprocessor import AdvLlavaInputs
+    g = load_golden("suffix_loss.npz")
+    logits = torch.tensor(g[f"ce{k}_logits"], requires_grad=True)
+    ids = [int(v) for v in g[f"ce{k}_ids"]]
+    inst = object.__new__(AdvLlavaInputs)
+    inst.device, inst.batch_size, inst.shift, inst.extra_token, inst.target_text = "cpu", logits.shape[0], int(g[f"ce{k}_shift"]), "", "t"
+    inst.processor = types.SimpleNamespace(tokenizer=lambda text, return_tensors, add_special_tokens:
+                                           types.SimpleNamespace(input_ids=torch.tensor([ids])))
+    inst.update_target_tokens()
+    assert inst.suffix_length == int(g[f"ce{k}_suffix_length"]) and torch.equal(inst.target, torch.tensor(g[f"ce{k}_target"]))
+    loss = inst.get_loss(logits[:, :-1, :])
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g[f"ce{k}_loss"]), rel=1e-6)
+    assert float((logits.grad - torch.tensor(g[f"ce{k}_logits_grad"])).abs().max()) < 1e-7
