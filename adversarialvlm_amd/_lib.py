@@ -66,6 +66,8 @@ SIGNATURES = {
     "advx_plan_taps": (_I32, [_P, _I32, _I32, _I32, _PI32, _PI32, _P, _P, _P]),
     "advx_plan_out_index": (_I32, [_P, _I32, _I32, _I32, _I32, _PI32, C.POINTER(C.c_int64)]),
     "advx_plan_live_range": (_I32, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "advx_plan_set_io": (_I32, [_P, _I32]),
+    "advx_plan_get_io": (_I32, [_P]),
     "advx_taps_compute": (_I32, [_I32, _I32, _I32, _I32, _PI32, _PI32, _P, _P, _P]),
     "advx_emit": (_I32, [_P, _P, _I32, _P, _P, _I32, _U64, _U64, _P, _P, _I64, _P]),
     "advx_emit_ex": (_I32, [_P, _P, _I32, _P, _P, _I32, _U64, _U64, _P, _P, _I64, _I32, _P]),

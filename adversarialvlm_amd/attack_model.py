@@ -189,7 +189,7 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
                       use_crop=use_local_crop, optimizer=optimizer, seed=seed + 7919 * rank,
                       process_group=torch.distributed.group.WORLD if world > 1 else None,
                       noise_on_padding=noise_on_padding)
-    if pixel_io == "model" and engine.mode == "pair":
+    if pixel_io == "model" and engine.mode != "step":
         model_dtype = next(model.parameters()).dtype
         if model_dtype in IO_DTYPES:
             engine.io_dtype = model_dtype

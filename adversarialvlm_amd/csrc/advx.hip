@@ -171,6 +171,7 @@ struct advx_plan {
   bool uploaded = false;
   int device = -1;
   void* dev_block = nullptr;
+  int io = 0;                  // boundary dtype of pixel_values / grad_out (ADVX_IO_*), advx_plan_set_io
 };
 
 // ---- integer geometry (restated from the reference / transformers helpers; see oracle/geometry.py)
@@ -564,6 +565,16 @@ static void plan_live_range(const advx_plan* p, long long* lo, long long* hi) {
   }
 }
 
+extern "C" int32_t advx_plan_set_io(advx_plan* p, int32_t io_dtype) {
+  REQUIRE(p, ADVX_E_BADARG, "advx_plan_set_io: null plan");
+  REQUIRE(io_dtype >= 0 && io_dtype <= 2, ADVX_E_BADARG, "advx_plan_set_io: io_dtype must be ADVX_IO_F32 / F16 / BF16");
+  REQUIRE(io_dtype == 0 || (p->info.out_numel % 4) == 0, ADVX_E_UNSUPPORTED,
+          "advx_plan_set_io: half boundary dtypes need a sample size that is a multiple of 4");
+  p->io = io_dtype;
+  return ADVX_OK;
+}
+extern "C" int32_t advx_plan_get_io(const advx_plan* p) { return p ? p->io : ADVX_E_BADARG; }
+
 extern "C" int32_t advx_plan_live_range(const advx_plan* p, int64_t* lo, int64_t* hi) {
   REQUIRE(p && lo && hi, ADVX_E_BADARG, "advx_plan_live_range: null argument");
   long long a, b;
@@ -606,11 +617,14 @@ extern "C" int32_t advx_emit_ex(advx_plan* p, const float* argument, int32_t bat
   int gx, slices, bps;
   emit_slices(q_hi - q_lo, batch, &gx, &slices, &bps);
   dim3 grid(gx, slices);
-#define ADVX_EMIT(N)                                                                                                \
-  hipLaunchKernelGGL(k_emit<N>, grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, offset, \
-                     out, q_lo, q_hi, live_lo, live_hi)
+#define ADVX_EMIT_T(N, T)                                                                                           \
+  hipLaunchKernelGGL((k_emit<N, T>), grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, \
+                     offset, (void*)out, q_lo, q_hi, live_lo, live_hi)
+#define ADVX_EMIT(N) \
+  do { if (p->io == 0) ADVX_EMIT_T(N, 0); else if (p->io == 1) ADVX_EMIT_T(N, 1); else ADVX_EMIT_T(N, 2); } while (0)
   if (noise == 0) ADVX_EMIT(0); else if (noise == 1) ADVX_EMIT(1); else ADVX_EMIT(2);
 #undef ADVX_EMIT
+#undef ADVX_EMIT_T
   LAUNCH_CHECK();
   return ADVX_OK;
 }
@@ -624,19 +638,28 @@ extern "C" int32_t advx_emit(advx_plan* p, const float* argument, int32_t batch,
 
 // [live_lo, live_hi): flat indices of a sample whose gradient is needed (defaults: all of it)
 static int32_t launch_batch_reduce(const float* g, int batch, long long n, float* out, hipStream_t st,
-                                   long long live_lo = 0, long long live_hi = -1) {
+                                   long long live_lo = 0, long long live_hi = -1, int io = 0) {
   REQUIRE(aligned16(g) && aligned16(out), ADVX_E_BADARG, "batch_reduce: pointers must be 16-byte aligned");
+  REQUIRE(io == 0 || (n & 3) == 0, ADVX_E_UNSUPPORTED, "batch_reduce: half gradients need rows that are a multiple of 4");
   if (live_hi < 0 || live_hi > n) live_hi = n;
   if ((n & 3) == 0) {
     long long q_lo = live_lo >> 2, q_hi = (live_hi + 3) >> 2;
     if (q_hi <= q_lo) return ADVX_OK;
     int blocks = (int)((q_hi - q_lo + kWave - 1) / kWave);
     // what is read here, B x (live columns) x 16 bytes: beyond the Infinity Cache it is streamed past it
-    const double read_bytes = (double)batch * (double)(q_hi - q_lo) * 16.0;
-    if (read_bytes > 256.0 * 1024 * 1024)
-      hipLaunchKernelGGL(k_batch_reduce<3>, dim3(blocks), dim3(kBlock), 0, st, g, batch, n, out, q_lo, q_hi);
-    else
-      hipLaunchKernelGGL(k_batch_reduce<0>, dim3(blocks), dim3(kBlock), 0, st, g, batch, n, out, q_lo, q_hi);
+    const double read_bytes = (double)batch * (double)(q_hi - q_lo) * (io == 0 ? 16.0 : 8.0);
+    const int code = io + ((read_bytes > 256.0 * 1024 * 1024) ? 3 : 0);   // io_load4: +3 = non-temporal
+#define ADVX_BR(T) \
+  hipLaunchKernelGGL(k_batch_reduce<T>, dim3(blocks), dim3(kBlock), 0, st, (const void*)g, batch, n, out, q_lo, q_hi)
+    switch (code) {
+      case 0: ADVX_BR(0); break;
+      case 1: ADVX_BR(1); break;
+      case 2: ADVX_BR(2); break;
+      case 3: ADVX_BR(3); break;
+      case 4: ADVX_BR(4); break;
+      default: ADVX_BR(5); break;
+    }
+#undef ADVX_BR
   } else {
     // rows are not 16-byte aligned: scalar columns (test-sized inputs only)
     hipLaunchKernelGGL(k_batch_reduce_scalar, dim3(grid_for(n)), dim3(kBlock), 0, st, g, batch, n, out);
@@ -654,11 +677,11 @@ extern "C" int32_t advx_collect(advx_plan* p, const float* grad_out, int32_t bat
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const float* gsum = grad_out;
-  if (batch > 1) {
+  if (batch > 1 || p->io != 0) {   // a half gradient is widened by the (one-row) reduction
     // the emits cover [lo, hi); what lies outside is constant padding whose gradient goes nowhere
     long long lo, hi;
     plan_live_range(p, &lo, &hi);
-    rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st, lo, hi);
+    rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st, lo, hi, p->io);
     if (rc) return rc;
     gsum = ws + p->dplan.gsum_off;
   }
@@ -1557,11 +1580,14 @@ extern "C" int32_t advx_prepared_fwd(advx_plan* p, const float* pp, const float*
   emit_slices(q_hi - q_lo, batch, &gx, &slices, &bps);
   dim3 grid(gx, slices);
   const float* sigma_dev = stats + ADVX_STAT_QERR_STD;   // quantise error of the PREVIOUS image (not yet rotated)
-#define ADVX_EMIT(N)                                                                                                \
-  hipLaunchKernelGGL(k_emit<N>, grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, offset, \
-                     out, q_lo, q_hi, live_lo, live_hi)
+#define ADVX_EMIT_T(N, T)                                                                                           \
+  hipLaunchKernelGGL((k_emit<N, T>), grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, \
+                     offset, (void*)out, q_lo, q_hi, live_lo, live_hi)
+#define ADVX_EMIT(N) \
+  do { if (p->io == 0) ADVX_EMIT_T(N, 0); else if (p->io == 1) ADVX_EMIT_T(N, 1); else ADVX_EMIT_T(N, 2); } while (0)
   if (noise == 0) ADVX_EMIT(0); else if (noise == 1) ADVX_EMIT(1); else ADVX_EMIT(2);
 #undef ADVX_EMIT
+#undef ADVX_EMIT_T
   LAUNCH_CHECK();
   return ADVX_OK;
 }
@@ -1586,7 +1612,7 @@ extern "C" int32_t advx_prepared_bwd(advx_plan* p, const float* grad_out, int32_
   const long long n = 3LL * p->info.in_h * p->info.in_w;
   long long lo, hi;
   plan_live_range(p, &lo, &hi);
-  rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st, lo, hi);
+  rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st, lo, hi, p->io);
   if (rc) return rc;
   const float* gsum = ws + p->dplan.gsum_off;
   const float* dgrad0 = prepared_upper_bwd(p, gsum, ws, st);
@@ -1620,7 +1646,7 @@ static int32_t prepared_grad_impl(advx_plan* p, const float* grad_out, int32_t b
   const long long n = 3LL * p->info.in_h * p->info.in_w;
   long long lo, hi;
   plan_live_range(p, &lo, &hi);
-  int32_t rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st, lo, hi);
+  int32_t rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st, lo, hi, p->io);
   if (rc) return rc;
   const float* dgrad0 = prepared_upper_bwd(p, ws + p->dplan.gsum_off, ws, st);
   LAUNCH_CHECK();

@@ -500,6 +500,63 @@ __global__ void __launch_bounds__(kBlock) k_crop_bwd(DStage st, const float* __r
   }
 }
 
+// Element type of the two B*P_out tensors at the VLM boundary: 0 = float32 (what the reference
+// hands to / gets from the model), 1 = float16, 2 = bfloat16.  A half-precision model casts
+// pixel_values on entry and autograd casts the gradient back, both exactly representable
+// steps (round-to-nearest-even on the way in, widening on the way out), so emitting / reading
+// the model's dtype directly gives bit-identical numerics with half the traffic.
+// 3 = float32 read with non-temporal loads: a gradient tensor larger than the 256 MiB Infinity
+// Cache is read once and only evicts what the next launches need (measured: Phi-3.5 512 -18 us,
+// Qwen2-VL 512 -12 us per step; the 86.7 MB headline tensor is better off cached: +1.6 us).
+template <int IO>
+__device__ inline float4 io_load4(const void* __restrict__ base, size_t idx) {
+  if (IO == 0) return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
+  if (IO == 3) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v r = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(reinterpret_cast<const float*>(base) + idx));
+    return make_float4(r.x, r.y, r.z, r.w);
+  }
+  // 1 / 2: float16 / bfloat16, cached; 4 / 5: the same read with non-temporal loads
+  uint2 raw;
+  if (IO >= 4) {
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    u2v r = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(reinterpret_cast<const unsigned short*>(base) + idx));
+    raw = make_uint2(r.x, r.y);
+  } else {
+    raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+  }
+  if (IO == 1 || IO == 4) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 a = __builtin_bit_cast(h2, raw.x), b = __builtin_bit_cast(h2, raw.y);
+    return make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+  }
+  return make_float4(__builtin_bit_cast(float, raw.x << 16), __builtin_bit_cast(float, raw.x & 0xffff0000u),
+                     __builtin_bit_cast(float, raw.y << 16), __builtin_bit_cast(float, raw.y & 0xffff0000u));
+}
+
+// streaming (non-temporal) store of four consecutive elements
+template <int IO>
+__device__ inline void io_store4(void* __restrict__ base, size_t idx, float4 v) {
+  if (IO == 0) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v ov = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(ov, reinterpret_cast<f4v*>(reinterpret_cast<float*>(base) + idx));
+    return;
+  }
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  u2v packed;
+  if (IO == 1) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 a = {(_Float16)v.x, (_Float16)v.y}, b = {(_Float16)v.z, (_Float16)v.w};   // v_cvt_f16_f32: RNE
+    packed = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+  } else {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    b2 a = {(__bf16)v.x, (__bf16)v.y}, b = {(__bf16)v.z, (__bf16)v.w};           // v_cvt_pk_bf16_f32: RNE
+    packed = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+  }
+  __builtin_nontemporal_store(packed, reinterpret_cast<u2v*>(reinterpret_cast<unsigned short*>(base) + idx));
+}
+
 // ================================================================================ emit
 // out[b, idx] = canvas value of flat index idx (+ sigma * N(0,1)); one thread = 4
 // consecutive flat indices (16-byte coalesced stores), blockIdx.y = slice of the batch.
@@ -516,11 +573,11 @@ __device__ inline float emit_value(const DPlan& pl, const float* __restrict__ ws
 }
 
 // NOISE: 0 none, 1 unit-noise tensor supplied, 2 in-kernel Philox
-template <int NOISE>
+template <int NOISE, int IO>   // IO: boundary dtype of `out` (0 f32, 1 f16, 2 bf16; halves need n % 4 == 0)
 __global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restrict__ ws, int batch, int b_per_slice,
                                                  const float* __restrict__ sigma_dev, const float* __restrict__ unit_noise,
                                                  unsigned long long seed, unsigned long long offset,
-                                                 float* __restrict__ out, long long q_lo, long long q_hi,
+                                                 void* __restrict__ out, long long q_lo, long long q_hi,
                                                  long long live_lo, long long live_hi) {
   // Only the float4 columns [q_lo, q_hi) are written.  The default is all of them, noise
   // included on the constant padding tiles, as the reference does (attack_model.py:320 adds
@@ -567,13 +624,11 @@ __global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restri
         if (i0 + k < live_lo || i0 + k >= live_hi) o[k] = 0.0f;
     }
     if (vec) {
-      // write-once stream: non-temporal, like the fused forward
-      typedef float f4v __attribute__((ext_vector_type(4)));
-      f4v ov = {o[0], o[1], o[2], o[3]};
-      __builtin_nontemporal_store(ov, reinterpret_cast<f4v*>(out + (size_t)b * n + i0));
+      // write-once stream: non-temporal, like the fused forward; rounded once to the boundary dtype
+      io_store4<IO>(out, (size_t)b * n + i0, make_float4(o[0], o[1], o[2], o[3]));
     } else {
       for (int k = 0; k < 4; ++k)
-        if (i0 + k < n) out[(size_t)b * n + i0 + k] = o[k];
+        if (i0 + k < n) reinterpret_cast<float*>(out)[(size_t)b * n + i0 + k] = o[k];
     }
   }
 }
@@ -583,55 +638,6 @@ __global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restri
 // meet in LDS; every wave-level load is 1 KiB contiguous.  Summation order is fixed
 // (b ascending inside a wave, waves 0..3) so the result is bitwise reproducible.
 __device__ inline float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-
-// Element type of the two B*P_out tensors at the VLM boundary: 0 = float32 (what the reference
-// hands to / gets from the model), 1 = float16, 2 = bfloat16.  A half-precision model casts
-// pixel_values on entry and autograd casts the gradient back, both exactly representable
-// steps (round-to-nearest-even on the way in, widening on the way out), so emitting / reading
-// the model's dtype directly gives bit-identical numerics with half the traffic.
-// 3 = float32 read with non-temporal loads: a gradient tensor larger than the 256 MiB Infinity
-// Cache is read once and only evicts what the next launches need (measured: Phi-3.5 512 -18 us,
-// Qwen2-VL 512 -12 us per step; the 86.7 MB headline tensor is better off cached: +1.6 us).
-template <int IO>
-__device__ inline float4 io_load4(const void* __restrict__ base, size_t idx) {
-  if (IO == 0) return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
-  if (IO == 3) {
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    f4v r = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(reinterpret_cast<const float*>(base) + idx));
-    return make_float4(r.x, r.y, r.z, r.w);
-  }
-  uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
-  if (IO == 1) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    h2 a = __builtin_bit_cast(h2, raw.x), b = __builtin_bit_cast(h2, raw.y);
-    return make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
-  }
-  return make_float4(__builtin_bit_cast(float, raw.x << 16), __builtin_bit_cast(float, raw.x & 0xffff0000u),
-                     __builtin_bit_cast(float, raw.y << 16), __builtin_bit_cast(float, raw.y & 0xffff0000u));
-}
-
-// streaming (non-temporal) store of four consecutive elements
-template <int IO>
-__device__ inline void io_store4(void* __restrict__ base, size_t idx, float4 v) {
-  if (IO == 0) {
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    f4v ov = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(ov, reinterpret_cast<f4v*>(reinterpret_cast<float*>(base) + idx));
-    return;
-  }
-  typedef unsigned u2v __attribute__((ext_vector_type(2)));
-  u2v packed;
-  if (IO == 1) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    h2 a = {(_Float16)v.x, (_Float16)v.y}, b = {(_Float16)v.z, (_Float16)v.w};   // v_cvt_f16_f32: RNE
-    packed = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
-  } else {
-    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-    b2 a = {(__bf16)v.x, (__bf16)v.y}, b = {(__bf16)v.z, (__bf16)v.w};           // v_cvt_pk_bf16_f32: RNE
-    packed = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
-  }
-  __builtin_nontemporal_store(packed, reinterpret_cast<u2v*>(reinterpret_cast<unsigned short*>(base) + idx));
-}
 
 template <int IO = 0>
 __device__ inline float4 batch_column_sum(const void* __restrict__ g, int batch, long long n, long long i0,
@@ -659,8 +665,8 @@ __device__ inline float4 batch_column_sum(const void* __restrict__ g, int batch,
 
 // Only the float4 columns [q_lo, q_hi) are reduced: the gradient of the constant padding tiles
 // (llama32processor.py:344-346, phi3processor.py:232-235) is never read.
-template <int IO>   // 0: cached loads, 3: non-temporal loads (io_load4)
-__global__ void __launch_bounds__(kBlock) k_batch_reduce(const float* __restrict__ g, int batch, long long n,
+template <int IO>   // io_load4 code: 0 / 1 / 2 cached f32 / f16 / bf16, 3 / 4 / 5 the same non-temporal
+__global__ void __launch_bounds__(kBlock) k_batch_reduce(const void* __restrict__ g, int batch, long long n,
                                                          float* __restrict__ out, long long q_lo, long long q_hi) {
   __shared__ float4 part[kBlock / kWave][kWave];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
@@ -674,13 +680,13 @@ __global__ void __launch_bounds__(kBlock) k_batch_reduce(const float* __restrict
     float4 t = f4add(f4add(f4add(part[0][lane], part[1][lane]), part[2][lane]), part[3][lane]);
     *reinterpret_cast<float4*>(out + (q << 2)) = t;
   }
-  // scalar tail (n not a multiple of 4): last block, first threads
-  if (q_hi == n4 && blockIdx.x == gridDim.x - 1) {
+  // scalar tail (n not a multiple of 4; float32 only): last block, first threads
+  if ((IO == 0 || IO == 3) && q_hi == n4 && blockIdx.x == gridDim.x - 1) {
     long long tail0 = n4 << 2;
     long long i = tail0 + threadIdx.x;
     if (i < n) {
       float s = 0.0f;
-      for (int b = 0; b < batch; ++b) s += g[(size_t)b * n + i];
+      for (int b = 0; b < batch; ++b) s += reinterpret_cast<const float*>(g)[(size_t)b * n + i];
       out[i] = s;
     }
   }

@@ -26,6 +26,17 @@ def _stream(t):
     return L.current_stream(t.device)
 
 
+def _plan_dtype(plan):
+    """Boundary dtype of a plan's pixel_values / grad_out (Plan.set_io; float32 unless changed)."""
+    return getattr(plan, "io_dtype", torch.float32)
+
+
+def _boundary(plan, t, what):
+    if t.dtype != _plan_dtype(plan):
+        raise L.AdvxError(f"{what} must be {_plan_dtype(plan)} (the plan's boundary dtype), got {t.dtype}")
+    return t.contiguous()
+
+
 def _crop_arg(crop):
     if crop is None:
         return None, None
@@ -49,7 +60,9 @@ def emit(plan, argument, batch, sigma_dev=None, unit_noise=None, philox=None, wo
     if keep_padding and (out is None or out.numel() != batch * plan.out_numel):
         raise L.AdvxError("keep_padding needs the caller's persistent [batch, out_numel] buffer")
     if out is None:
-        out = torch.empty((batch, plan.out_numel), dtype=torch.float32, device=dev)
+        out = torch.empty((batch, plan.out_numel), dtype=_plan_dtype(plan), device=dev)
+    else:
+        out = _boundary(plan, out, "out")
     seed, offset = (philox if philox is not None else (0, 0))
     if unit_noise is not None:
         unit_noise = _f32c(unit_noise)
@@ -64,7 +77,7 @@ def emit(plan, argument, batch, sigma_dev=None, unit_noise=None, philox=None, wo
 def collect(plan, grad_out, batch, grad_argument=None, accumulate=False, workspace=None):
     """Backward of `emit`: grad_out [batch, out_numel] -> grad wrt the [3,H,W] argument."""
     _require_cuda(grad_out)
-    grad_out = _f32c(grad_out)
+    grad_out = _boundary(plan, grad_out, "grad_out")
     dev = grad_out.device
     if grad_out.numel() != batch * plan.out_numel:
         raise L.AdvxError("grad_out has the wrong number of elements")
@@ -266,7 +279,9 @@ def prepared_fwd(plan, p, x0, epsilon, batch, stats, scratch, workspace, s_buf, 
     if keep_padding and (out is None or out.numel() != batch * plan.out_numel):
         raise L.AdvxError("keep_padding needs the caller's persistent [batch, out_numel] buffer")
     if out is None:
-        out = torch.empty((batch, plan.out_numel), dtype=torch.float32, device=p.device)
+        out = torch.empty((batch, plan.out_numel), dtype=_plan_dtype(plan), device=p.device)
+    else:
+        out = _boundary(plan, out, "out")
     if unit_noise is not None:
         unit_noise = _f32c(unit_noise)
         if unit_noise.numel() != batch * plan.out_numel:
@@ -282,7 +297,7 @@ def prepared_fwd(plan, p, x0, epsilon, batch, stats, scratch, workspace, s_buf, 
 def prepared_bwd(plan, grad_out, batch, p, x0, epsilon, imgfit_scale, mask, m, v, grad_p, opt, s_next, rows_in, parity,
                  stats, scratch, workspace):
     _require_cuda(grad_out, p, x0, mask, grad_p, s_next, stats, scratch, workspace)
-    grad_out = _f32c(grad_out)
+    grad_out = _boundary(plan, grad_out, "grad_out")
     if grad_out.numel() != batch * plan.out_numel:
         raise L.AdvxError("grad_out has the wrong number of elements")
     L.check(L.load().advx_prepared_bwd(plan.handle, L.ptr(grad_out), int(batch), L.ptr(p), L.ptr(x0), float(epsilon),
@@ -295,7 +310,7 @@ def prepared_bwd_grad(plan, grad_out, batch, p, x0, epsilon, imgfit_scale, grad_
                       workspace):
     """Data-parallel first half: batch-reduce and this rank's unmasked image gradient -> grad_p."""
     _require_cuda(grad_out, p, x0, grad_p, stats, scratch, workspace)
-    grad_out = _f32c(grad_out)
+    grad_out = _boundary(plan, grad_out, "grad_out")
     if grad_out.numel() != batch * plan.out_numel:
         raise L.AdvxError("grad_out has the wrong number of elements")
     L.check(L.load().advx_prepared_bwd_grad(plan.handle, L.ptr(grad_out), int(batch), L.ptr(p), L.ptr(x0), float(epsilon),
@@ -317,7 +332,7 @@ def prepared_bwd_dp(plan, exchange, grad_out, batch, p, x0, epsilon, imgfit_scal
                     stats, scratch, workspace):
     """Both halves around the peer exchange (dp.PeerExchange) in one call."""
     _require_cuda(grad_out, p, x0, mask, s_next, stats, scratch, workspace)
-    grad_out = _f32c(grad_out)
+    grad_out = _boundary(plan, grad_out, "grad_out")
     if grad_out.numel() != batch * plan.out_numel:
         raise L.AdvxError("grad_out has the wrong number of elements")
     L.check(L.load().advx_prepared_bwd_dp(plan.handle, exchange.handle, L.ptr(grad_out), int(batch), L.ptr(p), L.ptr(x0),

@@ -38,7 +38,7 @@ class PixelPGD:
                  optimizer="adamw", cross_mode=False, betas=(0.9, 0.999), adam_eps=1e-8, weight_decay=1e-2, seed=0,
                  process_group=None, allow_fused=True, fused_mode="auto", grad_prescale=None, force_exchange=False,
                  io_dtype=torch.float32, exchange_transport="auto", noise_on_padding=True):
-        """io_dtype: dtype of the pixel_values handed to the VLM by the fused pair.  float32 is
+        """io_dtype: dtype of the pixel_values handed to the VLM (every chain but `step`).  float32 is
         the reference's own boundary; float16 / bfloat16 emit the tensor already cast to the
         model's dtype (the cast the model's first layer would apply) and let backward_update
         read the half gradient directly.
@@ -123,9 +123,12 @@ class PixelPGD:
                 raise L.AdvxError("the one-launch step cannot host the gradient all-reduce: use fused_mode='pair'")
             self.mode = fused_mode
         ops.io_code(io_dtype)
-        if io_dtype != torch.float32 and self.mode != "pair":
-            raise L.AdvxError(f"io_dtype={io_dtype} needs the fused pair; this engine runs the {self.mode} chain")
-        self.io_dtype = io_dtype
+        if io_dtype != torch.float32 and self.mode == "step":
+            raise L.AdvxError(f"io_dtype={io_dtype} is not available in the one-launch step chain")
+        self._io_dtype = io_dtype
+        if self.mode != "pair":
+            for pl in self.plans:          # emit / collect / prepared_* follow the plan's boundary dtype
+                pl.set_io(io_dtype)
         if self.peer is not None and self.mode in ("pair", "prepared"):
             # the masked, all-reduced gradient of the last step lives in the exchange's recv buffer
             self.grad = self.peer.recv[:self.x0.numel()].view_as(self.x0)
@@ -163,6 +166,21 @@ class PixelPGD:
         self._last = None
         for pl in self.plans:
             pl.upload()
+
+    @property
+    def io_dtype(self):
+        return self._io_dtype
+
+    @io_dtype.setter
+    def io_dtype(self, dtype):
+        ops.io_code(dtype)
+        if dtype != torch.float32 and self.mode == "step":
+            raise L.AdvxError(f"io_dtype={dtype} is not available in the one-launch step chain")
+        self._io_dtype = dtype
+        if self.mode != "pair":
+            for pl in self.plans:
+                pl.set_io(dtype)
+            self._outs = [None] * len(self.plans)
 
     # ------------------------------------------------------------------ scalars
     def _opt_scalars(self, apply):
@@ -239,7 +257,7 @@ class PixelPGD:
             buf = None
             if keep:
                 if self._outs[0] is None or self._outs[0].shape[0] != B:
-                    self._outs[0] = torch.zeros((B, pl.out_numel), dtype=torch.float32, device=self.p.device)
+                    self._outs[0] = torch.zeros((B, pl.out_numel), dtype=self.io_dtype, device=self.p.device)
                 buf = self._outs[0]
             out = ops.prepared_fwd(pl, self.p, self.x0, self.eps, B, self.stats, self.prep_scratch, self.workspaces[0],
                                    self.s_bufs[self.s_cur], self.prepared, self.par, unit_noise=z, philox=ph, out=buf,
@@ -261,7 +279,7 @@ class PixelPGD:
             buf = None
             if keep:
                 if self._outs[i] is None or self._outs[i].shape[0] != B:
-                    self._outs[i] = torch.zeros((B, pl.out_numel), dtype=torch.float32, device=self.p.device)
+                    self._outs[i] = torch.zeros((B, pl.out_numel), dtype=self.io_dtype, device=self.p.device)
                 buf = self._outs[i]
             out = ops.emit(pl, arg, B, sigma_dev=sigma, unit_noise=z, philox=ph, workspace=self.workspaces[i], out=buf,
                            keep_padding=keep)

@@ -84,6 +84,12 @@ class Plan:
     def fused_supported(self):
         return bool(L.load().advx_fused_supported(self._h))
 
+    def set_io(self, dtype):
+        """Boundary dtype of this plan's pixel_values / their gradient (torch.float32 / float16 / bfloat16)."""
+        from .ops import io_code
+        L.check(L.load().advx_plan_set_io(self._h, io_code(dtype)), "advx_plan_set_io")
+        self.io_dtype = dtype
+
     def prepared_supported(self):
         return bool(L.load().advx_prepared_supported(self._h))
 

@@ -133,6 +133,14 @@ int32_t advx_plan_out_index(const advx_plan* plan, int32_t stage, int32_t c, int
 /* [lo, hi): flat indices of one sample that the plan's emits cover.  What lies outside is the
  * constant padding (zero tiles) of llama32processor.py:344-346 / phi3processor.py:232-235. */
 int32_t advx_plan_live_range(const advx_plan* plan, int64_t* lo, int64_t* hi);
+/* Boundary dtype of the plan's two B x out_numel tensors (`out` of advx_emit*, advx_prepared_fwd and
+ * `grad_out` of advx_collect, advx_prepared_bwd*): ADVX_IO_F32 (default, what the reference hands
+ * the model), ADVX_IO_F16 or ADVX_IO_BF16 = the model's own dtype - pixel_values are rounded once
+ * (the cast the vision tower applies first anyway), the half gradient is widened on load, all
+ * arithmetic stays fp32.  With a half dtype the `float*` parameters of those entry points point at
+ * half data; `unit_noise` stays float32.  Needs out_numel % 4 == 0. */
+int32_t advx_plan_set_io(advx_plan* plan, int32_t io_dtype);
+int32_t advx_plan_get_io(const advx_plan* plan);
 /* Host tap computation for an arbitrary 1-D resize (tests; also the crop window's tables). */
 int32_t advx_taps_compute(int32_t mode, int32_t in_size, int32_t out_size, int32_t transposed,
                           int32_t* n, int32_t* stride, int32_t* start, int32_t* count, float* weight);

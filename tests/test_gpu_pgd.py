@@ -225,15 +225,17 @@ def test_pair_half_io_is_the_models_own_cast(dev, dtype, noise):
     assert a == b
 
 
-def test_half_io_needs_the_pair(dev):
+def test_half_io_limits(dev):
     from adversarialvlm_amd import _lib as L
     from adversarialvlm_amd.pgd import PixelPGD
     Plan = _plans()
     x0 = torch.rand(3, 64, 64).to(dev)
     with pytest.raises(L.AdvxError):
-        PixelPGD(x0, [Plan.llava(64, 64, 32, 32)], io_dtype=torch.float16)          # generic chain
+        PixelPGD(x0, [Plan.llava(64, 64, 64, 64)], io_dtype=torch.float16, fused_mode="step")   # one-launch chain: fp32 only
     with pytest.raises(L.AdvxError):
         PixelPGD(x0, [Plan.llava(64, 64, 64, 64)], io_dtype=torch.float64)
+    with pytest.raises(L.AdvxError):
+        PixelPGD(x0[:, :5, :5].contiguous(), [Plan.llava(5, 5, 5, 5)], io_dtype=torch.float16, allow_fused=False)  # 75 % 4 != 0
 
 
 @pytest.mark.parametrize("kind", ["mllama", "phi3"])
@@ -374,3 +376,48 @@ def test_cross_mode_single_plan_pipelined_chains_agree_with_generic(dev, kind):
     assert rel_err(res["fast"][0], res["generic"][0]) < 2e-6
     for k, v in res["fast"][1].items():
         assert v == pytest.approx(res["generic"][1][k], rel=1e-5, abs=1e-12), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["mllama-prepared", "qwen2vl-prepared", "llava-blur-generic", "cross-generic"])
+def test_half_boundary_in_the_plan_chains(dev, dtype, kind):
+    """Plan.set_io / PixelPGD(io_dtype=...) outside the fused pair: pixel_values are the fp32
+    pixel_values rounded once to the model's dtype and a half gradient gives the update its
+    widened fp32 copy gives - both bit-exact - in the prepared and in the generic chain."""
+    from adversarialvlm_amd.pgd import PixelPGD
+    Plan = _plans()
+    B = 3
+    kw, blur_sigma = {}, None
+    if kind == "mllama-prepared":
+        H, W = 70, 100
+        mk = lambda: [Plan.mllama(H, W, tile=32)]
+        want = "prepared"
+    elif kind == "qwen2vl-prepared":
+        H, W = 60, 90
+        mk = lambda: [Plan.qwen2vl(H, W, min_pixels=28 * 28 * 4, max_pixels=28 * 28 * 64)]
+        want = "prepared"
+    elif kind == "llava-blur-generic":
+        H, W = 96, 80
+        mk = lambda: [Plan.llava(H, W, 48, 48)]
+        kw, blur_sigma, want = dict(blur_kernel=5), 1.3, "generic"
+    else:
+        H, W = 60, 90
+        mk = lambda: [Plan.phi3(H, W), Plan.mllama(H, W, tile=32)]
+        kw, want = dict(cross_mode=True, model_weights=[0.4, 1.1]), "generic"
+    x0 = torch.rand(3, H, W, generator=torch.Generator().manual_seed(61)).to(dev)
+    engines = {io: PixelPGD(x0, mk(), seed=4, io_dtype=io, **kw) for io in (torch.float32, dtype)}
+    assert all(e.mode == want for e in engines.values())
+    gen = torch.Generator().manual_seed(62)
+    for t in range(3):
+        outs = {io: e.forward(B, blur_sigma=blur_sigma) for io, e in engines.items()}
+        grads = []
+        for a, b in zip(outs[torch.float32], outs[dtype]):
+            assert b.dtype == dtype and torch.equal(a.to(dtype), b)
+            grads.append((torch.randn(a.shape, generator=gen) * 0.02).to(dev))
+        # what autograd hands over: the loss-scaled gradient in the model's dtype; the fp32 engine
+        # gets the same values widened (the reference's cast-backward)
+        scaled = [(g * engines[dtype].loss_scale(i)).to(dtype) for i, g in enumerate(grads)]
+        engines[dtype].backward_update(scaled)
+        engines[torch.float32].backward_update([g.float() for g in scaled])
+        assert torch.equal(engines[torch.float32].p, engines[dtype].p)
+    assert engines[torch.float32].stats_dict() == engines[dtype].stats_dict()

@@ -12,13 +12,13 @@ from adversarialvlm_amd.pgd import PixelPGD  # noqa: E402
 from adversarialvlm_amd.plan import Plan  # noqa: E402
 
 
-def run(name, plans, H, W, B, blur=None, crop=None, steps=50, cross=False, pad_noise=True, prepared=False):
+def run(name, plans, H, W, B, blur=None, crop=None, steps=50, cross=False, pad_noise=True, prepared=False, io=torch.float32):
     dev = torch.device("cuda:0")
     x0 = torch.rand(3, H, W, device=dev)
     eng = PixelPGD(x0, plans, blur_kernel=blur, use_crop=crop is not None, cross_mode=cross, allow_fused=prepared,
-                   fused_mode="prepared" if prepared else "auto", noise_on_padding=pad_noise)
-    name = f"{name} [{eng.mode}]"
-    gs = [torch.randn(B, pl.out_numel, device=dev) for pl in plans]
+                   fused_mode="prepared" if prepared else "auto", noise_on_padding=pad_noise, io_dtype=io)
+    name = f"{name} [{eng.mode}{'' if io == torch.float32 else ', ' + str(io).split('.')[-1]}]"
+    gs = [torch.randn(B, pl.out_numel, device=dev).to(io) for pl in plans]
 
     def step():
         eng.forward(B, blur_sigma=7.0 if blur else None, crop=crop)
@@ -35,8 +35,8 @@ def run(name, plans, H, W, B, blur=None, crop=None, steps=50, cross=False, pad_n
     # the elements an image reaches (the padding's gradient goes nowhere)
     live = [pl.live_range()[1] - pl.live_range()[0] for pl in plans]
     wr = sum(pl.out_numel if pad_noise else lv for pl, lv in zip(plans, live))
-    by = 4 * (B * (wr + sum(live)) + 10 * 3 * H * W)
-    print(f"{name:44s} B={B:3d}  {dt * 1e6:9.1f} us/step  {1 / dt:9.1f} steps/s  algorithmic {by / 1e6:8.1f} MB  "
+    by = (4 if io == torch.float32 else 2) * B * (wr + sum(live)) + 4 * 10 * 3 * H * W
+    print(f"{name:52s} B={B:3d}  {dt * 1e6:9.1f} us/step  {1 / dt:9.1f} steps/s  algorithmic {by / 1e6:8.1f} MB  "
           f"{by / dt / 1e12:5.2f} TB/s ({by / dt / 8e12:4.2f} of HBM peak)", flush=True)
 
 
@@ -56,6 +56,11 @@ if __name__ == "__main__":
     run("phi3 512, padding kept zero", [Plan.phi3(512, 512)], 512, 512, 64, pad_noise=False, prepared=True)
     run("qwen2vl 512", [Plan.qwen2vl(512, 512)], 512, 512, 64)
     run("qwen2vl 512", [Plan.qwen2vl(512, 512)], 512, 512, 64, prepared=True)
+    run("mllama 336 (4x560 tiles)", [Plan.mllama(336, 336)], 336, 336, 64, prepared=True, io=torch.float16)
+    run("mllama 336, padding kept zero", [Plan.mllama(336, 336)], 336, 336, 64, pad_noise=False, prepared=True, io=torch.float16)
+    run("phi3 512", [Plan.phi3(512, 512)], 512, 512, 64, prepared=True, io=torch.float16)
+    run("qwen2vl 512", [Plan.qwen2vl(512, 512)], 512, 512, 64, prepared=True, io=torch.bfloat16)
+    run("llava 512->336", [Plan.llava(512, 512)], 512, 512, 64, prepared=True, io=torch.float16)
     run("cross phi3+qwen+mllama 336 blur5", [Plan.phi3(336, 336), Plan.qwen2vl(336, 336), Plan.mllama(336, 336)], 336, 336,
         16, blur=5, cross=True)
     run("cross, padding kept zero", [Plan.phi3(336, 336), Plan.qwen2vl(336, 336), Plan.mllama(336, 336)], 336, 336,
