@@ -49,7 +49,7 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
           crop_scale_max=1.0, crop_ratio_min=0.75, crop_ratio_max=1.33,
           questions_file=None, test_questions_file=None, answers_file=None, log_every=1, use_wandb=False, seed=0,
           base_path="./runs", return_engine=False, resaved_loss_every=0, noise_on_padding=True,
-          suffix_only_ce=False):
+          suffix_only_ce=False, pixel_io="float32"):
     if clamp_method != "tanh":
         raise NotImplementedError("Clamping method except tanh are not implemented yet.")
     if mask_type == "random_square":
@@ -127,10 +127,13 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
                       seed=seed + 7919 * rank, allow_fused=(len(plans) == 1),   # one model on this rank: pipelined chains
                       process_group=torch.distributed.group.WORLD if world > 1 else None, grad_prescale=prescale,
                       noise_on_padding=noise_on_padding)
-    if world > 1:
-        # every rank sees ONE of the n_models image-fit terms; scaled by 1/group_size the SUM
-        # over all ranks restores "once per model"
-        pass
+    if pixel_io == "model":
+        # every model receives pixel_values in its own dtype (Qwen2-VL runs bf16, the others fp16)
+        from .ops import IO_DTYPES
+        dts = [next(m.parameters()).dtype for m in models]
+        engine.io_dtype = [d if d in IO_DTYPES else torch.float32 for d in dts]
+    elif pixel_io != "float32":
+        raise ValueError("pixel_io must be 'float32' or 'model'")
     logger = JsonlLogger(os.path.join(exp_path, "metrics.jsonl"), use_wandb and rank == 0, name=exp_name) if rank == 0 else None
 
     global_iteration = 0
@@ -249,6 +252,8 @@ def build_parser():
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no_noise_on_padding", dest="noise_on_padding", action="store_false",
                    help="keep the constant padding tiles of Mllama / Phi-3.5 exact zeros (the reference adds noise there)")
+    p.add_argument("--pixel_io", type=str, default="float32", choices=["float32", "model"],
+                   help="dtype of pixel_values at each VLM's boundary (model = that VLM's own half dtype)")
     p.add_argument("--suffix_only_ce", action="store_true",
                    help="logits of the target positions only (logits_to_keep) + HIP cross entropy: same loss, no [B,S,V] tensor")
     p.add_argument("--resaved_loss_every", type=int, default=0,

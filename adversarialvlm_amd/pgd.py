@@ -122,13 +122,7 @@ class PixelPGD:
             if fused_mode == "step" and self.exchange:
                 raise L.AdvxError("the one-launch step cannot host the gradient all-reduce: use fused_mode='pair'")
             self.mode = fused_mode
-        ops.io_code(io_dtype)
-        if io_dtype != torch.float32 and self.mode == "step":
-            raise L.AdvxError(f"io_dtype={io_dtype} is not available in the one-launch step chain")
-        self._io_dtype = io_dtype
-        if self.mode != "pair":
-            for pl in self.plans:          # emit / collect / prepared_* follow the plan's boundary dtype
-                pl.set_io(io_dtype)
+        self._set_io(io_dtype)
         if self.peer is not None and self.mode in ("pair", "prepared"):
             # the masked, all-reduced gradient of the last step lives in the exchange's recv buffer
             self.grad = self.peer.recv[:self.x0.numel()].view_as(self.x0)
@@ -167,20 +161,28 @@ class PixelPGD:
         for pl in self.plans:
             pl.upload()
 
+    def _set_io(self, dtype):
+        """One dtype for all plans, or one per plan (cross-model runs mix fp16 and bf16 models)."""
+        per_plan = list(dtype) if isinstance(dtype, (list, tuple)) else [dtype] * len(self.plans)
+        if len(per_plan) != len(self.plans):
+            raise L.AdvxError("io_dtype: one dtype, or one per plan")
+        for d in per_plan:
+            ops.io_code(d)
+            if d != torch.float32 and self.mode == "step":
+                raise L.AdvxError(f"io_dtype={d} is not available in the one-launch step chain")
+        self._io_dtype = per_plan[0] if len(set(per_plan)) == 1 else tuple(per_plan)
+        if self.mode != "pair":
+            for pl, d in zip(self.plans, per_plan):     # emit / collect / prepared_* follow the plan's boundary dtype
+                pl.set_io(d)
+            self._outs = [None] * len(self.plans)
+
     @property
     def io_dtype(self):
         return self._io_dtype
 
     @io_dtype.setter
     def io_dtype(self, dtype):
-        ops.io_code(dtype)
-        if dtype != torch.float32 and self.mode == "step":
-            raise L.AdvxError(f"io_dtype={dtype} is not available in the one-launch step chain")
-        self._io_dtype = dtype
-        if self.mode != "pair":
-            for pl in self.plans:
-                pl.set_io(dtype)
-            self._outs = [None] * len(self.plans)
+        self._set_io(dtype)
 
     # ------------------------------------------------------------------ scalars
     def _opt_scalars(self, apply):
@@ -257,7 +259,7 @@ class PixelPGD:
             buf = None
             if keep:
                 if self._outs[0] is None or self._outs[0].shape[0] != B:
-                    self._outs[0] = torch.zeros((B, pl.out_numel), dtype=self.io_dtype, device=self.p.device)
+                    self._outs[0] = torch.zeros((B, pl.out_numel), dtype=ops._plan_dtype(pl), device=self.p.device)
                 buf = self._outs[0]
             out = ops.prepared_fwd(pl, self.p, self.x0, self.eps, B, self.stats, self.prep_scratch, self.workspaces[0],
                                    self.s_bufs[self.s_cur], self.prepared, self.par, unit_noise=z, philox=ph, out=buf,
@@ -279,7 +281,7 @@ class PixelPGD:
             buf = None
             if keep:
                 if self._outs[i] is None or self._outs[i].shape[0] != B:
-                    self._outs[i] = torch.zeros((B, pl.out_numel), dtype=self.io_dtype, device=self.p.device)
+                    self._outs[i] = torch.zeros((B, pl.out_numel), dtype=ops._plan_dtype(pl), device=self.p.device)
                 buf = self._outs[i]
             out = ops.emit(pl, arg, B, sigma_dev=sigma, unit_noise=z, philox=ph, workspace=self.workspaces[i], out=buf,
                            keep_padding=keep)

@@ -134,7 +134,7 @@ def test_cross_trainer_two_models(tmp_path):
                                     mask_size=None, clamp_method="tanh", epsilon=0.4, sigma=1e-3, start_from_white=False,
                                     target_text_random=False, DPO_flag=False, model_weights=[0.2, 0.8],
                                     use_gaussian_blur=True, gblur_kernel_size=5, base_path=str(tmp_path),
-                                    resaved_loss_every=3, suffix_only_ce=True)
+                                    resaved_loss_every=3, suffix_only_ce=True, pixel_io="model")
     assert len(hist) == 4 and all(np.isfinite(h["loss_per_iteration"]) for h in hist)
     assert [("loss_resaved" in h) for h in hist] == [True, False, False, True] and np.isfinite(hist[3]["loss_resaved"])
     assert "optimized_image_iter_final.png" in os.listdir(os.path.join(str(tmp_path), "t3"))
