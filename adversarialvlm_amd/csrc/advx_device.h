@@ -238,10 +238,22 @@ __device__ inline uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
 // four N(0,1) draws from one Philox block: Box-Muller on uniforms built with one convert and
 // one fma each (u = r * 2^-32 [+ 2^-33 to keep the logarithm's argument in (0,1]]); raw
 // v_log / v_sqrt / v_sin / v_cos (the angle is in revolutions, v_log is log2).
+__device__ inline float4 box_muller4(uint4 r);
 __device__ inline float4 philox_normal4(unsigned long long gidx, unsigned long long offset,
                                         unsigned long long seed) {
   uint4 c = make_uint4((uint32_t)gidx, (uint32_t)(gidx >> 32), (uint32_t)offset, (uint32_t)(offset >> 32));
-  uint4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return box_muller4(philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32)));
+}
+// batched streams (k_emit, k_fused_fwd): counter = (quad q of the sample, batch row b, offset).  A thread
+// keeps q and walks b, so only the second counter word changes inside its loop: the products of
+// round 1 and one product each of rounds 2 and 3 do not depend on b and are hoisted by the
+// compiler (4 of the 20 v_mad_u64_u32 per block, against 1 with a flat b*n4+q counter).
+__device__ inline float4 philox_normal4_qb(uint32_t q, uint32_t b, unsigned long long offset,
+                                           unsigned long long seed) {
+  uint4 c = make_uint4(q, b, (uint32_t)offset, (uint32_t)(offset >> 32));
+  return box_muller4(philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32)));
+}
+__device__ inline float4 box_muller4(uint4 r) {
   const float k32 = 2.3283064365386963e-10f;   // 2^-32
   const float k33 = 1.1641532182693481e-10f;   // 2^-33
   float u1 = __builtin_fmaf((float)r.x, k32, k33);  // (0, 1]

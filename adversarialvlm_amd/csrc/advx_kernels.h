@@ -615,7 +615,7 @@ __global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restri
           if (i0 + k < n) o[k] = v[k] + unit_noise[(size_t)b * n + i0 + k] * sigma;
       }
     } else if (NOISE == 2) {
-      float4 z = philox_normal4((unsigned long long)b * (unsigned long long)n4 + (unsigned long long)q, offset, seed);
+      float4 z = philox_normal4_qb((uint32_t)q, (uint32_t)b, offset, seed);
       o[0] = v[0] + z.x * sigma; o[1] = v[1] + z.y * sigma; o[2] = v[2] + z.z * sigma; o[3] = v[3] + z.w * sigma;
     }
     if (edge) {
@@ -828,7 +828,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ 
       float4 z = *reinterpret_cast<const float4*>(unit_noise + (size_t)b * n + i0);
       o = make_float4(v.x + z.x * sigma, v.y + z.y * sigma, v.z + z.z * sigma, v.w + z.w * sigma);
     } else if (NOISE == 2) {
-      float4 z = philox_normal4((unsigned long long)b * (unsigned long long)n4 + (unsigned long long)q, offset, seed);
+      float4 z = philox_normal4_qb((uint32_t)q, (uint32_t)b, offset, seed);
       o = make_float4(v.x + z.x * sigma, v.y + z.y * sigma, v.z + z.z * sigma, v.w + z.w * sigma);
     }
     // write-once stream: non-temporal stores keep it out of the way of grad_out in the

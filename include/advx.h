@@ -150,7 +150,9 @@ int32_t advx_taps_compute(int32_t mode, int32_t in_size, int32_t out_size, int32
  *              (attack_model.py:314-321): argument [3,H,W] -> out [B, out_numel].
  *   unit_noise : optional N(0,1) tensor [B, out_numel] (parity mode); if NULL and
  *                use_philox != 0 the noise is generated in-kernel (Philox4x32-10 +
- *                Box-Muller, keyed by seed/offset); if both are off no noise is added.
+ *                Box-Muller; key = seed, element 4q+k of row b = k-th output of the block
+ *                with counter (q, b, offset_lo, offset_hi); oracle/philox.py restates it);
+ *                if both are off no noise is added.
  *   sigma_dev  : device pointer to the noise sigma (stats + ADVX_STAT_SIGMA), may be NULL
  *                when no noise is requested.
  * advx_collect = backward of the above: grad_out [B, out_numel] -> grad_argument [3,H,W]

@@ -109,6 +109,18 @@ def test_philox_normal_statistics(ops, dev):
     assert abs(np.corrcoef(z, z3)[0, 1]) < 5e-3        # different offset: independent stream
 
 
+@pytest.mark.parametrize("n", [4096, 1001])
+def test_philox_normal_matches_oracle(ops, dev, n):
+    """The device generator is Philox4x32-10 (oracle/philox.py, pinned by the Random123 known answers)
+    with counter (q, 0, offset) and Box-Muller on the hardware log2/sqrt/sin/cos: compared at their
+    tolerance, far below anything a different counter, key or round count could pass."""
+    from oracle import philox
+    seed, offset = 0x1234567890ABCDEF, (7 << 32) | 9
+    z = ops.philox_normal(n, seed=seed, offset=offset, device=dev).cpu().double().numpy()
+    ref = philox.unit_noise(1, n, seed, offset)[0]
+    assert np.abs(z - ref).max() < 2e-5
+
+
 def test_adamw_trajectory_golden(ops, dev):
     """torch.optim.AdamW + StepLR 6-step trajectory captured in closed_form.npz."""
     from adversarialvlm_amd import _lib as L

@@ -1,6 +1,7 @@
 """GPU tier: multi-step PGD trajectories of the HIP engine (PixelPGD, through the C ABI)
 against the CPU oracle (oracle/pgd.py) on identical inputs: noise, blur sigma and crop
 window are passed to both.  Bar: p, grad, sigma within 1e-4 relative (north star)."""
+import numpy as np
 import pytest
 import torch
 
@@ -134,7 +135,35 @@ def test_fused_chains_agree(dev):
     assert abs(float(z.mean())) < 2e-2 and abs(float(z.std()) - 2 ** 0.5) < 3e-2
 
 
+@pytest.mark.parametrize("mode", ["pair", "prepared", "generic"])
+def test_chain_noise_stream_matches_oracle(dev, mode):
+    """Every chain addresses the generator the same way: step t, batch row b, element i of the emitted
+    sample <- Philox block (i//4, b, offset=t) under key=seed (oracle/philox.py)."""
+    from oracle import philox
+    from adversarialvlm_amd.pgd import PixelPGD
+    Plan = _plans()
+    x0 = torch.rand(3, 112, 112, generator=torch.Generator().manual_seed(3)).to(dev)
+    g = (torch.randn(6, 3, 112, 112, generator=torch.Generator().manual_seed(4)) * 0.01).to(dev)
+    kw = dict(seed=21, fused_mode=mode if mode != "generic" else "auto", allow_fused=mode != "generic")
+    noisy_eng = PixelPGD(x0, [Plan.llava(112, 112, 112, 112)], **kw)
+    clean_eng = PixelPGD(x0, [Plan.llava(112, 112, 112, 112)], **kw)
+    assert noisy_eng.mode == mode
+    for t in range(2):
+        noisy = noisy_eng.forward(6)[0].double()
+        clean = clean_eng.forward(6, use_philox=False)[0].double()
+        d = (noisy - clean).cpu().numpy().reshape(6, -1)
+        ref = philox.unit_noise(6, 3 * 112 * 112, 21, t)
+        sigma = float((d * ref).sum() / (ref * ref).sum())      # the step's sigma lives on the device
+        assert 1e-4 < sigma < 1e-1
+        z = d / sigma
+        # clean + sigma z is rounded to fp32 at values of a few units; sigma is ~1e-3
+        assert np.abs(z - ref).max() < 1e-5 + 2.0 ** -22 * 4 / sigma
+        noisy_eng.backward_update([g])
+        clean_eng.backward_update([g])
+
+
 def test_llava_downsample_blur_crop_mask_accum(dev):
+
     Plan = _plans()
     torch.manual_seed(2)
     H, W = 96, 80

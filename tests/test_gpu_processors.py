@@ -188,6 +188,27 @@ def test_emit_philox_noise_statistics(dev):
     assert torch.equal(noisy, again)                          # counter-based: reproducible
 
 
+@pytest.mark.parametrize("kind", ["llava", "qwen2vl", "mllama"])
+def test_emit_philox_noise_matches_oracle(dev, kind):
+    """Element i of batch row b gets lane i%4 of Philox block (i//4, b, offset) -- in every layout, the
+    flat index of the emitted sample addresses the stream (oracle/philox.py::unit_noise)."""
+    from oracle import philox
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan
+    plan = {"llava": lambda: Plan.llava(48, 40, 32, 32),
+            "qwen2vl": lambda: Plan.qwen2vl(60, 90, min_pixels=28 * 28 * 4, max_pixels=28 * 28 * 64),
+            "mllama": lambda: Plan.mllama(64, 64, tile=32)}[kind]()
+    img = torch.rand(3, plan.in_h, plan.in_w, device=dev)
+    B, seed, offset = 5, 99, (1 << 33) + 4
+    sig = torch.tensor([0.25], device=dev)
+    clean = ops.emit(plan, img, B).double()
+    noisy = ops.emit(plan, img, B, sigma_dev=sig, philox=(seed, offset)).double()
+    z = ((noisy - clean) / 0.25).cpu().numpy().reshape(B, -1)
+    ref = philox.unit_noise(B, plan.out_numel, seed, offset)
+    # fp32 rounding of clean + 0.25 z (values of a few units) on top of the generator's own tolerance
+    assert np.abs(z - ref).max() < 1e-5 + 4 * 2.0 ** -22 * float(clean.abs().max() + 2)
+
+
 def test_layout_index_map_matches_device(dev):
     """advx_plan_out_index (host) vs what the device wrote: integer layout bit-exact."""
     from adversarialvlm_amd import ops
