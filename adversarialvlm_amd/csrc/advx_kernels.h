@@ -1244,7 +1244,7 @@ __global__ void __launch_bounds__(kBlock) k_step_flush(const double* __restrict_
   if (n_norm > 0) finalize_norm_block(norm_rows, n_norm, stats);
 }
 
-// stats finalisation for the fused pair: image statistics + (optionally) the gradient norm
+// the generator on its own (tests, advx_philox_normal): batch row 0 of the stream k_emit uses
 __global__ void __launch_bounds__(kBlock) k_philox_normal(float* __restrict__ out, long long n,
                                                           unsigned long long seed, unsigned long long offset) {
   long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;

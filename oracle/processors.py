@@ -15,8 +15,21 @@ CLIP_STD = [0.26862954, 0.26130258, 0.27577711]
 
 
 def _aa(img, h, w):
-    return F.interpolate(img.unsqueeze(0), size=[int(h), int(w)], mode="bilinear",
-                         align_corners=False, antialias=True).squeeze(0)
+    """`F.interpolate(..., mode='bilinear', antialias=True)` as the reference's GPU run evaluates it.
+
+    ATen's CPU kernel (torch 2.10 here) resamples the width first and then the height, and its height
+    pass goes wrong on an image that is ONE pixel wide: 594x1 -> 16x1 differs by 0.1-0.9 from the same
+    column inside a two-pixel-wide image, from the explicit tap tables (oracle/resample.py) and from
+    the GPU kernel (tests/test_gpu_processors.py::test_width_one_resize_follows_the_gpu_kernel).  Found
+    by tools/fuzz_parity.py on a 594x24 image in one 16x16 Mllama tile.  The reference runs on the GPU,
+    so a width-1 result takes the same two passes with the column duplicated for the second one."""
+    x = img.unsqueeze(0)
+    h, w = int(h), int(w)
+    if w == 1 and h != x.shape[2]:
+        x = F.interpolate(x, size=[x.shape[2], 1], mode="bilinear", align_corners=False, antialias=True)
+        x = x.expand(-1, -1, -1, 2).contiguous()
+        return F.interpolate(x, size=[h, 2], mode="bilinear", align_corners=False, antialias=True)[..., :1].squeeze(0)
+    return F.interpolate(x, size=[h, w], mode="bilinear", align_corners=False, antialias=True).squeeze(0)
 
 
 def _norm(img, mean, std):

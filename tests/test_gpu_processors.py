@@ -209,6 +209,42 @@ def test_emit_philox_noise_matches_oracle(dev, kind):
     assert np.abs(z - ref).max() < 1e-5 + 4 * 2.0 ** -22 * float(clean.abs().max() + 2)
 
 
+def test_width_one_resize_follows_the_gpu_kernel(dev):
+    """594x24 into one 16x16 Mllama tile resizes to 16x1.  torch's GPU antialias kernel (what the
+    reference runs), the tap tables and the HIP path agree; ATen's CPU kernel does not for a width-1
+    image, which is why oracle/processors.py::_aa widens the column (found by tools/fuzz_parity.py)."""
+    import torch.nn.functional as F
+    from oracle.processors import _aa
+    from adversarialvlm_amd.plan import Plan
+    img = torch.rand(3, 594, 24, generator=torch.Generator().manual_seed(0))
+    on_gpu = F.interpolate(img.to(dev)[None], size=[16, 1], mode="bilinear", align_corners=False, antialias=True)[0].cpu()
+    assert rel_err(_aa(img, 16, 1), on_gpu) < TIGHT
+    plan = Plan.mllama(594, 24, tile=16, max_tiles=1)
+    x = img.clone().requires_grad_(True)
+    ref = MllamaOracle(tile=16, max_tiles=1).process(x)["pixel_values"]
+    up = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1))
+    ref.backward(up)
+    pv, grad = _run(plan, img, up, dev)
+    assert rel_err(pv, ref.detach()) < TIGHT and rel_err(grad, x.grad) < 2e-5
+
+
+def test_random_geometries(dev):
+    """Seeded subset of tools/fuzz_parity.py: extreme aspect ratios, images below one tile, odd sizes
+    and processor parameters, forward + backward + integer metadata against the oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    rng = np.random.default_rng(2024)
+    bad = []
+    for k in range(60):
+        kind, H, W, args = fuzz_parity.draw_case(rng)
+        verdict, ef, eb = fuzz_parity.run_case(kind, H, W, args, dev, 7000 + k)
+        if verdict not in ("ok", "both-reject"):
+            bad.append((kind, H, W, args, verdict, ef, eb))
+    assert not bad, bad
+
+
 def test_layout_index_map_matches_device(dev):
     """advx_plan_out_index (host) vs what the device wrote: integer layout bit-exact."""
     from adversarialvlm_amd import ops

@@ -47,3 +47,23 @@ def test_transposed_taps_are_the_matrix_transpose(mode, n, m):
     M = R.taps_to_matrix(taps, n)
     Mt = R.taps_to_matrix(R.transpose_taps(taps, n), m)
     assert np.array_equal(Mt, M.T)
+
+
+@pytest.mark.parametrize("H,W,oh", [(594, 24, 16), (538, 21, 28), (40, 1, 90), (64, 5, 64)])
+def test_width_one_result_follows_the_tap_tables(H, W, oh):
+    """ATen's CPU antialias kernel mis-evaluates the height pass of a one-pixel-wide image (see
+    oracle/processors.py::_aa); the oracle's `_aa` must give what the explicit tables give, with a
+    gradient that is the transposed tables applied to the upstream gradient."""
+    from oracle.processors import _aa
+    rng = np.random.default_rng(3)
+    img = rng.random((3, H, W), dtype=np.float32)
+    x = torch.from_numpy(img).requires_grad_(True)
+    out = _aa(x, oh, 1)
+    assert tuple(out.shape) == (3, oh, 1)
+    th, tw = R.aa_bilinear_taps(H, oh), R.aa_bilinear_taps(W, 1)
+    assert np.abs(out.detach().numpy() - R.resize_separable(img, th, tw)).max() <= 1e-6
+    up = rng.random((3, oh, 1), dtype=np.float32)
+    out.backward(torch.from_numpy(up))
+    Mh, Mw = R.taps_to_matrix(th, H).astype(np.float64), R.taps_to_matrix(tw, W).astype(np.float64)
+    want = np.einsum("yh,cyx,xw->chw", Mh, up.astype(np.float64), Mw)
+    assert np.abs(x.grad.numpy() - want).max() <= 1e-6
