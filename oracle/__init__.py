@@ -15,5 +15,7 @@ Pinning status (see DESIGN.md "Oracle"):
     transformers `image_processing_pil_mllama` helpers, arithmetic by F.interpolate/F.pad.
   * GaussianBlur / RandomResizedCrop: torchvision is absent -> restated from the
     published algorithm, "torchvision-unverified" (parity unpinned for these two ops).
+  * In-kernel noise: `philox.py` restates Philox4x32-10 and the device's counter addressing,
+    pinned by the Random123 known-answer vectors (tests/test_oracle_philox.py).
   * The reference has no tests or golden vectors of its own.
 """

@@ -162,6 +162,29 @@ def test_chain_noise_stream_matches_oracle(dev, mode):
         clean_eng.backward_update([g])
 
 
+def test_random_trajectories(dev):
+    """Seeded subset of tools/fuzz_pgd.py: random image sizes, processors (single and weighted
+    cross-model sets), batches, blur, crop windows, masks, accumulation, optimiser, scheduler and
+    chain, 3-5 steps each, under the trajectory parity bar.  A case may be classified
+    "ill-conditioned" (fuzz_pgd.run_case: the gradient agrees to 1e-7 but one pixel's |g| is of the
+    order of adam_eps, or one pixel's uint8 truncation flips); none may fail."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_pgd
+    rng = np.random.default_rng(77)
+    me = sys.modules[__name__]
+    failed, soft = [], 0
+    for k in range(40):
+        verdict, desc, worst = fuzz_pgd.run_case(me, dev, rng, 31000 + k)
+        if verdict == "ill-conditioned":
+            soft += 1
+        elif verdict != "ok":
+            failed.append((desc, verdict))
+    assert not failed, failed
+    assert soft <= 4, soft
+
+
 def test_llava_downsample_blur_crop_mask_accum(dev):
 
     Plan = _plans()

@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Randomised differential test of whole PGD trajectories: PixelPGD (HIP, through the C ABI) against
+oracle/pgd.py on identical inputs (development tool; a seeded subset runs as
+tests/test_gpu_pgd.py::test_random_trajectories).
+
+    python tools/fuzz_pgd.py [--cases 100] [--seed 0] [--budget-s 240]
+
+Draws the image size, one processor or a weighted cross-model set, prompt batches, blur, random-resized
+crop windows, localized masks, gradient accumulation, optimiser, scheduler and the kernel chain, runs 3-5
+steps on both sides with the same noise / blur sigma / crop windows, and applies the parity bar of the
+trajectory tests (p, grad, sigma, statistics within 1e-4 relative).
+"""
+import argparse
+import os
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import pixel_ops as P  # noqa: E402
+from oracle.processors import LlavaOracle, MllamaOracle, Phi3Oracle, Qwen2VLOracle  # noqa: E402
+
+
+def one_processor(rng, H, W, allow_phi3=True):
+    from adversarialvlm_amd.plan import Plan
+    kind = rng.choice(["llava", "llava-ident", "mllama", "qwen"] + (["phi3"] if allow_phi3 else []))
+    if kind == "llava":
+        ch, cw = int(rng.choice([16, 33, 48, 64])), int(rng.choice([16, 33, 48, 64]))
+        return kind, LlavaOracle(ch, cw), Plan.llava(H, W, ch, cw)
+    if kind == "llava-ident":
+        return kind, LlavaOracle(H, W), Plan.llava(H, W, H, W)
+    if kind == "mllama":
+        tile, mt = int(rng.choice([16, 28, 32, 64])), int(rng.integers(1, 5))
+        return kind, MllamaOracle(tile=tile, max_tiles=mt), Plan.mllama(H, W, tile=tile, max_tiles=mt)
+    if kind == "qwen":
+        lo = int(rng.choice([4, 16])) * 28 * 28
+        hi = lo * int(rng.choice([1, 4, 16]))
+        return kind, Qwen2VLOracle(min_pixels=lo, max_pixels=hi), Plan.qwen2vl(H, W, min_pixels=lo, max_pixels=hi)
+    nc = int(rng.choice([1, 4, 6]))
+    return kind, Phi3Oracle(num_crops=nc), Plan.phi3(H, W, num_crops=nc)
+
+
+def draw_case(rng):
+    H, W = int(rng.integers(12, 140)), int(rng.integers(12, 140))
+    if rng.random() < 0.2:
+        H = W = int(rng.choice([32, 64, 112]))               # sizes the pair / one-launch chains accept
+    cross = rng.random() < 0.25
+    n_models = int(rng.integers(2, 4)) if cross else 1
+    procs = [one_processor(rng, H, W, allow_phi3=(k == 0)) for k in range(n_models)]
+    steps = int(rng.integers(3, 6))
+    kw = dict(optimizer=str(rng.choice(["adamw", "adamw", "sign"])), lr=float(rng.choice([1e-2, 3e-3, 1e-3])),
+              gamma=float(rng.choice([1.0, 0.5, 0.9])), step_size=int(rng.integers(1, 4)))
+    desc = dict(H=H, W=W, models=[p[0] for p in procs], steps=steps, **kw)
+    if cross:
+        kw["weights"] = [float(w) for w in rng.uniform(0.2, 2.0, size=n_models)]
+        kw["cross"] = True
+    blur = None if rng.random() < 0.55 else int(rng.choice([3, 5, 9, 15]))
+    if blur is not None:
+        sig = [float(s) for s in rng.uniform(0.1, 2.0, size=steps)]
+        kw["blur_kernel"] = blur
+        kw["blur_sigma_fn"] = lambda t, sig=sig: sig[t]
+        desc["blur"] = (blur, [round(s, 3) for s in sig])
+    if rng.random() < 0.3:
+        crops = []
+        for _ in range(steps):
+            h, w = int(rng.integers(max(4, H // 3), H + 1)), int(rng.integers(max(4, W // 3), W + 1))
+            crops.append((int(rng.integers(0, H - h + 1)), int(rng.integers(0, W - w + 1)), h, w))
+        kw["crop_fn"] = lambda t, crops=crops: crops[t]
+        kw["fused"] = False                                   # cropping engines are built for the generic chain
+        desc["crops"] = crops
+    mask = None
+    if rng.random() < 0.35:
+        kind = str(rng.choice(["corner", "bottom_lines"]))
+        size = int(rng.integers(2, min(H, W)))
+        mask = P.create_mask(kind, size, (3, H, W))
+        desc["mask"] = (kind, size)
+    if not cross and rng.random() < 0.25:
+        kw["accum"] = int(rng.integers(2, 4))
+        desc["accum"] = kw["accum"]
+    if rng.random() < 0.15:
+        kw["fused"] = False
+    desc["fused"] = kw.get("fused", True)
+    batches = [int(rng.integers(1, 7)) for _ in range(n_models)]
+    desc["batches"] = batches
+    return desc, procs, batches, steps, mask, kw
+
+
+def run_case(T, dev, rng, seed):
+    """-> (verdict, desc, worst): verdict is "ok", "ill-conditioned" or a failure text.
+
+    "ill-conditioned": everything that is a smooth function of the inputs agrees (pixel_values, the
+    gradient, its norm, the image-fit loss: 1e-7 level) and only quantities behind a discontinuity
+    moved past the bar - AdamW's g/(|g|+1e-8) at pixels whose gradient is of the order of adam_eps
+    (edge taps of a crop window, masked-out borders), where a 1e-7 relative difference of g changes
+    the step by a fraction of lr, or the uint8 truncation of the quantiser flipping for one pixel."""
+    desc, procs, batches, steps, mask, kw = draw_case(rng)
+    x0 = torch.rand(3, desc["H"], desc["W"], generator=torch.Generator().manual_seed(seed)) * 1.1 - 0.05
+    try:
+        worst = T._trajectory(dev, x0, [p[1] for p in procs], [p[2] for p in procs], batches, steps, mask=mask, **kw)
+        return "ok", desc, worst
+    except AssertionError as e:
+        arg = e.args[0] if e.args else None
+        if isinstance(arg, tuple) and len(arg) == 3 and isinstance(arg[2], dict):
+            worst = arg[2]
+            smooth = all(worst.get(k, 0.0) < 2e-6 for k in ("grad", "grad_norm", "imgfit")) and worst.get("pixel_values", 0.0) < 1e-5
+            rest = all(v < 5e-3 for v in worst.values())
+            if smooth and rest:
+                return "ill-conditioned", desc, worst
+            return f"PARITY {arg[0]} {arg[1]:.3e} {worst}", desc, worst
+        return f"PARITY {str(e)[:300]}", desc, {}
+    except Exception as e:
+        return f"EXCEPTION {type(e).__name__}: {e}\n{traceback.format_exc(limit=3)}", desc, {}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--budget-s", type=float, default=240.0)
+    a = ap.parse_args()
+    import test_gpu_pgd as T
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(a.seed)
+    t0, bad, soft, done = time.time(), 0, 0, 0
+    for k in range(a.cases):
+        if time.time() - t0 > a.budget_s:
+            break
+        verdict, desc, worst = run_case(T, dev, rng, a.seed * 7919 + k)
+        done += 1
+        if verdict == "ill-conditioned":
+            soft += 1
+            print(f"ill-conditioned case {k}: {desc}: { {n: f'{v:.1e}' for n, v in worst.items() if v > 1e-5} }", flush=True)
+        elif verdict != "ok":
+            bad += 1
+            print(f"FAIL case {k}: {desc}: {verdict}", flush=True)
+        elif k % 10 == 0:
+            print(f"case {k}: {desc}: ok, worst {max(worst.values()):.2e} ({max(worst, key=worst.get)})", flush=True)
+    print(f"{done} cases, {bad} failures, {soft} ill-conditioned (see run_case), {time.time() - t0:.0f} s", flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
