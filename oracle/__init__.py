@@ -10,9 +10,12 @@ path; nothing under `adversarialvlm_amd/` may import it.  Only `tests/`,
 Pinning status (see DESIGN.md "Oracle"):
   * LLaVA / Qwen2-VL / Phi-3.5 processors: pinned by captures from the imported
     reference classes (tests/golden/*.npz, generator tests/golden/make_golden.py).
-  * Llama-3.2 (mllama) processor: reference module is not importable here; restated
-    from llama32processor.py:255-405, integer geometry pinned by the installed
-    transformers `image_processing_pil_mllama` helpers, arithmetic by F.interpolate/F.pad.
+  * Llama-3.2 (mllama) processor: pinned by captures from the imported reference class
+    (mllama_reference.npz; the three integer helpers it asks transformers for are served
+    from `image_processing_pil_mllama`, see make_golden.py); integer geometry additionally
+    pinned by those helpers.
+  * image_fit_loss / create_mask / get_loss: pinned by outputs of the reference's own
+    functions (trainer_helpers.npz, suffix_loss.npz).
   * GaussianBlur / RandomResizedCrop: torchvision is absent -> restated from the
     published algorithm, "torchvision-unverified" (parity unpinned for these two ops).
   * In-kernel noise: `philox.py` restates Philox4x32-10 and the device's counter addressing,

@@ -51,7 +51,14 @@ def draw_case(rng):
         H = W = int(rng.choice([32, 64, 112]))               # sizes the pair / one-launch chains accept
     cross = rng.random() < 0.25
     n_models = int(rng.integers(2, 4)) if cross else 1
-    procs = [one_processor(rng, H, W, allow_phi3=(k == 0)) for k in range(n_models)]
+    procs = []
+    while len(procs) < n_models:
+        try:
+            procs.append(one_processor(rng, H, W, allow_phi3=(len(procs) == 0)))
+        except Exception:
+            # a geometry the plan rejects (e.g. Qwen2-VL's smart_resize leaves no 2x2 patch block);
+            # fuzz_parity.py checks that the oracle rejects the same ones - draw another processor
+            continue
     steps = int(rng.integers(3, 6))
     kw = dict(optimizer=str(rng.choice(["adamw", "adamw", "sign"])), lr=float(rng.choice([1e-2, 3e-3, 1e-3])),
               gamma=float(rng.choice([1.0, 0.5, 0.9])), step_size=int(rng.integers(1, 4)))
@@ -85,19 +92,64 @@ def draw_case(rng):
     if rng.random() < 0.15:
         kw["fused"] = False
     desc["fused"] = kw.get("fused", True)
+    if (desc["fused"] and not cross and procs[0][0] == "llava-ident" and blur is None and "accum" not in kw
+            and procs[0][2].fused_supported()):
+        # the identity-resize LLaVA plan may take any of the fused chains
+        mode = str(rng.choice(["auto", "pair", "step", "step-noise-ahead", "prepared"]))
+        kw["fused_mode"] = mode.split("-")[0]
+        if mode == "step-noise-ahead":
+            kw["noise_ahead"] = True
+        desc["chain"] = mode
     batches = [int(rng.integers(1, 7)) for _ in range(n_models)]
     desc["batches"] = batches
     return desc, procs, batches, steps, mask, kw
+
+
+def oracle_sensitivity(x0, procs, batches, steps, mask, kw, perturb):
+    """How far the ORACLE's own trajectory moves when the upstream gradients it is fed change by
+    `perturb` (relative to their largest entry) - the inputs of `_trajectory` replayed on the CPU.
+    Returns the relative L2 distances {p, sigma, qerr_mean, x_std, s} between the two oracle runs."""
+    from conftest import rel_err
+    from oracle.pgd import PGDOracle
+    plans = [p[2] for p in procs]
+    shapes = [(B * pl.out_shape[0],) + pl.out_shape[1:] for pl, B in zip(plans, batches)]
+    out = {}
+    runs = []
+    for eps in (0.0, perturb):
+        ora = PGDOracle(x0, [p[1] for p in procs], lr=kw["lr"], mask=mask, grad_accum_steps=kw.get("accum", 1),
+                        blur_kernel=kw.get("blur_kernel"), model_weights=kw.get("weights"), cross_mode=kw.get("cross", False),
+                        optimizer=kw["optimizer"], scheduler_gamma=kw["gamma"], scheduler_step_size=kw["step_size"])
+        gen = torch.Generator().manual_seed(11)                     # the input stream of _trajectory
+        pert = torch.Generator().manual_seed(12)
+        all_z = [[torch.randn(s, generator=gen) for s in shapes] for _ in range(steps + 1)]
+        trace = []
+        for t in range(steps):
+            gs = [torch.randn(s, generator=gen) * 0.01 for s in shapes]
+            if eps:
+                gs = [g + eps * float(g.abs().max()) * torch.randn(g.shape, generator=pert) for g in gs]
+            ora.forward(batches, all_z[t], blur_sigma=kw["blur_sigma_fn"](t) if "blur_sigma_fn" in kw else None,
+                        crop=kw["crop_fn"](t) if "crop_fn" in kw else None)
+            ref = ora.backward_update(gs)
+            trace.append(dict(p=ora.p.detach().clone(), s=ref["s"].clone(), sigma=ref["sigma_next"],
+                              qerr_mean=ref["qerr_mean"], x_std=ref["x_std"]))
+        runs.append(trace)
+    for a, b in zip(*runs):
+        for k in ("p", "s"):
+            out[k] = max(out.get(k, 0.0), rel_err(b[k], a[k]))
+        for k in ("sigma", "qerr_mean", "x_std"):
+            out[k] = max(out.get(k, 0.0), abs(b[k] - a[k]) / max(abs(a[k]), 1e-12))
+    return out
 
 
 def run_case(T, dev, rng, seed):
     """-> (verdict, desc, worst): verdict is "ok", "ill-conditioned" or a failure text.
 
     "ill-conditioned": everything that is a smooth function of the inputs agrees (pixel_values, the
-    gradient, its norm, the image-fit loss: 1e-7 level) and only quantities behind a discontinuity
-    moved past the bar - AdamW's g/(|g|+1e-8) at pixels whose gradient is of the order of adam_eps
-    (edge taps of a crop window, masked-out borders), where a 1e-7 relative difference of g changes
-    the step by a fraction of lr, or the uint8 truncation of the quantiser flipping for one pixel."""
+    gradient, its norm, the image-fit loss: 1e-7 level) and the quantities that moved past the bar
+    move just as far between two runs of the ORACLE whose upstream gradients differ by 3e-7 - the
+    size of the rounding differences between the two implementations (`oracle_sensitivity`).  Seen
+    for AdamW's g/(|g|+1e-8) at a pixel whose gradient is of the order of adam_eps (edge tap of a
+    crop window, border of a mask), and for one pixel's uint8 truncation flipping in the quantiser."""
     desc, procs, batches, steps, mask, kw = draw_case(rng)
     x0 = torch.rand(3, desc["H"], desc["W"], generator=torch.Generator().manual_seed(seed)) * 1.1 - 0.05
     try:
@@ -107,10 +159,13 @@ def run_case(T, dev, rng, seed):
         arg = e.args[0] if e.args else None
         if isinstance(arg, tuple) and len(arg) == 3 and isinstance(arg[2], dict):
             worst = arg[2]
-            smooth = all(worst.get(k, 0.0) < 2e-6 for k in ("grad", "grad_norm", "imgfit")) and worst.get("pixel_values", 0.0) < 1e-5
-            rest = all(v < 5e-3 for v in worst.values())
-            if smooth and rest:
-                return "ill-conditioned", desc, worst
+            # pixel_values of step t+1 carry the difference of p_t on, so they only have to stay under the bar
+            smooth = all(worst.get(k, 0.0) < 2e-6 for k in ("grad", "grad_norm", "imgfit"))
+            if smooth:
+                sens = oracle_sensitivity(x0, procs, batches, steps, mask, kw, perturb=3e-7)
+                over = {k: v for k, v in worst.items() if v >= T.TOL}
+                if all(sens.get(k, 0.0) >= 0.2 * v for k, v in over.items()):
+                    return "ill-conditioned", desc, dict(worst, **{f"oracle_sensitivity_{k}": sens.get(k, 0.0) for k in over})
             return f"PARITY {arg[0]} {arg[1]:.3e} {worst}", desc, worst
         return f"PARITY {str(e)[:300]}", desc, {}
     except Exception as e:
