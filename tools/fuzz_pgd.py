@@ -181,12 +181,14 @@ def main():
     import test_gpu_pgd as T
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(a.seed)
-    t0, bad, soft, done = time.time(), 0, 0, 0
+    t0, bad, soft, done, seen = time.time(), 0, 0, 0, {}
     for k in range(a.cases):
         if time.time() - t0 > a.budget_s:
             break
         verdict, desc, worst = run_case(T, dev, rng, a.seed * 7919 + k)
         done += 1
+        tag = desc.get("chain", "cross" if len(desc["models"]) > 1 else ("fused-auto" if desc["fused"] else "generic"))
+        seen[tag] = seen.get(tag, 0) + 1
         if verdict == "ill-conditioned":
             soft += 1
             print(f"ill-conditioned case {k}: {desc}: { {n: f'{v:.1e}' for n, v in worst.items() if v > 1e-5} }", flush=True)
@@ -195,7 +197,7 @@ def main():
             print(f"FAIL case {k}: {desc}: {verdict}", flush=True)
         elif k % 10 == 0:
             print(f"case {k}: {desc}: ok, worst {max(worst.values()):.2e} ({max(worst, key=worst.get)})", flush=True)
-    print(f"{done} cases, {bad} failures, {soft} ill-conditioned (see run_case), {time.time() - t0:.0f} s", flush=True)
+    print(f"{done} cases, {bad} failures, {soft} ill-conditioned (see run_case), {time.time() - t0:.0f} s; chains {seen}", flush=True)
     return 1 if bad else 0
 
 
