@@ -701,6 +701,141 @@ extern "C" int32_t advx_collect(advx_plan* p, const float* grad_out, int32_t bat
   return ADVX_OK;
 }
 
+// Several plans over one image: what n advx_emit_ex / advx_collect calls do, bit for bit, with the
+// stage-0 kernels of all plans in ONE launch each way (k_stage0_fwd_multi / k_stage0_bwd_multi).
+static int32_t check_multi(int32_t n, advx_plan* const* plans, const int32_t* batches, float* const* wss, const int64_t* ws_floats,
+                           const char* who) {
+  const std::string w = std::string(who) + ": ";
+  REQUIRE(n >= 1 && n <= kMaxMulti, ADVX_E_BADARG, w + "between 1 and 4 plans");
+  REQUIRE(plans && batches && wss && ws_floats, ADVX_E_BADARG, w + "null argument");
+  for (int i = 0; i < n; ++i) {
+    REQUIRE(plans[i] && wss[i], ADVX_E_BADARG, w + "null plan or workspace");
+    REQUIRE(batches[i] >= 1 && batches[i] <= 65535, ADVX_E_BADARG, w + "batch out of range");
+    REQUIRE(ws_floats[i] >= plans[i]->info.workspace_floats, ADVX_E_SHAPE, w + "workspace too small");
+    REQUIRE(plans[i]->info.in_h == plans[0]->info.in_h && plans[i]->info.in_w == plans[0]->info.in_w, ADVX_E_SHAPE,
+            w + "all plans must take the same image");
+    REQUIRE(plans[i]->st[0].info.src == 0, ADVX_E_UNSUPPORTED, w + "stage 0 of every plan must read the image");
+    for (int j = 0; j < i; ++j) REQUIRE(wss[i] != wss[j], ADVX_E_BADARG, w + "every plan needs its own workspace");
+  }
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_emit_multi(int32_t n, advx_plan* const* plans, const float* argument, const int32_t* batches,
+                                   const float* sigma_dev, const float* const* unit_noises, int32_t use_philox, uint64_t seed,
+                                   const uint64_t* offsets, void* const* outs, float* const* wss, const int64_t* ws_floats,
+                                   int32_t pad_mode, void* stream) {
+  int32_t rc = check_multi(n, plans, batches, wss, ws_floats, "advx_emit_multi");
+  if (rc) return rc;
+  REQUIRE(argument && outs && offsets, ADVX_E_BADARG, "advx_emit_multi: null argument");
+  REQUIRE(pad_mode == ADVX_PAD_NOISE || pad_mode == ADVX_PAD_KEEP, ADVX_E_BADARG, "advx_emit_multi: unknown pad_mode");
+  hipStream_t st = (hipStream_t)stream;
+  MultiFwd mf;
+  std::memset(&mf, 0, sizeof(mf));
+  mf.n = n;
+  long long biggest = 0;
+  for (int i = 0; i < n; ++i) {
+    advx_plan* p = plans[i];
+    const float* z = unit_noises ? unit_noises[i] : nullptr;
+    REQUIRE(outs[i], ADVX_E_BADARG, "advx_emit_multi: null output");
+    REQUIRE(aligned16(outs[i]) && aligned16(wss[i]) && (!z || aligned16(z)), ADVX_E_BADARG,
+            "advx_emit_multi: pointers must be 16-byte aligned");
+    REQUIRE((!z && !use_philox) || sigma_dev, ADVX_E_BADARG, "advx_emit_multi: noise requested without sigma_dev");
+    rc = advx_plan_upload(p, stream);
+    if (rc) return rc;
+    mf.st[i] = p->dstage[0];
+    mf.canvas[i] = wss[i] + p->dplan.canvas_off[0];
+    biggest = std::max(biggest, 3LL * p->dstage[0].can_h * p->dstage[0].can_w);
+  }
+  const DStage& D0 = plans[0]->dstage[0];
+  hipLaunchKernelGGL(k_stage0_fwd_multi, dim3(grid_for(biggest), n), dim3(kBlock), 0, st, mf, argument,
+                     (long long)D0.src_h * D0.src_w, D0.src_w);
+  LAUNCH_CHECK();
+  for (int i = 0; i < n; ++i) {
+    advx_plan* p = plans[i];
+    float* ws = wss[i];
+    for (int k = 1; k < p->info.n_stage; ++k) {
+      const DStage& D = p->dstage[k];
+      const advx_stage_info& s = p->st[k].info;
+      const float* src = (s.src == 0) ? argument : ws + p->dplan.canvas_off[s.src - 1];
+      hipLaunchKernelGGL(k_stage_fwd, dim3(grid_for(3LL * D.can_h * D.can_w)), dim3(kBlock), 0, st, D, src,
+                         (long long)D.src_h * D.src_w, D.src_w, ws + p->dplan.canvas_off[k]);
+      LAUNCH_CHECK();
+    }
+    const float* z = unit_noises ? unit_noises[i] : nullptr;
+    const int noise = z ? 1 : (use_philox ? 2 : 0);
+    const long long n4 = (p->info.out_numel + 3) >> 2;
+    long long q_lo = 0, q_hi = n4, live_lo = 0, live_hi = n4 << 2;
+    if (pad_mode == ADVX_PAD_KEEP) {
+      plan_live_range(p, &live_lo, &live_hi);
+      q_lo = live_lo >> 2;
+      q_hi = (live_hi + 3) >> 2;
+    }
+    int gx, slices, bps;
+    emit_slices(q_hi - q_lo, batches[i], &gx, &slices, &bps);
+    dim3 grid(gx, slices);
+#define ADVX_EMIT_T(N, T)                                                                                             \
+  hipLaunchKernelGGL((k_emit<N, T>), grid, dim3(kBlock), 0, st, p->dplan, ws, batches[i], bps, sigma_dev, z, seed, \
+                     offsets[i], outs[i], q_lo, q_hi, live_lo, live_hi)
+#define ADVX_EMIT(N) \
+  do { if (p->io == 0) ADVX_EMIT_T(N, 0); else if (p->io == 1) ADVX_EMIT_T(N, 1); else ADVX_EMIT_T(N, 2); } while (0)
+    if (noise == 0) ADVX_EMIT(0); else if (noise == 1) ADVX_EMIT(1); else ADVX_EMIT(2);
+#undef ADVX_EMIT
+#undef ADVX_EMIT_T
+    LAUNCH_CHECK();
+  }
+  return ADVX_OK;
+}
+
+extern "C" int32_t advx_collect_multi(int32_t n, advx_plan* const* plans, const void* const* grad_outs, const int32_t* batches,
+                                      float* grad_argument, int32_t accumulate, float* const* wss, const int64_t* ws_floats,
+                                      void* stream) {
+  int32_t rc = check_multi(n, plans, batches, wss, ws_floats, "advx_collect_multi");
+  if (rc) return rc;
+  REQUIRE(grad_outs && grad_argument, ADVX_E_BADARG, "advx_collect_multi: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  MultiBwd mb;
+  std::memset(&mb, 0, sizeof(mb));
+  mb.n = n;
+  // all batch reductions first, then the upper stages (Phi-3.5's global view), then stage 0 of every plan
+  for (int i = 0; i < n; ++i) {
+    advx_plan* p = plans[i];
+    REQUIRE(grad_outs[i], ADVX_E_BADARG, "advx_collect_multi: null gradient");
+    rc = advx_plan_upload(p, stream);
+    if (rc) return rc;
+    const float* gsum = reinterpret_cast<const float*>(grad_outs[i]);
+    if (batches[i] > 1 || p->io != 0) {
+      long long lo, hi;
+      plan_live_range(p, &lo, &hi);
+      rc = launch_batch_reduce(gsum, batches[i], p->info.out_numel, wss[i] + p->dplan.gsum_off, st, lo, hi, p->io);
+      if (rc) return rc;
+      gsum = wss[i] + p->dplan.gsum_off;
+    }
+    mb.st[i] = p->dstage[0];
+    mb.pl[i] = p->dplan;
+    mb.gsum[i] = gsum;
+    mb.dgrad[i] = (p->dplan.dgrad_off[0] >= 0) ? wss[i] + p->dplan.dgrad_off[0] : nullptr;
+  }
+  const int rowblk = 128;
+  for (int i = 0; i < n; ++i) {
+    advx_plan* p = plans[i];
+    for (int k = p->info.n_stage - 1; k >= 1; --k) {
+      const DStage& D = p->dstage[k];
+      const advx_stage_info& s = p->st[k].info;
+      REQUIRE(s.src >= 1, ADVX_E_UNSUPPORTED, "advx_collect_multi: only stage 0 may read the image");
+      const float* dgrad = (p->dplan.dgrad_off[k] >= 0) ? wss[i] + p->dplan.dgrad_off[k] : nullptr;
+      float* gsrc = wss[i] + p->dplan.dgrad_off[s.src - 1];
+      hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D, p->dplan, k,
+                         mb.gsum[i], dgrad, gsrc, (long long)D.src_h * D.src_w, D.src_w, 0);
+      LAUNCH_CHECK();
+    }
+  }
+  const DStage& D0 = plans[0]->dstage[0];
+  hipLaunchKernelGGL(k_stage0_bwd_multi, dim3((D0.src_w + rowblk - 1) / rowblk, D0.src_h, 3), dim3(rowblk), 0, st, mb,
+                     grad_argument, (long long)D0.src_h * D0.src_w, D0.src_w, accumulate);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
 // ------------------------------------------------------------------------- image level
 namespace {
 struct Bump {

@@ -470,6 +470,59 @@ __global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, DPlan pl, int s
   }
 }
 
+// Several plans over ONE image (cross-model runs, crossattack_models.py:352-391).  Their
+// stage-0 kernels are each too small to fill the device and a dependent launch costs ~5 us, so
+// the stage-0 work of all plans goes into one launch:
+//   forward : blockIdx.y = plan; canvas_k = resize_k(image), pad, normalise
+//   backward: one thread per image element sums the plans' transposed resizes left to right -
+//             the value n accumulating launches of k_stage_bwd leave, without their n-1
+//             read-modify-write passes over the image gradient.
+constexpr int kMaxMulti = 4;
+struct MultiFwd {
+  int n;
+  DStage st[kMaxMulti];
+  float* canvas[kMaxMulti];
+};
+struct MultiBwd {
+  int n;
+  DStage st[kMaxMulti];
+  DPlan pl[kMaxMulti];
+  const float* gsum[kMaxMulti];
+  const float* dgrad[kMaxMulti];
+};
+
+__global__ void __launch_bounds__(kBlock) k_stage0_fwd_multi(MultiFwd mf, const float* __restrict__ src, long long src_cstride,
+                                                             int src_rstride) {
+  const int k = blockIdx.y;
+  const DStage& st = mf.st[k];
+  const long long n = 3LL * st.can_h * st.can_w;
+  float* __restrict__ canvas = mf.canvas[k];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)((unsigned)i / ((unsigned)st.can_h * (unsigned)st.can_w));
+    int rem = (int)((unsigned)i - (unsigned)c * (unsigned)st.can_h * (unsigned)st.can_w);
+    int y = rem / st.can_w, x = rem - y * st.can_w;
+    canvas[i] = stage_fwd_value(st, src, src_cstride, src_rstride, c, y, x);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_stage0_bwd_multi(MultiBwd mb, float* __restrict__ gsrc, long long gsrc_cstride,
+                                                             int gsrc_rstride, int accumulate) {
+  const int c = blockIdx.z, ys = blockIdx.y;
+  const int xs = blockIdx.x * blockDim.x + threadIdx.x;
+  if (xs < mb.st[0].src_w) {
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kMaxMulti; ++k) {
+      if (k < mb.n) {
+        const float t = stage_bwd_value(mb.st[k], mb.pl[k], 0, mb.gsum[k], mb.dgrad[k], c, ys, xs);
+        v = (k == 0) ? t : v + t;
+      }
+    }
+    size_t o = (size_t)c * gsrc_cstride + (size_t)ys * gsrc_rstride + xs;
+    gsrc[o] = accumulate ? (gsrc[o] + v) : v;
+  }
+}
+
 // adjoint of the random-resized crop (attack_model.py:307-310): the gradient arrives in the
 // canvas order of the resized window (H x W); one thread per pixel of the WHOLE image writes the
 // transposed resize inside the window (ci, cj, src_h, src_w) and exact zeros outside it

@@ -91,6 +91,63 @@ def collect(plan, grad_out, batch, grad_argument=None, accumulate=False, workspa
     return grad_argument
 
 
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def emit_multi(plans, argument, batches, sigma_dev=None, unit_noises=None, philox=None, workspaces=None, outs=None,
+               keep_padding=False):
+    """`emit` for several plans over one image (cross-model runs): same tensors, bit for bit, with the
+    plans' image resizes in one launch.  philox = (seed, [offset per plan])."""
+    _require_cuda(argument)
+    argument = _f32c(argument)
+    dev = argument.device
+    n = len(plans)
+    if workspaces is None:
+        workspaces = [torch.empty(pl.workspace_floats, dtype=torch.float32, device=dev) for pl in plans]
+    if outs is None:
+        outs = [None] * n
+    outs = list(outs)
+    for i, (pl, B) in enumerate(zip(plans, batches)):
+        if keep_padding and (outs[i] is None or outs[i].numel() != B * pl.out_numel):
+            raise L.AdvxError("keep_padding needs the caller's persistent [batch, out_numel] buffers")
+        outs[i] = (torch.empty((B, pl.out_numel), dtype=_plan_dtype(pl), device=dev) if outs[i] is None
+                   else _boundary(pl, outs[i], "out"))
+    zs = [None] * n if unit_noises is None else [None if z is None else _f32c(z) for z in unit_noises]
+    for z, pl, B in zip(zs, plans, batches):
+        if z is not None and z.numel() != B * pl.out_numel:
+            raise L.AdvxError("unit_noise has the wrong number of elements")
+    seed, offsets = (philox if philox is not None else (0, [0] * n))
+    L.check(L.load().advx_emit_multi(n, (C.c_void_p * n)(*[pl.handle.value for pl in plans]), L.ptr(argument),
+                                     (C.c_int32 * n)(*[int(b) for b in batches]), L.ptr(sigma_dev), _ptr_array(zs),
+                                     int(philox is not None), int(seed), (C.c_uint64 * n)(*[int(o) for o in offsets]),
+                                     _ptr_array(outs), _ptr_array(workspaces),
+                                     (C.c_int64 * n)(*[int(w.numel()) for w in workspaces]), 1 if keep_padding else 0,
+                                     _stream(argument)), "advx_emit_multi")
+    return outs
+
+
+def collect_multi(plans, grad_outs, batches, grad_argument=None, accumulate=False, workspaces=None):
+    """Backward of `emit_multi`: the sum over plans of each plan's image gradient, in plan order."""
+    n = len(plans)
+    _require_cuda(*grad_outs)
+    grad_outs = [_boundary(pl, g, "grad_out") for pl, g in zip(plans, grad_outs)]
+    dev = grad_outs[0].device
+    for pl, g, B in zip(plans, grad_outs, batches):
+        if g.numel() != B * pl.out_numel:
+            raise L.AdvxError("grad_out has the wrong number of elements")
+    if workspaces is None:
+        workspaces = [torch.empty(pl.workspace_floats, dtype=torch.float32, device=dev) for pl in plans]
+    if grad_argument is None:
+        grad_argument = torch.empty((3, plans[0].in_h, plans[0].in_w), dtype=torch.float32, device=dev)
+        accumulate = False
+    L.check(L.load().advx_collect_multi(n, (C.c_void_p * n)(*[pl.handle.value for pl in plans]), _ptr_array(grad_outs),
+                                        (C.c_int32 * n)(*[int(b) for b in batches]), L.ptr(grad_argument), int(accumulate),
+                                        _ptr_array(workspaces), (C.c_int64 * n)(*[int(w.numel()) for w in workspaces]),
+                                        _stream(grad_outs[0])), "advx_collect_multi")
+    return grad_argument
+
+
 class ProcessFunction(torch.autograd.Function):
     """Differentiable `process(image)` of the plugin API: forward = advx_emit (batch 1, no
     noise), backward = advx_collect.  Keeps autograd users of the reference API working."""

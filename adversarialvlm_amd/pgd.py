@@ -275,6 +275,25 @@ class PixelPGD:
         _, arg = ops.image_fwd(self.p, self.x0, self.eps, self.stats, self.img_scratch, blur=blur, crop=crop,
                                s=self.s, argument=self.argument if crop is not None else None)
         sigma = self.stats[L.STAT_SIGMA:L.STAT_SIGMA + 1]
+        if len(self.plans) > 1:
+            # cross-model: the plans' image resizes in one launch (advx_emit_multi), then one emit each
+            n = len(self.plans)
+            given = any(z is not None for z in unit_noises)
+            if given and not all(z is not None for z in unit_noises):
+                raise L.AdvxError("unit_noises: give the noise of every plan or of none")
+            keep = (not self.noise_on_padding) and not given
+            bufs = None
+            if keep:
+                for i, (pl, B) in enumerate(zip(self.plans, batches)):
+                    if self._outs[i] is None or self._outs[i].shape[0] != B:
+                        self._outs[i] = torch.zeros((B, pl.out_numel), dtype=ops._plan_dtype(pl), device=self.p.device)
+                bufs = self._outs
+            ph = None if (given or not use_philox) else (self.seed, [self.iteration * n + i for i in range(n)])
+            res = ops.emit_multi(self.plans, arg, batches, sigma_dev=sigma, unit_noises=unit_noises if given else None,
+                                 philox=ph, workspaces=self.workspaces, outs=bufs, keep_padding=keep)
+            outs = [o.view((B * pl.out_shape[0],) + pl.out_shape[1:]) for o, pl, B in zip(res, self.plans, batches)]
+            self._last = dict(batches=list(batches), blur=blur, crop=crop)
+            return outs
         for i, (pl, B, z) in enumerate(zip(self.plans, batches, unit_noises)):
             ph = None if (z is not None or not use_philox) else (self.seed, self.iteration * len(self.plans) + i)
             keep = (not self.noise_on_padding) and z is None
@@ -361,9 +380,13 @@ class PixelPGD:
             self.rows_in = self.rows_bwd
             self.s_cur = nxt
         else:
-            for i, (pl, g, B) in enumerate(zip(self.plans, grads, st["batches"])):
-                ops.collect(pl, g.reshape(B, pl.out_numel), B, grad_argument=self.garg, accumulate=(i > 0),
-                            workspace=self.workspaces[i])
+            if len(self.plans) > 1:
+                # batch reductions, then every plan's transposed resize summed in one launch
+                ops.collect_multi(self.plans, [g.reshape(B, pl.out_numel) for pl, g, B in zip(self.plans, grads, st["batches"])],
+                                  st["batches"], grad_argument=self.garg, workspaces=self.workspaces)
+            else:
+                pl, g, B = self.plans[0], grads[0], st["batches"][0]
+                ops.collect(pl, g.reshape(B, pl.out_numel), B, grad_argument=self.garg, workspace=self.workspaces[0])
             ops.image_bwd(self.p, self.s, self.garg, self.eps, self.imgfit_scale(), self.grad, self.img_scratch,
                           blur=st["blur"], crop=st["crop"], accumulate=accumulate)
             if self.exchange and take_step:

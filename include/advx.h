@@ -179,6 +179,22 @@ int32_t advx_emit_ex(advx_plan* plan, const float* argument, int32_t batch, cons
 int32_t advx_collect(advx_plan* plan, const float* grad_out, int32_t batch, float* grad_argument,
                      int32_t accumulate, float* workspace, int64_t workspace_floats, void* stream);
 
+/* Cross-model runs (crossattack_models.py:352-391): n <= 4 processors over ONE image.  The result
+ * is, bit for bit, what n calls of advx_emit_ex / advx_collect (the first with `accumulate`, the
+ * others adding) give; the resize kernels of all plans that read the image run in one launch each
+ * way and the plans' image gradients are summed left to right inside it, without read-modify-write
+ * passes.  Arrays have n entries, host memory; every plan needs its own workspace; plan i's noise
+ * stream is (seed, offsets[i]); unit_noises may be NULL or hold NULL entries; `outs` / `grad_outs`
+ * carry each plan's boundary dtype (advx_plan_set_io). */
+int32_t advx_emit_multi(int32_t n, advx_plan* const* plans, const float* argument, const int32_t* batches,
+                        const float* sigma_dev, const float* const* unit_noises, int32_t use_philox,
+                        uint64_t seed, const uint64_t* offsets, void* const* outs,
+                        float* const* workspaces, const int64_t* workspace_floats, int32_t pad_mode,
+                        void* stream);
+int32_t advx_collect_multi(int32_t n, advx_plan* const* plans, const void* const* grad_outs,
+                           const int32_t* batches, float* grad_argument, int32_t accumulate,
+                           float* const* workspaces, const int64_t* workspace_floats, void* stream);
+
 /* ---------------------------------------------------- image level (trainer)
  * advx_image_fwd : attack_model.py:300-312,329,366-373,386-391
  *     x = eps*tanh(p) ; optional Gaussian blur (kernel k, sigma) ; s = x0 + x ;

@@ -3,7 +3,6 @@ Tolerance: fp32 within 1e-4 relative (north star); in practice ~1e-6."""
 import numpy as np
 import pytest
 import torch
-import torch.nn.functional as F
 
 from conftest import load_golden, rel_err
 from oracle import pixel_ops as P

@@ -245,6 +245,56 @@ def test_random_geometries(dev):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("H,W,half", [(60, 90, False), (112, 112, False), (45, 31, False), (112, 112, True)])
+def test_multi_plan_calls_equal_the_single_plan_calls(dev, H, W, half):
+    """advx_emit_multi / advx_collect_multi (cross-model runs: the plans' image resizes in one launch,
+    their image gradients summed in one kernel) against n advx_emit_ex / accumulating advx_collect
+    calls: identical bits, with noise, per-plan boundary dtypes and padding kept zero."""
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd._lib import AdvxError
+    from adversarialvlm_amd.plan import Plan
+    mk = lambda: [Plan.phi3(H, W), Plan.qwen2vl(H, W, min_pixels=28 * 28 * 4, max_pixels=28 * 28 * 64),
+                  Plan.mllama(H, W, tile=32), Plan.llava(H, W, 48, 48)]
+    single, multi = mk(), mk()
+    if half:
+        for group in (single, multi):
+            group[0].set_io(torch.float16)
+            group[1].set_io(torch.bfloat16)
+    gen = torch.Generator().manual_seed(12)
+    img = torch.rand(3, H, W, generator=gen).to(dev)
+    sig = torch.tensor([0.05], device=dev)
+    batches = [2, 3, 1, 4]
+    offs = [40, 41, 42, 43]
+    for keep in (False, True):
+        bufs_a = [torch.zeros(B, pl.out_numel, dtype=ops._plan_dtype(pl), device=dev) for pl, B in zip(single, batches)] if keep else [None] * 4
+        bufs_b = [b.clone() for b in bufs_a] if keep else None
+        ws_a = [torch.empty(pl.workspace_floats, device=dev) for pl in single]
+        ws_b = [torch.empty(pl.workspace_floats, device=dev) for pl in multi]
+        ref = [ops.emit(pl, img, B, sigma_dev=sig, philox=(5, o), workspace=w, out=b, keep_padding=keep)
+               for pl, B, o, w, b in zip(single, batches, offs, ws_a, bufs_a)]
+        got = ops.emit_multi(multi, img, batches, sigma_dev=sig, philox=(5, offs), workspaces=ws_b, outs=bufs_b, keep_padding=keep)
+        for a, b in zip(ref, got):
+            assert a.dtype == b.dtype and torch.equal(a, b)
+        ups = [(torch.randn(o.shape, generator=gen) * 0.1).to(dev).to(o.dtype) for o in ref]
+        g_ref = torch.empty(3, H, W, device=dev)
+        for i, (pl, u, B, w) in enumerate(zip(single, ups, batches, ws_a)):
+            ops.collect(pl, u, B, grad_argument=g_ref, accumulate=(i > 0), workspace=w)
+        g_got = ops.collect_multi(multi, ups, batches, workspaces=ws_b)
+        assert torch.equal(g_ref, g_got)
+        # accumulate: adds onto what is there
+        g2 = ops.collect_multi(multi, ups, batches, grad_argument=g_got.clone(), accumulate=True, workspaces=ws_b)
+        assert rel_err(g2.cpu(), 2 * g_ref.cpu()) < TIGHT
+    # one plan is the plain call; argument checks
+    one = ops.emit_multi(multi[:1], img, [2], workspaces=ws_b[:1])
+    assert torch.equal(one[0], ops.emit(single[0], img, 2, workspace=ws_a[0]))
+    with pytest.raises(AdvxError):
+        ops.emit_multi(multi[:2], img, [1, 1], workspaces=[ws_b[0], ws_b[0]])            # shared workspace
+    with pytest.raises(AdvxError):
+        ops.emit_multi(multi + multi[:1], img, batches + [1], workspaces=ws_b + ws_a[:1])   # more than four plans
+    with pytest.raises(AdvxError):
+        ops.emit_multi([multi[0], Plan.llava(H + 1, W, 48, 48)], img, [1, 1])              # different images
+
+
 def test_layout_index_map_matches_device(dev):
     """advx_plan_out_index (host) vs what the device wrote: integer layout bit-exact."""
     from adversarialvlm_amd import ops

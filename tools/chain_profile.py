@@ -18,17 +18,27 @@ def main():
     chain = sys.argv[2] if len(sys.argv) > 2 else "prepared"
     dev = torch.device("cuda:0")
     H = W = 336 if which == "mllama" else 512
-    plans = {"mllama": lambda: [Plan.mllama(H, W)], "phi3": lambda: [Plan.phi3(H, W)], "qwen2vl": lambda: [Plan.qwen2vl(H, W)],
-             "llava": lambda: [Plan.llava(H, W)]}[which]()
-    B = 64
+    if which == "cross":                       # BASELINE configs 4/5 in the shape tools/generic_bench.py times
+        H = W = 336
+        plans, B, kw = [Plan.phi3(H, W), Plan.qwen2vl(H, W), Plan.mllama(H, W)], 16, dict(blur_kernel=5, cross_mode=True)
+    else:
+        plans = {"mllama": lambda: [Plan.mllama(H, W)], "phi3": lambda: [Plan.phi3(H, W)], "qwen2vl": lambda: [Plan.qwen2vl(H, W)],
+                 "llava": lambda: [Plan.llava(H, W)]}[which]()
+        B, kw = 64, {}
     x0 = torch.rand(3, H, W, device=dev)
-    eng = PixelPGD(x0, plans, allow_fused=(chain == "prepared"))
+    eng = PixelPGD(x0, plans, allow_fused=(chain == "prepared"), **kw)
     assert eng.mode == chain, eng.mode
     gs = [torch.randn(B, pl.out_numel, device=dev) for pl in plans]
-    for _ in range(60):
-        eng.forward(B)
+    sig = 7.0 if "blur_kernel" in kw else None
+    import time
+    for it in range(60):
+        if it == 10:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        eng.forward(B, blur_sigma=sig)
         eng.backward_update(gs)
     torch.cuda.synchronize()
+    print(f"{which} {chain}: {(time.perf_counter() - t0) / 50 * 1e6:.1f} us/step (wall, 50 steps)")
 
 
 if __name__ == "__main__":
