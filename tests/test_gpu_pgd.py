@@ -185,6 +185,25 @@ def test_random_trajectories(dev):
     assert soft <= 4, soft
 
 
+def test_random_relations(dev):
+    """Seeded subset of `tools/fuzz_pgd.py --relations`: on random cases the half boundary, the
+    kept-zero padding and the prepared chain must reproduce the plain fp32 / generic run (bit for bit,
+    resp. to 1e-5)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_pgd
+    rng = np.random.default_rng(78)
+    failed, ran = [], 0
+    for k in range(50):
+        verdict, desc = fuzz_pgd.run_relations(dev, rng, 32000 + k)
+        ran += verdict != "skipped"
+        if verdict not in ("ok", "skipped"):
+            failed.append((desc, verdict))
+    assert not failed, failed
+    assert ran >= 25
+
+
 def test_llava_downsample_blur_crop_mask_accum(dev):
 
     Plan = _plans()

@@ -172,8 +172,84 @@ def run_case(T, dev, rng, seed):
         return f"EXCEPTION {type(e).__name__}: {e}\n{traceback.format_exc(limit=3)}", desc, {}
 
 
+def run_relations(dev, rng, seed):
+    """Engine-against-engine relations on a random case (no oracle involved):
+      * half boundary: pixel_values are the fp32 ones rounded once; a half gradient gives the update its
+        widened copy gives - bit for bit;
+      * padding tiles kept zero: same values on every element an image reaches, same p - bit for bit;
+      * with one plan and no blur / crop / accumulation: the prepared chain against the generic one
+        (same arithmetic, different summation order of the statistics) - p to 1e-6.
+    -> (verdict, desc)"""
+    from adversarialvlm_amd.pgd import PixelPGD
+    desc, procs, batches, steps, mask, kw = draw_case(rng)
+    if "crop_fn" in kw:
+        return "skipped", desc
+    H, W = desc["H"], desc["W"]
+    x0 = (torch.rand(3, H, W, generator=torch.Generator().manual_seed(seed)) * 1.1 - 0.05).to(dev)
+    plans_of = lambda: [type(p[2])(p[2].kind, H, W, [p[2].desc.a0, p[2].desc.a1, p[2].desc.a2, p[2].desc.a3, p[2].desc.a4])
+                        for p in procs]
+    half = [torch.float16 if rng.random() < 0.5 else torch.bfloat16 for _ in procs]
+    if any(pl.out_numel % 4 for pl in plans_of()):
+        half = None
+    common = dict(lr=kw["lr"], mask=None if mask is None else mask.to(dev), grad_accum_steps=kw.get("accum", 1),
+                  blur_kernel=kw.get("blur_kernel"), model_weights=kw.get("weights"), cross_mode=kw.get("cross", False),
+                  optimizer=kw["optimizer"], scheduler_gamma=kw["gamma"], scheduler_step_size=kw["step_size"], seed=5,
+                  allow_fused=kw.get("fused", True))
+    engines = {"f32": PixelPGD(x0, plans_of(), **common), "keep": PixelPGD(x0, plans_of(), noise_on_padding=False, **common)}
+    if engines["f32"].mode == "pair":
+        del engines["keep"]                       # the identity LLaVA plan has no padding
+    if half is not None and engines["f32"].mode != "step":
+        engines["half"] = PixelPGD(x0, plans_of(), io_dtype=half if len(half) > 1 else half[0], **common)
+    if engines["f32"].mode == "prepared":
+        engines["generic"] = PixelPGD(x0, plans_of(), **dict(common, allow_fused=False))
+    desc["relations"] = sorted(engines)
+    gen = torch.Generator().manual_seed(seed + 1)
+    try:
+        for t in range(steps):
+            bs = kw["blur_sigma_fn"](t) if "blur_sigma_fn" in kw else None
+            outs = {k: e.forward(batches, blur_sigma=bs) for k, e in engines.items()}
+            grads = [(torch.randn(o.shape, generator=gen) * 0.02).to(dev) for o in outs["f32"]]
+            ref = outs["f32"]
+            if "half" in outs:
+                for a, b, d in zip(ref, outs["half"], half):
+                    assert b.dtype == d and torch.equal(a.to(d), b), "half pixel_values are not the rounded fp32 ones"
+            if "keep" in outs:
+                for a, b, pl in zip(ref, outs["keep"], engines["keep"].plans):
+                    lo, hi = pl.live_range()
+                    fa, fb = a.reshape(a.shape[0] // pl.out_shape[0], -1), b.reshape(a.shape[0] // pl.out_shape[0], -1)
+                    assert torch.equal(fa[:, lo:hi], fb[:, lo:hi]), "kept-padding run differs where an image is"
+                    assert not fb[:, :lo].any() and not fb[:, hi:].any(), "padding is not zero"
+            if "generic" in outs:
+                for a, b in zip(ref, outs["generic"]):
+                    assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max())), "prepared vs generic pixel_values"
+            scale = [engines["f32"].loss_scale(i) for i in range(len(grads))]
+            if "half" in engines:
+                rounded = [(g * s).to(d) for g, s, d in zip(grads, scale, half)]
+                engines["half"].backward_update(rounded)
+                feed = [r.float() for r in rounded]
+            else:
+                feed = [g * s for g, s in zip(grads, scale)]
+            for k, e in engines.items():
+                if k != "half":
+                    e.backward_update(feed)
+            p = engines["f32"].p
+            if "half" in engines:
+                assert torch.equal(p, engines["half"].p), f"half boundary: p differs at step {t}"
+            if "keep" in engines:
+                assert torch.equal(p, engines["keep"].p), f"kept padding: p differs at step {t}"
+            if "generic" in engines:
+                d = float((p - engines["generic"].p).norm() / max(float(p.norm()), 1e-30))
+                assert d < 1e-5, f"prepared vs generic p: {d:.2e} at step {t}"
+    except AssertionError as e:
+        return f"RELATION {e}", desc
+    except Exception as e:
+        return f"EXCEPTION {type(e).__name__}: {e}\n{traceback.format_exc(limit=4)}", desc
+    return "ok", desc
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--relations", action="store_true", help="engine-against-engine relations instead of the oracle")
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--budget-s", type=float, default=240.0)
@@ -185,8 +261,14 @@ def main():
     for k in range(a.cases):
         if time.time() - t0 > a.budget_s:
             break
-        verdict, desc, worst = run_case(T, dev, rng, a.seed * 7919 + k)
+        if a.relations:
+            verdict, desc = run_relations(dev, rng, a.seed * 7919 + k)
+            worst = {"-": 0.0}
+        else:
+            verdict, desc, worst = run_case(T, dev, rng, a.seed * 7919 + k)
         done += 1
+        if verdict == "skipped":
+            continue
         tag = desc.get("chain", "cross" if len(desc["models"]) > 1 else ("fused-auto" if desc["fused"] else "generic"))
         seen[tag] = seen.get(tag, 0) + 1
         if verdict == "ill-conditioned":
