@@ -870,7 +870,10 @@ struct CropCache {
 thread_local CropCache g_crop_cache;
 
 // carve the crop's tap tables out of scratch and launch their device-side construction
-int32_t build_crop_stage(int H, int W, const int32_t* crop, Bump& b, hipStream_t stq, DStage* out, bool may_reuse = false) {
+// `deferred`: do not launch k_build_taps; hand the two descriptors to the caller, who builds the
+// tables inside its own first launch (k_prep_taps)
+int32_t build_crop_stage(int H, int W, const int32_t* crop, Bump& b, hipStream_t stq, DStage* out, bool may_reuse = false,
+                         TapBuild* deferred = nullptr) {
   int ci = crop[0], cj = crop[1], ch = crop[2], cw = crop[3];
   const float* where = b.base + b.used;
   REQUIRE(ch > 0 && cw > 0 && ci >= 0 && cj >= 0 && ci + ch <= H && cj + cw <= W, ADVX_E_BADARG, "crop window outside the image");
@@ -902,9 +905,14 @@ int32_t build_crop_stage(int H, int W, const int32_t* crop, Bump& b, hipStream_t
   const bool same = may_reuse && cc.where == where && cc.H == H && cc.W == W && cc.stream == stq && cc.crop[0] == ci &&
                     cc.crop[1] == cj && cc.crop[2] == ch && cc.crop[3] == cw;
   if (!same) {
-    int rows = std::max(H + ch, W + cw);
-    hipLaunchKernelGGL(k_build_taps, dim3((rows + kBlock - 1) / kBlock, 2), dim3(kBlock), 0, stq, a[0], a[1]);
-    LAUNCH_CHECK();
+    if (deferred) {
+      deferred[0] = a[0];
+      deferred[1] = a[1];
+    } else {
+      int rows = std::max(H + ch, W + cw);
+      hipLaunchKernelGGL(k_build_taps, dim3((rows + kBlock - 1) / kBlock, 2), dim3(kBlock), 0, stq, a[0], a[1]);
+      LAUNCH_CHECK();
+    }
     cc.where = where; cc.H = H; cc.W = W; cc.stream = stq;
     cc.crop[0] = ci; cc.crop[1] = cj; cc.crop[2] = ch; cc.crop[3] = cw;
   }
@@ -948,16 +956,24 @@ extern "C" int32_t advx_image_fwd(const float* p, const float* x0, int32_t H, in
   Bump b{scratch};
   double* partials = reinterpret_cast<double*>(b.take(partial_floats(H, W)));
   DStage crop_stage;
+  TapBuild taps[2];
+  int tap_blocks = 0;          // per axis; > 0: the first launch below also builds the crop window's tap tables
   if (crop) {
-    int32_t rc = build_crop_stage(H, W, crop, b, st, &crop_stage);
+    int32_t rc = build_crop_stage(H, W, crop, b, st, &crop_stage, false, taps);
     if (rc) return rc;
+    tap_blocks = (std::max(H + crop[2], W + crop[3]) + kBlock - 1) / kBlock;
   }
   int nblk;
   if (blur_k > 0) {
     int32_t rc = check_blur(H, W, blur_k, blur_sigma);
     if (rc) return rc;
     float* xbuf = b.take(n);
-    hipLaunchKernelGGL(k_prep<false>, dim3(grid_for(n, kMaxStatBlocks)), dim3(kBlock), 0, st, p, x0, eps, n, xbuf, partials);
+    const int nprep = grid_for(n, kMaxStatBlocks);
+    if (tap_blocks > 0)
+      hipLaunchKernelGGL(k_prep_taps<false>, dim3(nprep + 2 * tap_blocks), dim3(kBlock), 0, st, p, x0, eps, n, xbuf, partials,
+                         nprep, taps[0], taps[1], tap_blocks);
+    else
+      hipLaunchKernelGGL(k_prep<false>, dim3(nprep), dim3(kBlock), 0, st, p, x0, eps, n, xbuf, partials);
     LAUNCH_CHECK();
     dim3 grid((W + kBlurTile - 1) / kBlurTile, (H + kBlurTile - 1) / kBlurTile, 3);
     hipLaunchKernelGGL(k_blur<0>, grid, dim3(kBlock), 0, st, xbuf, H, W, blur_k / 2, blur_sigma, x0, s, partials);
@@ -965,16 +981,24 @@ extern "C" int32_t advx_image_fwd(const float* p, const float* x0, int32_t H, in
     nblk = (int)blur_tiles(H, W);
   } else {
     nblk = grid_for(n, kMaxStatBlocks);
-    hipLaunchKernelGGL(k_prep<true>, dim3(nblk), dim3(kBlock), 0, st, p, x0, eps, n, s, partials);
+    if (tap_blocks > 0)
+      hipLaunchKernelGGL(k_prep_taps<true>, dim3(nblk + 2 * tap_blocks), dim3(kBlock), 0, st, p, x0, eps, n, s, partials, nblk,
+                         taps[0], taps[1], tap_blocks);
+    else
+      hipLaunchKernelGGL(k_prep<true>, dim3(nblk), dim3(kBlock), 0, st, p, x0, eps, n, s, partials);
     LAUNCH_CHECK();
+  }
+  if (crop) {
+    // block 0 of the window's resize reduces the statistics partials: no one-block launch in between
+    const float* src = s + (size_t)crop[0] * W + crop[1];
+    hipLaunchKernelGGL(k_stage_fwd_img, dim3(grid_for(n)), dim3(kBlock), 0, st, crop_stage, src, (long long)H * W, W, argument,
+                       (const double*)partials, nblk, n, stats);
+    LAUNCH_CHECK();
+    return ADVX_OK;
   }
   hipLaunchKernelGGL(k_finalize_image, dim3(1), dim3(kBlock), 0, st, partials, nblk, n, stats);
   LAUNCH_CHECK();
-  if (crop) {
-    const float* src = s + (size_t)crop[0] * W + crop[1];
-    hipLaunchKernelGGL(k_stage_fwd, dim3(grid_for(n)), dim3(kBlock), 0, st, crop_stage, src, (long long)H * W, W, argument);
-    LAUNCH_CHECK();
-  } else if (argument && argument != s) {
+  if (argument && argument != s) {
     HIP_TRY(hipMemcpyAsync(argument, s, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
   }
   return ADVX_OK;

@@ -303,9 +303,11 @@ struct TapBuild {
   int* tcount;
   float* tw;
 };
+__device__ inline void build_taps_row(const TapBuild& a, int i);
 __global__ void __launch_bounds__(kBlock) k_build_taps(TapBuild a0, TapBuild a1) {
-  const TapBuild a = (blockIdx.y == 0) ? a0 : a1;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  build_taps_row((blockIdx.y == 0) ? a0 : a1, blockIdx.x * blockDim.x + threadIdx.x);
+}
+__device__ inline void build_taps_row(const TapBuild& a, int i) {
   float row[64];
   if (i < a.out_size) {
     float* w = a.w + (size_t)i * a.stride;
@@ -327,6 +329,33 @@ __global__ void __launch_bounds__(kBlock) k_build_taps(TapBuild a0, TapBuild a1)
       tw[q] = (slot >= 0 && slot < st) ? row[slot] : 0.0f;
     }
   }
+}
+
+// k_prep with the crop window's tap tables built beside it: blocks [0, nprep) are k_prep's, the
+// rest k_build_taps' (axis = which half of them) - one launch instead of two at the head of a step
+// that crops; both only feed the resize of the window that follows.
+template <bool WRITE_S>
+__global__ void __launch_bounds__(kBlock) k_prep_taps(const float* __restrict__ p, const float* __restrict__ x0, float eps,
+                                                      long long n, float* __restrict__ out, double* __restrict__ partials,
+                                                      int nprep, TapBuild a0, TapBuild a1, int tap_blocks_per_axis) {
+  if ((int)blockIdx.x >= nprep) {
+    const int tb = (int)blockIdx.x - nprep;
+    const int axis = tb / tap_blocks_per_axis;
+    build_taps_row(axis == 0 ? a0 : a1, (tb - axis * tap_blocks_per_axis) * blockDim.x + threadIdx.x);
+    return;
+  }
+  double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)nprep * blockDim.x) {
+    float x = eps * tanhf(p[i]);
+    if (WRITE_S) {
+      float s = x0[i] + x;
+      out[i] = s;
+      stat_accumulate(s, x, acc);
+    } else {
+      out[i] = x;
+    }
+  }
+  if (WRITE_S) block_sum_store<kStatSlots>(acc, partials + (size_t)blockIdx.x * kStatSlots);
 }
 
 // ========================================================================== stage fwd
@@ -365,6 +394,23 @@ __device__ inline float stage_fwd_value(const DStage& st, const float* __restric
 
 __global__ void __launch_bounds__(kBlock) k_stage_fwd(DStage st, const float* __restrict__ src, long long src_cstride,
                                                       int src_rstride, float* __restrict__ canvas) {
+  long long n = 3LL * st.can_h * st.can_w;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)((unsigned)i / ((unsigned)st.can_h * (unsigned)st.can_w));
+    int rem = (int)((unsigned)i - (unsigned)c * (unsigned)st.can_h * (unsigned)st.can_w);
+    int y = rem / st.can_w, x = rem - y * st.can_w;
+    canvas[i] = stage_fwd_value(st, src, src_cstride, src_rstride, c, y, x);
+  }
+}
+
+// k_stage_fwd whose block 0 first reduces the statistics partials of the image (the crop's resize
+// follows, in the same call, the kernels that left them): no one-block launch in between
+__global__ void __launch_bounds__(kBlock) k_stage_fwd_img(DStage st, const float* __restrict__ src, long long src_cstride,
+                                                          int src_rstride, float* __restrict__ canvas,
+                                                          const double* __restrict__ img_partials, int nblk, long long n_img,
+                                                          float* __restrict__ stats) {
+  if (blockIdx.x == 0 && nblk > 0) finalize_image_block<true>(img_partials, nblk, n_img, stats);
   long long n = 3LL * st.can_h * st.can_w;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {

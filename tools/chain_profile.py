@@ -18,7 +18,13 @@ def main():
     chain = sys.argv[2] if len(sys.argv) > 2 else "prepared"
     dev = torch.device("cuda:0")
     H = W = 336 if which == "mllama" else 512
-    if which == "cross":                       # BASELINE configs 4/5 in the shape tools/generic_bench.py times
+    crop = None
+    if which in ("llava-crop", "llava-blur-crop"):      # what half of the reference's attack scripts run (--use_local_crop)
+        H = W = 512
+        plans, B = [Plan.llava(H, W)], 64
+        kw = dict(use_crop=True, **(dict(blur_kernel=9) if "blur" in which else {}))
+        crop = (40, 30, 400, 420)
+    elif which == "cross":                       # BASELINE configs 4/5 in the shape tools/generic_bench.py times
         H = W = 336
         plans, B, kw = [Plan.phi3(H, W), Plan.qwen2vl(H, W), Plan.mllama(H, W)], 16, dict(blur_kernel=5, cross_mode=True)
     else:
@@ -35,7 +41,7 @@ def main():
         if it == 10:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        eng.forward(B, blur_sigma=sig)
+        eng.forward(B, blur_sigma=sig, crop=crop)
         eng.backward_update(gs)
     torch.cuda.synchronize()
     print(f"{which} {chain}: {(time.perf_counter() - t0) / 50 * 1e6:.1f} us/step (wall, 50 steps)")
