@@ -1085,6 +1085,67 @@ extern "C" int32_t advx_update(float* p, float* m, float* v, float* grad_p, cons
   return ADVX_OK;
 }
 
+// advx_image_bwd followed by advx_update when nothing sits between them (one rank, or a step inside a
+// gradient-accumulation window): the same arithmetic with the tanh backward - and, without blur, the
+// crop window's transposed resize - inside the optimiser's launch.
+extern "C" int32_t advx_image_bwd_update(float* p, const float* s, const float* garg, int32_t H, int32_t W, float eps,
+                                         int32_t blur_k, float blur_sigma, const int32_t* crop, float imgfit_scale,
+                                         float* grad_p, int32_t accumulate, const float* mask, float* m, float* v,
+                                         const advx_opt_scalars* opt, float* stats, float* image_scratch, float* update_scratch,
+                                         void* stream) {
+  REQUIRE(p && s && garg && grad_p && mask && opt && stats && image_scratch && update_scratch, ADVX_E_BADARG,
+          "advx_image_bwd_update: null argument");
+  REQUIRE(H > 0 && W > 0 && H <= 16384 && W <= 16384, ADVX_E_SHAPE, "advx_image_bwd_update: bad image size");
+  int32_t rc = check_opt(opt, m, v);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = 3LL * H * W;
+  const float c_fit = imgfit_scale / (float)n;
+  Bump b{image_scratch};
+  (void)b.take(partial_floats(H, W));
+  double* partials = reinterpret_cast<double*>(update_scratch);
+  const int nblk = grid_for(n, 2048);
+  const OptScalars o = to_dev(opt);
+  DStage D;
+  std::memset(&D, 0, sizeof(D));
+  if (crop) {
+    rc = build_crop_stage(H, W, crop, b, st, &D, /*may_reuse=*/true);
+    if (rc) return rc;
+  }
+  if (blur_k > 0) {
+    rc = check_blur(H, W, blur_k, blur_sigma);
+    if (rc) return rc;
+    const float* gs = garg;
+    if (crop) {
+      float* gsbuf = b.take(n);
+      hipLaunchKernelGGL(k_crop_bwd, dim3(grid_for(n)), dim3(kBlock), 0, st, D, garg, gsbuf, H, W, crop[0], crop[1]);
+      LAUNCH_CHECK();
+      gs = gsbuf;
+    }
+    const int r = blur_k / 2;
+    float* gpre = b.take(n);
+    float* c2 = b.take(3LL * (H + 2 * r) * (W + 2 * r));
+    hipLaunchKernelGGL(k_add_imgfit, dim3(grid_for(n)), dim3(kBlock), 0, st, gs, s, c_fit, n, gpre);
+    LAUNCH_CHECK();
+    dim3 grid((W + 2 * r + kBlurTile - 1) / kBlurTile, (H + 2 * r + kBlurTile - 1) / kBlurTile, 3);
+    hipLaunchKernelGGL(k_blur<1>, grid, dim3(kBlock), 0, st, gpre, H, W, r, blur_sigma, (const float*)nullptr, c2,
+                       (double*)nullptr);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bwd_update<1>, dim3(nblk), dim3(kBlock), 0, st, s, gs, (const float*)c2, D, 0, 0, H, W, r, eps, c_fit,
+                       accumulate, p, m, v, grad_p, mask, o, partials);
+  } else if (crop) {
+    hipLaunchKernelGGL(k_bwd_update<2>, dim3(nblk), dim3(kBlock), 0, st, s, garg, (const float*)nullptr, D, crop[0], crop[1], H,
+                       W, 0, eps, c_fit, accumulate, p, m, v, grad_p, mask, o, partials);
+  } else {
+    hipLaunchKernelGGL(k_bwd_update<0>, dim3(nblk), dim3(kBlock), 0, st, s, garg, (const float*)nullptr, D, 0, 0, H, W, 0, eps,
+                       c_fit, accumulate, p, m, v, grad_p, mask, o, partials);
+  }
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_finalize_norm, dim3(1), dim3(kBlock), 0, st, partials, nblk, stats);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
 // ------------------------------------------------------------------------------- fused
 extern "C" int32_t advx_fused_supported(const advx_plan* p) {
   if (!p) return 0;

@@ -572,6 +572,23 @@ __global__ void __launch_bounds__(kBlock) k_stage0_bwd_multi(MultiBwd mb, float*
 // adjoint of the random-resized crop (attack_model.py:307-310): the gradient arrives in the
 // canvas order of the resized window (H x W); one thread per pixel of the WHOLE image writes the
 // transposed resize inside the window (ci, cj, src_h, src_w) and exact zeros outside it
+__device__ inline float crop_bwd_value(const DStage& st, const float* __restrict__ gcan, int ci, int cj, int c, int y, int x) {
+  const int ys = y - ci, xs = x - cj;
+  float v = 0.0f;
+  if (ys >= 0 && ys < st.src_h && xs >= 0 && xs < st.src_w) {
+    int oy = st.tth.start[ys], oyc = st.tth.count[ys];
+    int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
+    const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
+    const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
+    const float* gp = gcan + (size_t)c * st.can_h * st.can_w;
+    for (int a = 0; a < oyc; ++a) {
+      float h = 0.0f;
+      for (int b = 0; b < oxc; ++b) h += wx[b] * gp[(size_t)(oy + a) * st.can_w + ox + b];
+      v += wy[a] * h;
+    }
+  }
+  return v;
+}
 __global__ void __launch_bounds__(kBlock) k_crop_bwd(DStage st, const float* __restrict__ gcan, float* __restrict__ gimg,
                                                      int H, int W, int ci, int cj) {
   const unsigned plane = (unsigned)H * (unsigned)W;
@@ -581,21 +598,7 @@ __global__ void __launch_bounds__(kBlock) k_crop_bwd(DStage st, const float* __r
     const int c = (int)((unsigned)i / plane);
     const unsigned rem = (unsigned)i - (unsigned)c * plane;
     const int y = (int)(rem / (unsigned)W), x = (int)(rem - (unsigned)y * (unsigned)W);
-    const int ys = y - ci, xs = x - cj;
-    float v = 0.0f;
-    if (ys >= 0 && ys < st.src_h && xs >= 0 && xs < st.src_w) {
-      int oy = st.tth.start[ys], oyc = st.tth.count[ys];
-      int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
-      const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
-      const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
-      const float* gp = gcan + (size_t)c * st.can_h * st.can_w;
-      for (int a = 0; a < oyc; ++a) {
-        float h = 0.0f;
-        for (int b = 0; b < oxc; ++b) h += wx[b] * gp[(size_t)(oy + a) * st.can_w + ox + b];
-        v += wy[a] * h;
-      }
-    }
-    gimg[i] = v;
+    gimg[i] = crop_bwd_value(st, gcan, ci, cj, c, y, x);
   }
 }
 
@@ -844,6 +847,53 @@ __global__ void __launch_bounds__(kBlock) k_update(float* __restrict__ p, float*
 __global__ void __launch_bounds__(kBlock) k_finalize_norm(const double* __restrict__ partials, int nblk,
                                                           float* __restrict__ stats) {
   finalize_norm_block(partials, nblk, stats);
+}
+
+// Image-level backward tail and optimiser in ONE launch (no all-reduce in between): what
+// [k_crop_bwd,] k_tanh_bwd and k_update do per element, in their order, on values kept in
+// registers.  MODE 0: gradient of the image given (gs); 1: folded blur adjoint (c2); 2: gs is
+// the gradient of the crop window's resize, gathered here (exact zeros outside the window).
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_bwd_update(const float* __restrict__ s, const float* __restrict__ gs,
+                                                       const float* __restrict__ c2, DStage crop_st, int ci, int cj, int H, int W,
+                                                       int r, float eps, float c_fit, int accumulate, float* __restrict__ p,
+                                                       float* __restrict__ m, float* __restrict__ v, float* __restrict__ grad,
+                                                       const float* __restrict__ mask, OptScalars o,
+                                                       double* __restrict__ partials) {
+  const unsigned plane = (unsigned)H * (unsigned)W;
+  const long long n = 3LL * plane;
+  double acc[1] = {0.0};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float gx;
+    if (MODE == 0) {
+      gx = gs[i] + imgfit_grad(s[i], c_fit);
+    } else {
+      const int c = (int)((unsigned)i / plane);
+      const unsigned rem = (unsigned)i - (unsigned)c * plane;
+      const int y = (int)(rem / (unsigned)W), x = (int)(rem - (unsigned)y * (unsigned)W);
+      if (MODE == 1) gx = blur_fold(c2 + (size_t)c * (H + 2 * r) * (W + 2 * r), H, W, r, y, x);
+      else gx = crop_bwd_value(crop_st, gs, ci, cj, c, y, x) + imgfit_grad(s[i], c_fit);
+    }
+    float pp = p[i];
+    const float t = tanhf(pp);
+    float g = (gx * eps) * (1.0f - t * t);
+    if (accumulate) g = grad[i] + g;
+    g = g * mask[i];                          // attack_model.py:336
+    grad[i] = g;
+    acc[0] += (double)g * (double)g;
+    if (o.apply) {
+      if (o.kind == 0) {
+        float mm = m[i], vv = v[i];
+        adamw_element(pp, mm, vv, g, o);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+      } else {
+        float sg = (g > 0.0f) ? 1.0f : ((g < 0.0f) ? -1.0f : 0.0f);
+        p[i] = pp - o.lr * sg;
+      }
+    }
+  }
+  block_sum_store<1>(acc, partials + blockIdx.x);
 }
 
 // ================================================================= fused (identity plan)

@@ -199,6 +199,20 @@ def image_bwd(p, s, grad_argument, epsilon, imgfit_scale, grad_p, scratch, blur=
     return grad_p
 
 
+def image_bwd_update(p, s, grad_argument, epsilon, imgfit_scale, grad_p, mask, m, v, opt, stats, image_scratch, update_scratch,
+                     blur=None, crop=None, accumulate=False):
+    """image_bwd + update in one call (nothing in between: no all-reduce)."""
+    _require_cuda(p, s, grad_argument, grad_p, mask, stats, image_scratch, update_scratch)
+    _, H, W = p.shape
+    k, sig = (blur if blur is not None else (0, 0.0))
+    keep, cptr = _crop_arg(crop)
+    L.check(L.load().advx_image_bwd_update(L.ptr(p), L.ptr(s), L.ptr(_f32c(grad_argument)), H, W, float(epsilon), int(k),
+                                           float(sig), cptr, float(imgfit_scale), L.ptr(grad_p), int(accumulate), L.ptr(mask),
+                                           L.ptr(m), L.ptr(v), C.byref(opt), L.ptr(stats), L.ptr(image_scratch),
+                                           L.ptr(update_scratch), _stream(p)), "advx_image_bwd_update")
+    return grad_p
+
+
 def update(p, m, v, grad_p, mask, opt, stats, scratch):
     _require_cuda(p, grad_p, mask, stats, scratch)
     L.check(L.load().advx_update(L.ptr(p), L.ptr(m), L.ptr(v), L.ptr(grad_p), L.ptr(mask), p.numel(), C.byref(opt),

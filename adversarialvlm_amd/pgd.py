@@ -387,6 +387,17 @@ class PixelPGD:
             else:
                 pl, g, B = self.plans[0], grads[0], st["batches"][0]
                 ops.collect(pl, g.reshape(B, pl.out_numel), B, grad_argument=self.garg, workspace=self.workspaces[0])
+            if not (self.exchange and take_step):
+                # nothing between the image-level backward and the optimiser: one call, the tanh backward
+                # (and the crop's transposed resize) inside the optimiser's launch
+                ops.image_bwd_update(self.p, self.s, self.garg, self.eps, self.imgfit_scale(), self.grad, self.mask, self.m,
+                                     self.v, opt, self.stats, self.img_scratch, self.upd_scratch, blur=st["blur"],
+                                     crop=st["crop"], accumulate=accumulate)
+                if take_step:
+                    self._scheduler_step()
+                self.iteration += 1
+                self._last = None
+                return take_step
             ops.image_bwd(self.p, self.s, self.garg, self.eps, self.imgfit_scale(), self.grad, self.img_scratch,
                           blur=st["blur"], crop=st["crop"], accumulate=accumulate)
             if self.exchange and take_step:

@@ -236,6 +236,16 @@ typedef struct advx_opt_scalars {
 } advx_opt_scalars;
 int32_t advx_update(float* p, float* m, float* v, float* grad_p, const float* mask, int64_t n,
                     const advx_opt_scalars* opt, float* stats, float* scratch, void* stream);
+
+/* advx_image_bwd followed by advx_update in one call, for when nothing sits between them (one rank,
+ * or a step inside a gradient-accumulation window): same results, with the tanh backward - and,
+ * without blur, the crop window's transposed resize - inside the optimiser's launch.
+ * image_scratch / update_scratch as for advx_image_bwd / advx_update. */
+int32_t advx_image_bwd_update(float* p, const float* s, const float* grad_argument, int32_t H, int32_t W,
+                              float epsilon, int32_t blur_kernel, float blur_sigma, const int32_t* crop_ijhw,
+                              float imgfit_scale, float* p_grad, int32_t accumulate, const float* mask,
+                              float* m, float* v, const advx_opt_scalars* opt, float* stats,
+                              float* image_scratch, float* update_scratch, void* stream);
 int64_t advx_update_scratch_floats(int64_t n);
 
 /* ------------------------------------------- fused fast path (headline config)
@@ -322,7 +332,7 @@ int32_t advx_fused_step_flush(advx_plan* plan, int32_t parity, int32_t norm_rows
  * launch each way) without blur, crop or gradient accumulation: the backward of step t leaves
  * s_{t+1}, its statistics partials and the processed canvas of step t+1 behind, so a step of
  * attack_model.py:300-346,366-373 is four launches (emit | batch-reduce, tail, head) instead of
- * the nine of advx_image_* + advx_emit + advx_collect + advx_update.
+ * the seven to eleven of advx_image_fwd + advx_emit + advx_collect + advx_image_bwd_update.
  *   advx_prepared_fwd : out[B, out_numel] = canvas (+ sigma*noise), sigma = stats[QERR_STD] of the
  *                       previous image; prepared == 0 (first step / p changed elsewhere) first
  *                       builds s (s_buf), its partials (row set `parity`) and the canvas.

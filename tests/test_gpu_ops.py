@@ -200,3 +200,42 @@ def test_quantise_is_uint8_truncation():
                    torch.tensor([-1.0, 0.0, 1.0, 2.0, 0.999999, 1e-9])])
     got = ops.quantise(s.to(dev)).cpu()
     assert torch.equal(got, P.quantise(s))
+
+
+@pytest.mark.parametrize("blur,crop", [(None, None), ((5, 1.7), None), (None, (6, 9, 50, 61)), ((9, 0.8), (6, 9, 50, 61))])
+@pytest.mark.parametrize("kind,apply,accumulate", [("adamw", 1, False), ("adamw", 0, True), ("sign", 1, True)])
+def test_image_bwd_update_is_image_bwd_then_update(ops, dev, blur, crop, kind, apply, accumulate):
+    """advx_image_bwd_update (tanh backward - and the crop's transposed resize - inside the optimiser's
+    launch) against advx_image_bwd followed by advx_update: identical bits in grad, p, m, v, ||g||."""
+    from adversarialvlm_amd import _lib as L
+    H, W = 64, 80
+    gen = torch.Generator().manual_seed(17)
+    x0 = torch.rand(3, H, W, generator=gen).to(dev)
+    mask = (torch.rand(3, H, W, generator=gen) > 0.3).float().to(dev)
+    garg = (torch.randn(3, H, W, generator=gen) * 0.05).to(dev)
+    o = L.OptScalars()
+    o.kind, o.apply = (L.OPT_ADAMW if kind == "adamw" else L.OPT_SIGN), apply
+    o.lr, o.decay, o.w1, o.beta2, o.w2 = 1e-2, 1 - 1e-4, 0.1, 0.999, 0.001
+    o.bias2_sqrt, o.eps, o.neg_step_size = (1 - 0.999 ** 3) ** 0.5, 1e-8, -(1e-2 / (1 - 0.9 ** 3))
+    runs = []
+    for fused in (False, True):
+        g2 = torch.Generator().manual_seed(18)
+        p = (torch.randn(3, H, W, generator=g2) * 0.3).to(dev)
+        m = (torch.randn(3, H, W, generator=g2) * 0.01).to(dev)
+        v = (torch.rand(3, H, W, generator=g2) * 1e-4).to(dev)
+        grad = (torch.randn(3, H, W, generator=g2) * 0.01).to(dev)
+        stats = torch.zeros(L.STATS_N, device=dev)
+        iscr = ops.image_scratch(H, W, blur[0] if blur else 0, dev)
+        uscr = ops.update_scratch(p.numel(), dev)
+        s, arg = ops.image_fwd(p, x0, 0.5, stats, iscr, blur=blur, crop=crop,
+                               argument=torch.empty_like(x0) if crop is not None else None)
+        if fused:
+            ops.image_bwd_update(p, s, garg, 0.5, 0.7, grad, mask, m, v, o, stats, iscr, uscr, blur=blur, crop=crop,
+                                 accumulate=accumulate)
+        else:
+            ops.image_bwd(p, s, garg, 0.5, 0.7, grad, iscr, blur=blur, crop=crop, accumulate=accumulate)
+            ops.update(p, m, v, grad, mask, o, stats, uscr)
+        runs.append((grad.clone(), p.clone(), m.clone(), v.clone(), stats.clone()))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    assert float(runs[0][4][L.STAT_GRAD_NORM]) > 0
