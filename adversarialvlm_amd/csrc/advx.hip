@@ -967,16 +967,23 @@ extern "C" int32_t advx_image_fwd(const float* p, const float* x0, int32_t H, in
   if (blur_k > 0) {
     int32_t rc = check_blur(H, W, blur_k, blur_sigma);
     if (rc) return rc;
-    float* xbuf = b.take(n);
-    const int nprep = grid_for(n, kMaxStatBlocks);
-    if (tap_blocks > 0)
-      hipLaunchKernelGGL(k_prep_taps<false>, dim3(nprep + 2 * tap_blocks), dim3(kBlock), 0, st, p, x0, eps, n, xbuf, partials,
-                         nprep, taps[0], taps[1], tap_blocks);
-    else
-      hipLaunchKernelGGL(k_prep<false>, dim3(nprep), dim3(kBlock), 0, st, p, x0, eps, n, xbuf, partials);
-    LAUNCH_CHECK();
+    // x = eps*tanh(p) is formed while the blur loads its tiles (k_blur<0, 1>): no launch, no buffer for x.
+    // The crop window's tap tables are built by extra blocks of the same launch when the grid has room.
     dim3 grid((W + kBlurTile - 1) / kBlurTile, (H + kBlurTile - 1) / kBlurTile, 3);
-    hipLaunchKernelGGL(k_blur<0>, grid, dim3(kBlock), 0, st, xbuf, H, W, blur_k / 2, blur_sigma, x0, s, partials);
+    TapBuild none[2];
+    std::memset(none, 0, sizeof(none));
+    int riding = 0;
+    if (tap_blocks > 0) {
+      if ((long long)grid.x * grid.y >= 2LL * tap_blocks) {
+        riding = tap_blocks;
+        grid.z = 4;
+      } else {
+        hipLaunchKernelGGL(k_build_taps, dim3(tap_blocks, 2), dim3(kBlock), 0, st, taps[0], taps[1]);
+        LAUNCH_CHECK();
+      }
+    }
+    hipLaunchKernelGGL((k_blur<0, 1>), grid, dim3(kBlock), 0, st, p, H, W, blur_k / 2, blur_sigma, x0, s, partials,
+                       (const float*)nullptr, eps, riding ? taps[0] : none[0], riding ? taps[1] : none[1], riding);
     LAUNCH_CHECK();
     nblk = (int)blur_tiles(H, W);
   } else {
@@ -1031,11 +1038,11 @@ extern "C" int32_t advx_image_bwd(const float* p, const float* s, const float* g
     int r = blur_k / 2;
     float* gpre = b.take(n);
     float* c2 = b.take(3LL * (H + 2 * r) * (W + 2 * r));
-    hipLaunchKernelGGL(k_add_imgfit, dim3(grid_for(n)), dim3(kBlock), 0, st, gs, s, c_fit, n, gpre);
-    LAUNCH_CHECK();
+    // the blur adjoint's input gs + imgfit'(s) is formed while its tiles are loaded (k_blur<1, 2>)
+    (void)gpre;
     dim3 grid((W + 2 * r + kBlurTile - 1) / kBlurTile, (H + 2 * r + kBlurTile - 1) / kBlurTile, 3);
-    hipLaunchKernelGGL(k_blur<1>, grid, dim3(kBlock), 0, st, gpre, H, W, r, blur_sigma, (const float*)nullptr, c2,
-                       (double*)nullptr);
+    hipLaunchKernelGGL((k_blur<1, 2>), grid, dim3(kBlock), 0, st, gs, H, W, r, blur_sigma, (const float*)nullptr, c2,
+                       (double*)nullptr, s, c_fit);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_tanh_bwd<true>, dim3(grid_for(n)), dim3(kBlock), 0, st, p, s, gs, c2, H, W, r, eps, c_fit,
                        accumulate, grad_p);
@@ -1125,11 +1132,11 @@ extern "C" int32_t advx_image_bwd_update(float* p, const float* s, const float* 
     const int r = blur_k / 2;
     float* gpre = b.take(n);
     float* c2 = b.take(3LL * (H + 2 * r) * (W + 2 * r));
-    hipLaunchKernelGGL(k_add_imgfit, dim3(grid_for(n)), dim3(kBlock), 0, st, gs, s, c_fit, n, gpre);
-    LAUNCH_CHECK();
+    // the blur adjoint's input gs + imgfit'(s) is formed while its tiles are loaded (k_blur<1, 2>)
+    (void)gpre;
     dim3 grid((W + 2 * r + kBlurTile - 1) / kBlurTile, (H + 2 * r + kBlurTile - 1) / kBlurTile, 3);
-    hipLaunchKernelGGL(k_blur<1>, grid, dim3(kBlock), 0, st, gpre, H, W, r, blur_sigma, (const float*)nullptr, c2,
-                       (double*)nullptr);
+    hipLaunchKernelGGL((k_blur<1, 2>), grid, dim3(kBlock), 0, st, gs, H, W, r, blur_sigma, (const float*)nullptr, c2,
+                       (double*)nullptr, s, c_fit);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bwd_update<1>, dim3(nblk), dim3(kBlock), 0, st, s, gs, (const float*)c2, D, 0, 0, H, W, r, eps, c_fit,
                        accumulate, p, m, v, grad_p, mask, o, partials);

@@ -109,6 +109,46 @@ __global__ void __launch_bounds__(kBlock) k_fused_flush(FusedHeader* __restrict_
   }
 }
 
+// ===================================================================== tap-table builder
+// Device-side construction of the tables of a dynamic resize (the random-resized-crop
+// window changes every step).  blockIdx.y = axis; rows [0,out) forward, [out,out+in) transposed.
+struct TapBuild {
+  int mode, in_size, out_size, stride, tstride;
+  int* start;
+  int* count;
+  float* w;
+  int* tstart;
+  int* tcount;
+  float* tw;
+};
+__device__ inline void build_taps_row(const TapBuild& a, int i);
+__global__ void __launch_bounds__(kBlock) k_build_taps(TapBuild a0, TapBuild a1) {
+  build_taps_row((blockIdx.y == 0) ? a0 : a1, blockIdx.x * blockDim.x + threadIdx.x);
+}
+__device__ inline void build_taps_row(const TapBuild& a, int i) {
+  float row[64];
+  if (i < a.out_size) {
+    float* w = a.w + (size_t)i * a.stride;
+    TapRow r = tap_row(a.mode, a.in_size, a.out_size, i, a.stride, w);
+    a.start[i] = r.start;
+    a.count[i] = r.count;
+  } else if (i < a.out_size + a.in_size) {
+    int j = i - a.out_size;
+    TapRow t = tap_bounds_transposed(a.mode, a.in_size, a.out_size, j);
+    if (t.count > a.tstride) t.count = a.tstride;  // guarded by the host-side bound
+    a.tstart[j] = t.start;
+    a.tcount[j] = t.count;
+    float* tw = a.tw + (size_t)j * a.tstride;
+    for (int q = 0; q < a.tstride; ++q) tw[q] = 0.0f;
+    int st = a.stride < 64 ? a.stride : 64;
+    for (int q = 0; q < t.count; ++q) {
+      TapRow r = tap_row(a.mode, a.in_size, a.out_size, t.start + q, st, row);
+      int slot = j - r.start;
+      tw[q] = (slot >= 0 && slot < st) ? row[slot] : 0.0f;
+    }
+  }
+}
+
 // ================================================================================ blur
 // Separable Gaussian, LDS-staged 32x32 output tile with halo r on every side; one block =
 // one tile of one channel.  REFLECT: torchvision GaussianBlur forward (reflect pad).
@@ -126,10 +166,27 @@ __device__ inline int reflect_index(int u, int n) {
 
 // MODE 0: reflect, output HxW, epilogue s = x0 + blur(x) with statistics (x0 may be null: plain store)
 // MODE 1: zero padding, output (H+2r)x(W+2r)
-template <int MODE>
+// IN: what a tile element is made of while it is loaded - 0: in[i]; 1: eps*tanh(in[i]) (in = p: the
+// tanh reparameterisation without a launch and a buffer of its own); 2: in[i] + imgfit'(aux[i])
+// (in = gradient w.r.t. s, aux = s: the input of the blur adjoint).  Same expressions as k_prep /
+// k_add_imgfit, so the same bits; halo elements are evaluated once per tile that needs them.
+// IN == 1 launches may carry extra blocks (blockIdx.z == 3) that build the crop window's tap tables.
+__device__ inline float imgfit_grad(float s, float c);
+template <int MODE, int IN = 0>
 __global__ void __launch_bounds__(kBlock) k_blur(const float* __restrict__ in, int H, int W, int r, float sigma,
                                                  const float* __restrict__ x0, float* __restrict__ out,
-                                                 double* __restrict__ partials) {
+                                                 double* __restrict__ partials, const float* __restrict__ aux = nullptr,
+                                                 float scalar = 0.0f, TapBuild taps0 = TapBuild(),
+                                                 TapBuild taps1 = TapBuild(), int tap_blocks = 0) {
+  if (IN == 1 && blockIdx.z == 3) {
+    // tap-table builder blocks riding in this launch (k_build_taps' work)
+    const int tb = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    if (tb < 2 * tap_blocks) {
+      const int axis = tb / tap_blocks;
+      build_taps_row(axis == 0 ? taps0 : taps1, (tb - axis * tap_blocks) * (int)blockDim.x + (int)threadIdx.x);
+    }
+    return;
+  }
   __shared__ float wgt[2 * kBlurMaxR + 1];
   __shared__ float tile[kBlurTile + 2 * kBlurMaxR][kBlurTile + 2 * kBlurMaxR + 1];
   __shared__ float tmp[kBlurTile + 2 * kBlurMaxR][kBlurTile + 1];
@@ -155,11 +212,13 @@ __global__ void __launch_bounds__(kBlock) k_blur(const float* __restrict__ in, i
   for (int e = threadIdx.x; e < th * tw; e += blockDim.x) {
     int ty = e / tw, tx = e - ty * tw;
     int gy = oy0 - ext - r + ty, gx = ox0 - ext - r + tx;  // image coordinates
-    float v;
-    if (MODE == 0) {
-      v = src[(size_t)reflect_index(gy, H) * W + reflect_index(gx, W)];
-    } else {
-      v = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[(size_t)gy * W + gx] : 0.0f;
+    float v = 0.0f;
+    const bool on = (MODE == 0) || (gy >= 0 && gy < H && gx >= 0 && gx < W);
+    if (on) {
+      const size_t o = (MODE == 0) ? (size_t)reflect_index(gy, H) * W + reflect_index(gx, W) : (size_t)gy * W + gx;
+      v = src[o];
+      if (IN == 1) v = scalar * tanhf(v);
+      if (IN == 2) v = v + imgfit_grad(aux[(size_t)c * H * W + o], scalar);
     }
     tile[ty][tx] = v;
   }
@@ -288,46 +347,6 @@ __global__ void __launch_bounds__(kBlock) k_tanh_bwd_plain(const float* __restri
        i += (long long)gridDim.x * blockDim.x) {
     float t = tanhf(p[i]);
     gp[i] = (gx[i] * eps) * (1.0f - t * t);
-  }
-}
-
-// ===================================================================== tap-table builder
-// Device-side construction of the tables of a dynamic resize (the random-resized-crop
-// window changes every step).  blockIdx.y = axis; rows [0,out) forward, [out,out+in) transposed.
-struct TapBuild {
-  int mode, in_size, out_size, stride, tstride;
-  int* start;
-  int* count;
-  float* w;
-  int* tstart;
-  int* tcount;
-  float* tw;
-};
-__device__ inline void build_taps_row(const TapBuild& a, int i);
-__global__ void __launch_bounds__(kBlock) k_build_taps(TapBuild a0, TapBuild a1) {
-  build_taps_row((blockIdx.y == 0) ? a0 : a1, blockIdx.x * blockDim.x + threadIdx.x);
-}
-__device__ inline void build_taps_row(const TapBuild& a, int i) {
-  float row[64];
-  if (i < a.out_size) {
-    float* w = a.w + (size_t)i * a.stride;
-    TapRow r = tap_row(a.mode, a.in_size, a.out_size, i, a.stride, w);
-    a.start[i] = r.start;
-    a.count[i] = r.count;
-  } else if (i < a.out_size + a.in_size) {
-    int j = i - a.out_size;
-    TapRow t = tap_bounds_transposed(a.mode, a.in_size, a.out_size, j);
-    if (t.count > a.tstride) t.count = a.tstride;  // guarded by the host-side bound
-    a.tstart[j] = t.start;
-    a.tcount[j] = t.count;
-    float* tw = a.tw + (size_t)j * a.tstride;
-    for (int q = 0; q < a.tstride; ++q) tw[q] = 0.0f;
-    int st = a.stride < 64 ? a.stride : 64;
-    for (int q = 0; q < t.count; ++q) {
-      TapRow r = tap_row(a.mode, a.in_size, a.out_size, t.start + q, st, row);
-      int slot = j - r.start;
-      tw[q] = (slot >= 0 && slot < st) ? row[slot] : 0.0f;
-    }
   }
 }
 
