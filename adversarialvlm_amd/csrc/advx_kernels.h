@@ -291,14 +291,6 @@ __device__ inline float imgfit_grad(float s, float c) {
   return c * (2.0f * up) - c * (2.0f * lo);
 }
 
-// g_pre[i] = grad_s[i] + imgfit'(s[i])   (input of the blur adjoint)
-__global__ void __launch_bounds__(kBlock) k_add_imgfit(const float* __restrict__ gs, const float* __restrict__ s,
-                                                       float c, long long n, float* __restrict__ out) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x)
-    out[i] = gs[i] + imgfit_grad(s[i], c);
-}
-
 // grad_p (+)= (g_x * eps) * (1 - tanh(p)^2) ; g_x = folded blur adjoint or gs + imgfit'
 template <bool BLUR>
 __global__ void __launch_bounds__(kBlock) k_tanh_bwd(const float* __restrict__ p, const float* __restrict__ s,
