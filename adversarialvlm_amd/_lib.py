@@ -79,7 +79,8 @@ SIGNATURES = {
     "advx_image_bwd": (_I32, [_P, _P, _P, _I32, _I32, _F, _I32, _F, _P, _F, _P, _I32, _P, _P]),
     "advx_update": (_I32, [_P, _P, _P, _P, _P, _I64, C.POINTER(OptScalars), _P, _P, _P]),
     "advx_image_bwd_update": (_I32, [_P, _P, _P, _I32, _I32, _F, _I32, _F, _P, _F, _P, _I32, _P, _P, _P, C.POINTER(OptScalars),
-                                     _P, _P, _P, _P]),
+                                     _P, _P, _P, _I32, _P]),
+    "advx_update_flush": (_I32, [_I64, _P, _P, _P]),
     "advx_update_scratch_floats": (_I64, [_I64]),
     "advx_fused_supported": (_I32, [_P]),
     "advx_fused_fwd": (_I32, [_P, _P, _P, _F, _I32, _P, _I32, _U64, _U64, _P, _P, _P, _I32, _I32, _P, _P, _P]),

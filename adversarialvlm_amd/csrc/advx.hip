@@ -1099,7 +1099,7 @@ extern "C" int32_t advx_image_bwd_update(float* p, const float* s, const float* 
                                          int32_t blur_k, float blur_sigma, const int32_t* crop, float imgfit_scale,
                                          float* grad_p, int32_t accumulate, const float* mask, float* m, float* v,
                                          const advx_opt_scalars* opt, float* stats, float* image_scratch, float* update_scratch,
-                                         void* stream) {
+                                         int32_t finalize_norm, void* stream) {
   REQUIRE(p && s && garg && grad_p && mask && opt && stats && image_scratch && update_scratch, ADVX_E_BADARG,
           "advx_image_bwd_update: null argument");
   REQUIRE(H > 0 && W > 0 && H <= 16384 && W <= 16384, ADVX_E_SHAPE, "advx_image_bwd_update: bad image size");
@@ -1148,7 +1148,19 @@ extern "C" int32_t advx_image_bwd_update(float* p, const float* s, const float* 
                        c_fit, accumulate, p, m, v, grad_p, mask, o, partials);
   }
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_finalize_norm, dim3(1), dim3(kBlock), 0, st, partials, nblk, stats);
+  if (finalize_norm) {
+    hipLaunchKernelGGL(k_finalize_norm, dim3(1), dim3(kBlock), 0, st, partials, nblk, stats);
+    LAUNCH_CHECK();
+  }
+  return ADVX_OK;
+}
+
+// ||g|| of the last advx_image_bwd_update(..., finalize_norm = 0) of an n-element image: the one-block
+// reduction its caller skipped, run when somebody reads the statistics
+extern "C" int32_t advx_update_flush(int64_t n, float* stats, float* update_scratch, void* stream) {
+  REQUIRE(n > 0 && stats && update_scratch, ADVX_E_BADARG, "advx_update_flush: bad argument");
+  hipLaunchKernelGGL(k_finalize_norm, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, reinterpret_cast<const double*>(update_scratch),
+                     grid_for(n, 2048), stats);
   LAUNCH_CHECK();
   return ADVX_OK;
 }

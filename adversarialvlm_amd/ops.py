@@ -200,8 +200,9 @@ def image_bwd(p, s, grad_argument, epsilon, imgfit_scale, grad_p, scratch, blur=
 
 
 def image_bwd_update(p, s, grad_argument, epsilon, imgfit_scale, grad_p, mask, m, v, opt, stats, image_scratch, update_scratch,
-                     blur=None, crop=None, accumulate=False):
-    """image_bwd + update in one call (nothing in between: no all-reduce)."""
+                     blur=None, crop=None, accumulate=False, finalize_norm=True):
+    """image_bwd + update in one call (nothing in between: no all-reduce).  finalize_norm=False leaves
+    stats[GRAD_NORM] to `update_flush` (call it before reading the statistics)."""
     _require_cuda(p, s, grad_argument, grad_p, mask, stats, image_scratch, update_scratch)
     _, H, W = p.shape
     k, sig = (blur if blur is not None else (0, 0.0))
@@ -209,8 +210,12 @@ def image_bwd_update(p, s, grad_argument, epsilon, imgfit_scale, grad_p, mask, m
     L.check(L.load().advx_image_bwd_update(L.ptr(p), L.ptr(s), L.ptr(_f32c(grad_argument)), H, W, float(epsilon), int(k),
                                            float(sig), cptr, float(imgfit_scale), L.ptr(grad_p), int(accumulate), L.ptr(mask),
                                            L.ptr(m), L.ptr(v), C.byref(opt), L.ptr(stats), L.ptr(image_scratch),
-                                           L.ptr(update_scratch), _stream(p)), "advx_image_bwd_update")
+                                           L.ptr(update_scratch), int(bool(finalize_norm)), _stream(p)), "advx_image_bwd_update")
     return grad_p
+
+
+def update_flush(n, stats, update_scratch):
+    L.check(L.load().advx_update_flush(int(n), L.ptr(stats), L.ptr(update_scratch), _stream(stats)), "advx_update_flush")
 
 
 def update(p, m, v, grad_p, mask, opt, stats, scratch):

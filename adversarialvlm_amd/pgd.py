@@ -392,7 +392,8 @@ class PixelPGD:
                 # (and the crop's transposed resize) inside the optimiser's launch
                 ops.image_bwd_update(self.p, self.s, self.garg, self.eps, self.imgfit_scale(), self.grad, self.mask, self.m,
                                      self.v, opt, self.stats, self.img_scratch, self.upd_scratch, blur=st["blur"],
-                                     crop=st["crop"], accumulate=accumulate)
+                                     crop=st["crop"], accumulate=accumulate, finalize_norm=False)
+                self._norm_pending = True         # ||g|| is reduced when the statistics are read
                 if take_step:
                     self._scheduler_step()
                 self.iteration += 1
@@ -427,10 +428,16 @@ class PixelPGD:
             ops.fused_step_flush(self.plans[0], self.par, self.norm_rows, self.stats, self.fused_scratch)
         elif self.mode == "pair":
             ops.fused_flush(self.plans[0], self.stats, self.fused_scratch)
+        self._flush_norm()
         v = self.stats.tolist()
         return dict(sigma=v[L.STAT_SIGMA], sigma_next=v[L.STAT_QERR_STD], qerr_mean=v[L.STAT_QERR_MEAN],
                     qerr_l1=v[L.STAT_QERR_L1], img_loss=v[L.STAT_IMGFIT], x_mean=v[L.STAT_X_MEAN],
                     x_std=v[L.STAT_X_STD], grad_norm=v[L.STAT_GRAD_NORM])
+
+    def _flush_norm(self):
+        if getattr(self, "_norm_pending", False):
+            ops.update_flush(self.p.numel(), self.stats, self.upd_scratch)
+            self._norm_pending = False
 
     def current_lr(self):
         return self.lr
@@ -444,6 +451,7 @@ class PixelPGD:
                 ops.fused_step_flush(self.plans[0], self.par, self.norm_rows, self.stats, self.fused_scratch)
             else:
                 ops.fused_flush(self.plans[0], self.stats, self.fused_scratch)
+        self._flush_norm()
         return dict(p=self.p.clone(), m=self.m.clone(), v=self.v.clone(), grad=self.grad.clone(), stats=self.stats.clone(),
                     lr=self.lr, opt_steps=self.opt_steps, iteration=self.iteration, seed=self.seed)
 
@@ -453,6 +461,7 @@ class PixelPGD:
         for k in ("p", "m", "v", "grad", "stats"):
             getattr(self, k).copy_(sd[k].to(self.p.device))
         self.lr, self.opt_steps, self.iteration = float(sd["lr"]), int(sd["opt_steps"]), int(sd["iteration"])
+        self._norm_pending = False                 # the loaded statistics are complete
         self.seed = int(sd.get("seed", self.seed))
         if self.fused:
             # nothing prepared, nothing pending: the next forward re-derives s / v from p

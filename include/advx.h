@@ -245,7 +245,11 @@ int32_t advx_image_bwd_update(float* p, const float* s, const float* grad_argume
                               float epsilon, int32_t blur_kernel, float blur_sigma, const int32_t* crop_ijhw,
                               float imgfit_scale, float* p_grad, int32_t accumulate, const float* mask,
                               float* m, float* v, const advx_opt_scalars* opt, float* stats,
-                              float* image_scratch, float* update_scratch, void* stream);
+                              float* image_scratch, float* update_scratch, int32_t finalize_norm, void* stream);
+/* finalize_norm == 0 leaves stats[ADVX_STAT_GRAD_NORM] to a later advx_update_flush (same n, same
+ * update_scratch, before the next update overwrites its partial sums): a training loop that logs every
+ * k-th step skips the one-block reduction on the others. */
+int32_t advx_update_flush(int64_t n, float* stats, float* update_scratch, void* stream);
 int64_t advx_update_scratch_floats(int64_t n);
 
 /* ------------------------------------------- fused fast path (headline config)
