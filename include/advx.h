@@ -336,7 +336,7 @@ int32_t advx_fused_step_flush(advx_plan* plan, int32_t parity, int32_t norm_rows
  * launch each way) without blur, crop or gradient accumulation: the backward of step t leaves
  * s_{t+1}, its statistics partials and the processed canvas of step t+1 behind, so a step of
  * attack_model.py:300-346,366-373 is four launches (emit | batch-reduce, tail, head) instead of
- * the seven to eleven of advx_image_fwd + advx_emit + advx_collect + advx_image_bwd_update.
+ * the seven to nine of advx_image_fwd + advx_emit + advx_collect + advx_image_bwd_update.
  *   advx_prepared_fwd : out[B, out_numel] = canvas (+ sigma*noise), sigma = stats[QERR_STD] of the
  *                       previous image; prepared == 0 (first step / p changed elsewhere) first
  *                       builds s (s_buf), its partials (row set `parity`) and the canvas.
