@@ -74,6 +74,8 @@ SIGNATURES = {
     "advx_collect": (_I32, [_P, _P, _I32, _P, _I32, _P, _I64, _P]),
     "advx_emit_multi": (_I32, [_I32, _P, _P, _P, _P, _P, _I32, _U64, _P, _P, _P, _P, _I32, _P]),
     "advx_collect_multi": (_I32, [_I32, _P, _P, _P, _P, _I32, _P, _P, _P]),
+    "advx_forward_multi": (_I32, [_P, _P, _I32, _I32, _F, _I32, _F, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _I32, _U64, _P, _P, _P,
+                                  _P, _I32, _P]),
     "advx_image_scratch_floats": (_I64, [_I32, _I32, _I32]),
     "advx_image_fwd": (_I32, [_P, _P, _I32, _I32, _F, _I32, _F, _P, _P, _P, _P, _P, _P]),
     "advx_image_bwd": (_I32, [_P, _P, _P, _I32, _I32, _F, _I32, _F, _P, _F, _P, _I32, _P, _P]),

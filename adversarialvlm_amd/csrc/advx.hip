@@ -720,10 +720,19 @@ static int32_t check_multi(int32_t n, advx_plan* const* plans, const int32_t* ba
   return ADVX_OK;
 }
 
-extern "C" int32_t advx_emit_multi(int32_t n, advx_plan* const* plans, const float* argument, const int32_t* batches,
-                                   const float* sigma_dev, const float* const* unit_noises, int32_t use_philox, uint64_t seed,
-                                   const uint64_t* offsets, void* const* outs, float* const* wss, const int64_t* ws_floats,
-                                   int32_t pad_mode, void* stream) {
+namespace {
+struct PendingImageStats {   // statistics partials an advx_image_fwd left for the next launch to reduce
+  const double* partials = nullptr;
+  int nblk = 0;
+  long long n_img = 0;
+  float* stats = nullptr;
+};
+}  // namespace
+
+static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* argument, const int32_t* batches,
+                               const float* sigma_dev, const float* const* unit_noises, int32_t use_philox, uint64_t seed,
+                               const uint64_t* offsets, void* const* outs, float* const* wss, const int64_t* ws_floats,
+                               int32_t pad_mode, const PendingImageStats& pend, void* stream) {
   int32_t rc = check_multi(n, plans, batches, wss, ws_floats, "advx_emit_multi");
   if (rc) return rc;
   REQUIRE(argument && outs && offsets, ADVX_E_BADARG, "advx_emit_multi: null argument");
@@ -748,7 +757,7 @@ extern "C" int32_t advx_emit_multi(int32_t n, advx_plan* const* plans, const flo
   }
   const DStage& D0 = plans[0]->dstage[0];
   hipLaunchKernelGGL(k_stage0_fwd_multi, dim3(grid_for(biggest), n), dim3(kBlock), 0, st, mf, argument,
-                     (long long)D0.src_h * D0.src_w, D0.src_w);
+                     (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats);
   LAUNCH_CHECK();
   for (int i = 0; i < n; ++i) {
     advx_plan* p = plans[i];
@@ -784,6 +793,14 @@ extern "C" int32_t advx_emit_multi(int32_t n, advx_plan* const* plans, const flo
     LAUNCH_CHECK();
   }
   return ADVX_OK;
+}
+
+extern "C" int32_t advx_emit_multi(int32_t n, advx_plan* const* plans, const float* argument, const int32_t* batches,
+                                   const float* sigma_dev, const float* const* unit_noises, int32_t use_philox, uint64_t seed,
+                                   const uint64_t* offsets, void* const* outs, float* const* wss, const int64_t* ws_floats,
+                                   int32_t pad_mode, void* stream) {
+  return emit_multi_impl(n, plans, argument, batches, sigma_dev, unit_noises, use_philox, seed, offsets, outs, wss, ws_floats,
+                         pad_mode, PendingImageStats(), stream);
 }
 
 extern "C" int32_t advx_collect_multi(int32_t n, advx_plan* const* plans, const void* const* grad_outs, const int32_t* batches,
@@ -944,9 +961,11 @@ static int32_t check_blur(int H, int W, int k, float sigma) {
   return ADVX_OK;
 }
 
-extern "C" int32_t advx_image_fwd(const float* p, const float* x0, int32_t H, int32_t W, float eps, int32_t blur_k,
-                                  float blur_sigma, const int32_t* crop, float* s, float* argument, float* stats,
-                                  float* scratch, void* stream) {
+// `defer`: without a crop window, leave the one-block reduction of the statistics to the caller's next
+// launch and describe it in *defer (with a crop it rides in the window's resize anyway)
+static int32_t image_fwd_impl(const float* p, const float* x0, int32_t H, int32_t W, float eps, int32_t blur_k,
+                              float blur_sigma, const int32_t* crop, float* s, float* argument, float* stats,
+                              float* scratch, PendingImageStats* defer, void* stream) {
   REQUIRE(p && x0 && s && stats && scratch, ADVX_E_BADARG, "advx_image_fwd: null argument");
   REQUIRE(H > 0 && W > 0 && H <= 16384 && W <= 16384, ADVX_E_SHAPE, "advx_image_fwd: bad image size");
   REQUIRE(!crop || argument, ADVX_E_BADARG, "advx_image_fwd: crop needs an argument buffer");
@@ -1003,12 +1022,49 @@ extern "C" int32_t advx_image_fwd(const float* p, const float* x0, int32_t H, in
     LAUNCH_CHECK();
     return ADVX_OK;
   }
-  hipLaunchKernelGGL(k_finalize_image, dim3(1), dim3(kBlock), 0, st, partials, nblk, n, stats);
-  LAUNCH_CHECK();
+  if (defer) {
+    defer->partials = partials;
+    defer->nblk = nblk;
+    defer->n_img = n;
+    defer->stats = stats;
+  } else {
+    hipLaunchKernelGGL(k_finalize_image, dim3(1), dim3(kBlock), 0, st, partials, nblk, n, stats);
+    LAUNCH_CHECK();
+  }
   if (argument && argument != s) {
     HIP_TRY(hipMemcpyAsync(argument, s, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
   }
   return ADVX_OK;
+}
+
+extern "C" int32_t advx_image_fwd(const float* p, const float* x0, int32_t H, int32_t W, float eps, int32_t blur_k,
+                                  float blur_sigma, const int32_t* crop, float* s, float* argument, float* stats,
+                                  float* scratch, void* stream) {
+  return image_fwd_impl(p, x0, H, W, eps, blur_k, blur_sigma, crop, s, argument, stats, scratch, nullptr, stream);
+}
+
+// advx_image_fwd followed by advx_emit_multi in one call: same tensors, and without a crop window the
+// statistics of the image are reduced by block (0,0) of the plans' resize launch instead of a launch
+// of their own.  The noise sigma the emits read is stats[ADVX_STAT_SIGMA] (rotated by that reduction).
+extern "C" int32_t advx_forward_multi(const float* p, const float* x0, int32_t H, int32_t W, float eps, int32_t blur_k,
+                                      float blur_sigma, const int32_t* crop, float* s, float* argument, float* stats,
+                                      float* image_scratch, int32_t n, advx_plan* const* plans, const int32_t* batches,
+                                      const float* const* unit_noises, int32_t use_philox, uint64_t seed,
+                                      const uint64_t* offsets, void* const* outs, float* const* wss,
+                                      const int64_t* ws_floats, int32_t pad_mode, void* stream) {
+  PendingImageStats pend;
+  int32_t rc = image_fwd_impl(p, x0, H, W, eps, blur_k, blur_sigma, crop, s, argument, stats, image_scratch,
+                              crop ? nullptr : &pend, stream);
+  if (rc) return rc;
+  const float* arg = (crop || (argument && argument != s)) ? argument : s;
+  rc = emit_multi_impl(n, plans, arg, batches, stats + ADVX_STAT_SIGMA, unit_noises, use_philox, seed, offsets, outs, wss,
+                       ws_floats, pad_mode, pend, stream);
+  if (rc && pend.nblk > 0) {
+    // the emit was refused after the image kernels ran: do not leave the statistics unreduced
+    hipLaunchKernelGGL(k_finalize_image, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, pend.partials, pend.nblk, pend.n_img,
+                       pend.stats);
+  }
+  return rc;
 }
 
 extern "C" int32_t advx_image_bwd(const float* p, const float* s, const float* garg, int32_t H, int32_t W, float eps,

@@ -549,7 +549,11 @@ struct MultiBwd {
 };
 
 __global__ void __launch_bounds__(kBlock) k_stage0_fwd_multi(MultiFwd mf, const float* __restrict__ src, long long src_cstride,
-                                                             int src_rstride) {
+                                                             int src_rstride, const double* __restrict__ img_partials, int nblk,
+                                                             long long n_img, float* __restrict__ stats) {
+  // nblk > 0: the image kernels of the same call left statistics partials; block (0,0) reduces them
+  // here (k_emit, the consumer of sigma, is a later launch)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && nblk > 0) finalize_image_block<true>(img_partials, nblk, n_img, stats);
   const int k = blockIdx.y;
   const DStage& st = mf.st[k];
   const long long n = 3LL * st.can_h * st.can_w;

@@ -127,6 +127,40 @@ def emit_multi(plans, argument, batches, sigma_dev=None, unit_noises=None, philo
     return outs
 
 
+def forward_multi(p, x0, epsilon, stats, image_scratch, plans, batches, s, argument=None, blur=None, crop=None,
+                  unit_noises=None, philox=None, workspaces=None, outs=None, keep_padding=False):
+    """image_fwd + emit_multi in one call (advx_forward_multi).  -> (list of pixel_values, argument)."""
+    _require_cuda(p, x0, stats, image_scratch, s)
+    dev = p.device
+    _, H, W = p.shape
+    n = len(plans)
+    if crop is not None and argument is None:
+        argument = torch.empty_like(p)
+    k, sig = (blur if blur is not None else (0, 0.0))
+    keep, cptr = _crop_arg(crop)
+    if workspaces is None:
+        workspaces = [torch.empty(pl.workspace_floats, dtype=torch.float32, device=dev) for pl in plans]
+    outs = [None] * n if outs is None else list(outs)
+    for i, (pl, B) in enumerate(zip(plans, batches)):
+        if keep_padding and (outs[i] is None or outs[i].numel() != B * pl.out_numel):
+            raise L.AdvxError("keep_padding needs the caller's persistent [batch, out_numel] buffers")
+        outs[i] = (torch.empty((B, pl.out_numel), dtype=_plan_dtype(pl), device=dev) if outs[i] is None
+                   else _boundary(pl, outs[i], "out"))
+    zs = [None] * n if unit_noises is None else [None if z is None else _f32c(z) for z in unit_noises]
+    for z, pl, B in zip(zs, plans, batches):
+        if z is not None and z.numel() != B * pl.out_numel:
+            raise L.AdvxError("unit_noise has the wrong number of elements")
+    seed, offsets = (philox if philox is not None else (0, [0] * n))
+    L.check(L.load().advx_forward_multi(L.ptr(p), L.ptr(x0), H, W, float(epsilon), int(k), float(sig), cptr, L.ptr(s),
+                                        L.ptr(argument) if argument is not None else None, L.ptr(stats), L.ptr(image_scratch),
+                                        n, (C.c_void_p * n)(*[pl.handle.value for pl in plans]),
+                                        (C.c_int32 * n)(*[int(b) for b in batches]), _ptr_array(zs), int(philox is not None),
+                                        int(seed), (C.c_uint64 * n)(*[int(o) for o in offsets]), _ptr_array(outs),
+                                        _ptr_array(workspaces), (C.c_int64 * n)(*[int(w.numel()) for w in workspaces]),
+                                        1 if keep_padding else 0, _stream(p)), "advx_forward_multi")
+    return outs, (argument if argument is not None else s)
+
+
 def collect_multi(plans, grad_outs, batches, grad_argument=None, accumulate=False, workspaces=None):
     """Backward of `emit_multi`: the sum over plans of each plan's image gradient, in plan order."""
     n = len(plans)

@@ -272,39 +272,25 @@ class PixelPGD:
             self._last = dict(batches=list(batches))
             return outs
         blur = (self.blur_kernel, blur_sigma) if self.blur_kernel is not None else None
-        _, arg = ops.image_fwd(self.p, self.x0, self.eps, self.stats, self.img_scratch, blur=blur, crop=crop,
-                               s=self.s, argument=self.argument if crop is not None else None)
-        sigma = self.stats[L.STAT_SIGMA:L.STAT_SIGMA + 1]
-        if len(self.plans) > 1:
-            # cross-model: the plans' image resizes in one launch (advx_emit_multi), then one emit each
-            n = len(self.plans)
-            given = any(z is not None for z in unit_noises)
-            if given and not all(z is not None for z in unit_noises):
-                raise L.AdvxError("unit_noises: give the noise of every plan or of none")
-            keep = (not self.noise_on_padding) and not given
-            bufs = None
-            if keep:
-                for i, (pl, B) in enumerate(zip(self.plans, batches)):
-                    if self._outs[i] is None or self._outs[i].shape[0] != B:
-                        self._outs[i] = torch.zeros((B, pl.out_numel), dtype=ops._plan_dtype(pl), device=self.p.device)
-                bufs = self._outs
-            ph = None if (given or not use_philox) else (self.seed, [self.iteration * n + i for i in range(n)])
-            res = ops.emit_multi(self.plans, arg, batches, sigma_dev=sigma, unit_noises=unit_noises if given else None,
-                                 philox=ph, workspaces=self.workspaces, outs=bufs, keep_padding=keep)
-            outs = [o.view((B * pl.out_shape[0],) + pl.out_shape[1:]) for o, pl, B in zip(res, self.plans, batches)]
-            self._last = dict(batches=list(batches), blur=blur, crop=crop)
-            return outs
-        for i, (pl, B, z) in enumerate(zip(self.plans, batches, unit_noises)):
-            ph = None if (z is not None or not use_philox) else (self.seed, self.iteration * len(self.plans) + i)
-            keep = (not self.noise_on_padding) and z is None
-            buf = None
-            if keep:
+        # one call: image kernels, the plans' resizes (one launch for all plans that read the image) and one
+        # emit per plan; the statistics are reduced inside that chain, sigma is read from the device
+        n = len(self.plans)
+        given = any(z is not None for z in unit_noises)
+        if given and not all(z is not None for z in unit_noises):
+            raise L.AdvxError("unit_noises: give the noise of every plan or of none")
+        keep = (not self.noise_on_padding) and not given
+        bufs = None
+        if keep:
+            for i, (pl, B) in enumerate(zip(self.plans, batches)):
                 if self._outs[i] is None or self._outs[i].shape[0] != B:
                     self._outs[i] = torch.zeros((B, pl.out_numel), dtype=ops._plan_dtype(pl), device=self.p.device)
-                buf = self._outs[i]
-            out = ops.emit(pl, arg, B, sigma_dev=sigma, unit_noise=z, philox=ph, workspace=self.workspaces[i], out=buf,
-                           keep_padding=keep)
-            outs.append(out.view((B * pl.out_shape[0],) + pl.out_shape[1:]))
+            bufs = self._outs
+        ph = None if (given or not use_philox) else (self.seed, [self.iteration * n + i for i in range(n)])
+        res, _ = ops.forward_multi(self.p, self.x0, self.eps, self.stats, self.img_scratch, self.plans, batches, self.s,
+                                   argument=self.argument if crop is not None else None, blur=blur, crop=crop,
+                                   unit_noises=unit_noises if given else None, philox=ph, workspaces=self.workspaces,
+                                   outs=bufs, keep_padding=keep)
+        outs = [o.view((B * pl.out_shape[0],) + pl.out_shape[1:]) for o, pl, B in zip(res, self.plans, batches)]
         self._last = dict(batches=list(batches), blur=blur, crop=crop)
         return outs
 

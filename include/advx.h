@@ -195,6 +195,18 @@ int32_t advx_collect_multi(int32_t n, advx_plan* const* plans, const void* const
                            const int32_t* batches, float* grad_argument, int32_t accumulate,
                            float* const* workspaces, const int64_t* workspace_floats, void* stream);
 
+/* advx_image_fwd followed by advx_emit_multi in one call (the forward half of a step of either trainer
+ * whenever the fused / prepared chains do not apply): same tensors; without a crop window the
+ * statistics of the image are reduced by one block of the plans' resize launch instead of a launch of
+ * their own.  The emits read their sigma from stats[ADVX_STAT_SIGMA].  Arguments as for the two calls. */
+int32_t advx_forward_multi(const float* p, const float* x0, int32_t H, int32_t W, float epsilon,
+                           int32_t blur_kernel, float blur_sigma, const int32_t* crop_ijhw, float* s,
+                           float* argument, float* stats, float* image_scratch, int32_t n,
+                           advx_plan* const* plans, const int32_t* batches, const float* const* unit_noises,
+                           int32_t use_philox, uint64_t seed, const uint64_t* offsets, void* const* outs,
+                           float* const* workspaces, const int64_t* workspace_floats, int32_t pad_mode,
+                           void* stream);
+
 /* ---------------------------------------------------- image level (trainer)
  * advx_image_fwd : attack_model.py:300-312,329,366-373,386-391
  *     x = eps*tanh(p) ; optional Gaussian blur (kernel k, sigma) ; s = x0 + x ;

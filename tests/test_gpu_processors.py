@@ -350,3 +350,40 @@ def test_batch_of_one_and_large_batch(dev):
     assert torch.equal(many, one.expand(130, -1))
     g = torch.randn(130, plan.out_numel, device=dev)
     assert rel_err(ops.collect(plan, g, 130).cpu(), ops.collect(plan, g.double().sum(0, keepdim=True).float(), 1).cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("blur,crop", [(None, None), ((5, 1.3), None), (None, (4, 7, 40, 61)), ((9, 0.7), (4, 7, 40, 61))])
+def test_forward_multi_is_image_fwd_then_emit_multi(dev, blur, crop):
+    """advx_forward_multi against advx_image_fwd + advx_emit_multi: same pixel_values, image, argument and
+    statistics (the reduction of the statistics rides in the plans' resize launch), one and three plans."""
+    from adversarialvlm_amd import _lib as L
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan
+    H, W = 60, 90
+    gen = torch.Generator().manual_seed(31)
+    x0 = torch.rand(3, H, W, generator=gen).to(dev)
+    p = (torch.randn(3, H, W, generator=gen) * 0.4).to(dev)
+    for n in (1, 3):
+        mk = lambda: [Plan.phi3(H, W), Plan.qwen2vl(H, W, min_pixels=28 * 28 * 4, max_pixels=28 * 28 * 64),
+                      Plan.mllama(H, W, tile=32)][:n]
+        batches = [2, 3, 1][:n]
+        runs = []
+        for one_call in (False, True):
+            plans = mk()
+            stats = torch.zeros(L.STATS_N, device=dev)
+            stats[L.STAT_QERR_STD] = 0.02
+            scr = ops.image_scratch(H, W, blur[0] if blur else 0, dev)
+            ws = [torch.empty(pl.workspace_floats, device=dev) for pl in plans]
+            s = torch.empty_like(x0)
+            arg_buf = torch.empty_like(x0) if crop is not None else None
+            if one_call:
+                outs, arg = ops.forward_multi(p, x0, 0.5, stats, scr, plans, batches, s, argument=arg_buf, blur=blur, crop=crop,
+                                              philox=(9, [70, 71, 72][:n]), workspaces=ws)
+            else:
+                _, arg = ops.image_fwd(p, x0, 0.5, stats, scr, blur=blur, crop=crop, s=s, argument=arg_buf)
+                outs = ops.emit_multi(plans, arg, batches, sigma_dev=stats[L.STAT_SIGMA:L.STAT_SIGMA + 1],
+                                      philox=(9, [70, 71, 72][:n]), workspaces=ws)
+            runs.append([o.clone() for o in outs] + [s.clone(), arg.clone(), stats.clone()])
+        for a, b in zip(*runs):
+            assert torch.equal(a, b)
+        assert float(runs[0][-1][L.STAT_SIGMA]) == pytest.approx(0.02)     # rotated from the previous QERR_STD
