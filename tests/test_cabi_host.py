@@ -209,3 +209,41 @@ def test_header_is_plain_c():
     res = subprocess.run(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror",
                           os.path.join(ROOT, "include", "advx.h")], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
+
+
+def test_multi_plan_entry_points_validate_before_any_device_work(lib):
+    """Argument checks of advx_emit_multi / advx_collect_multi / advx_forward_multi / advx_image_bwd_update /
+    advx_update_flush come before the first HIP call: they can be exercised without a GPU and must
+    return ADVX_E_* with a message, never crash."""
+    import ctypes as C
+    from adversarialvlm_amd import _lib as L
+    from adversarialvlm_amd.plan import Plan
+    a, b, other = Plan.llava(40, 52, 32, 32), Plan.mllama(40, 52, tile=16), Plan.llava(41, 52, 32, 32)
+    E_BADARG, E_SHAPE = -1, -2                                 # ADVX_E_BADARG, ADVX_E_SHAPE (include/advx.h)
+    fake = lambda k: C.c_void_p(0x1000 * (k + 1))              # never dereferenced: checks fail first
+    arr_p = lambda *v: (C.c_void_p * len(v))(*v)
+    plans2 = arr_p(a.handle.value, b.handle.value)
+    b2, w2 = (C.c_int32 * 2)(1, 1), (C.c_int64 * 2)(a.workspace_floats, b.workspace_floats)
+    offs = (C.c_uint64 * 2)(0, 0)
+    two_ws, same_ws = arr_p(0x1000, 0x2000), arr_p(0x1000, 0x1000)
+
+    def emit(n, plans, batches, wss, wsf):
+        return lib.advx_emit_multi(n, plans, fake(7), batches, None, None, 0, 0, offs, arr_p(0x3000, 0x4000), wss, wsf, 0, None)
+
+    assert emit(0, plans2, b2, two_ws, w2) == E_BADARG and b"between 1 and 4" in lib.advx_last_error()
+    assert emit(5, plans2, b2, two_ws, w2) == E_BADARG
+    assert emit(2, plans2, b2, same_ws, w2) == E_BADARG and b"own workspace" in lib.advx_last_error()
+    assert emit(2, plans2, (C.c_int32 * 2)(1, 0), two_ws, w2) == E_BADARG
+    assert emit(2, plans2, b2, two_ws, (C.c_int64 * 2)(a.workspace_floats, 1)) == E_SHAPE
+    assert emit(2, arr_p(a.handle.value, other.handle.value), b2, two_ws, w2) == E_SHAPE
+    assert b"same image" in lib.advx_last_error()
+    assert lib.advx_collect_multi(2, plans2, None, b2, fake(1), 0, two_ws, w2, None) == E_BADARG
+    assert lib.advx_collect_multi(2, plans2, arr_p(0x5000, 0x6000), b2, None, 0, two_ws, w2, None) == E_BADARG
+    assert lib.advx_forward_multi(None, fake(1), 40, 52, 0.5, 0, 0.0, None, fake(2), None, fake(3), fake(4), 2, plans2, b2, None,
+                                  0, 0, offs, arr_p(0x3000, 0x4000), two_ws, w2, 0, None) == E_BADARG
+    opt = L.OptScalars()
+    assert lib.advx_image_bwd_update(fake(1), fake(2), fake(3), 40, 52, 0.5, 0, 0.0, None, 1.0, fake(4), 0, None, fake(5),
+                                     fake(6), C.byref(opt), fake(7), fake(8), fake(9), 1, None) == E_BADARG
+    assert lib.advx_image_bwd_update(fake(1), fake(2), fake(3), 0, 52, 0.5, 0, 0.0, None, 1.0, fake(4), 0, fake(5), fake(5),
+                                     fake(6), C.byref(opt), fake(7), fake(8), fake(9), 1, None) == E_SHAPE
+    assert lib.advx_update_flush(0, fake(1), fake(2), None) == E_BADARG
