@@ -93,3 +93,36 @@ def test_suffix_ce_against_the_reference_method(k):
     assert float(loss.detach()) == pytest.approx(float(g[f"ce{k}_loss"]), rel=1e-6)
     assert float((kept.grad.cpu() - ref_grad[:, -K:, :]).abs().max()) < 1e-7
     assert not bool(ref_grad[:, :-K, :].any())
+
+
+def test_suffix_ce_random_shapes():
+    """Random shapes: vocabulary sizes that are not multiples of the vector width, one supervised
+    position, rows of large logits (stable log-sum-exp), ignored targets, kept positions beyond T."""
+    from adversarialvlm_amd.ce import suffix_cross_entropy
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(40)
+    for case in range(30):
+        B, V = int(rng.integers(1, 6)), int(rng.choice([3, 17, 255, 1001, 4099, 32003]))
+        T = int(rng.integers(1, 8))
+        K = T + int(rng.integers(0, 3))
+        dtype = [torch.float32, torch.float16, torch.bfloat16][case % 3]
+        gen = torch.Generator().manual_seed(1000 + case)
+        scale = float(rng.choice([0.5, 3.0, 30.0]))
+        base = (torch.randn(B, K, V, generator=gen) * scale).to(dtype)
+        targets = torch.randint(0, V, (B, T), generator=gen)
+        if B * T > 1 and case % 4 == 0:
+            targets.view(-1)[int(rng.integers(0, B * T))] = -100
+        ref_in = base.double().clone().requires_grad_(True)
+        ref = F.cross_entropy(ref_in[:, :T, :].permute(0, 2, 1), targets, ignore_index=-100)
+        ref.backward()
+        x = base.to(dev).clone().requires_grad_(True)
+        loss = suffix_cross_entropy(x, targets.to(dev))
+        loss.backward()
+        assert float(loss.detach()) == pytest.approx(float(ref.detach()), rel=2e-6, abs=1e-6), (case, B, K, T, V, dtype, scale)
+        # p = exp(x - lse) in fp32: the absolute rounding of x - lse (half an ulp of the largest logit, twice)
+        # is the relative error of p, on top of the output rounding of the dtype
+        tol = {torch.float32: 4e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype] + 2.5e-7 * float(base.float().abs().max())
+        got, want = x.grad.double().cpu(), ref_in.grad
+        floor = 2e-7 * float(want.abs().max()) + (6.1e-8 if dtype == torch.float16 else 0.0)
+        bad = (got - want).abs() > tol * want.abs() + floor
+        assert not bool(bad.any()), (case, B, K, T, V, dtype, scale, float(((got - want).abs() / (want.abs() + floor))[bad].max()))
