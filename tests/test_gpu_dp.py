@@ -199,3 +199,66 @@ def test_peer_barrier_gives_up_instead_of_hanging():
     mp.spawn(_peer_lost, args=(2, _free_port(), out), nprocs=2, join=True)
     lost, seconds = out["rank0"]
     assert lost and seconds < 5.0
+
+
+def _cross_setup():
+    """Two processors over one 60x90 image, blur and a crop window per step, three steps, 4 + 6 prompts."""
+    from adversarialvlm_amd.plan import Plan
+    gen = torch.Generator().manual_seed(3)
+    H, W = 60, 90
+    x0 = torch.rand(3, H, W, generator=gen)
+    mk = lambda: [Plan.mllama(H, W, tile=32), Plan.llava(H, W, 48, 48)]
+    batches = [4, 6]
+    plans = mk()
+    shapes = [(B * pl.out_shape[0],) + pl.out_shape[1:] for pl, B in zip(plans, batches)]
+    zs = [[torch.randn(s, generator=gen) for s in shapes] for _ in range(3)]
+    gs = [[torch.randn(s, generator=gen) * 0.01 for s in shapes] for _ in range(3)]
+    crops = [(3, 5, 50, 70), (0, 0, 60, 90), (10, 20, 40, 60)]
+    sig = [0.7, 1.4, 0.3]
+    kw = dict(lr=1e-2, blur_kernel=5, use_crop=True, cross_mode=True, model_weights=[0.6, 1.3])
+    return x0, mk, batches, plans, zs, gs, crops, sig, kw
+
+
+def _cross_rank(rank, world, port, out, transport):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("gloo")
+    from adversarialvlm_amd.pgd import PixelPGD
+    dev = torch.device("cuda:0")
+    x0, mk, batches, plans, zs, gs, crops, sig, kw = _cross_setup()
+    eng = PixelPGD(x0.to(dev), mk(), process_group=torch.distributed.group.WORLD, exchange_transport=transport, **kw)
+    assert eng.world == world and eng.mode == "generic" and (eng.peer is not None) == (transport == "peer")
+    local = [B // world for B in batches]
+    rows = [pl.out_shape[0] for pl in plans]
+    for t in range(3):
+        cut = [slice(rank * b * r, (rank + 1) * b * r) for b, r in zip(local, rows)]
+        eng.forward(local, [z[c].to(dev) for z, c in zip(zs[t], cut)], blur_sigma=sig[t], crop=crops[t])
+        # mean-type loss over the LOCAL prompts of every model, then the engine's weights and DP pre-scale
+        eng.backward_update([g[c].to(dev) / b * eng.loss_scale(i) for i, (g, c, b) in enumerate(zip(gs[t], cut, local))])
+    st = eng.stats_dict()
+    out[rank] = (eng.p.cpu(), st["grad_norm"], st["sigma_next"])
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("transport", ["rccl", "peer"])
+def test_two_ranks_cross_model_blur_crop(transport):
+    """Data parallelism under the multi-plan calls (advx_forward_multi / advx_collect_multi), blur and a crop
+    window: two ranks, half of every model's prompts each, against one process with all of them."""
+    from adversarialvlm_amd.pgd import PixelPGD
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_cross_rank, args=(2, _free_port(), out, transport), nprocs=2, join=True)
+    (p0, n0, s0), (p1, n1, s1) = out[0], out[1]
+    assert torch.equal(p0, p1) and n0 == n1 and s0 == s1        # replicas bit-identical
+    dev = torch.device("cuda:0")
+    x0, mk, batches, plans, zs, gs, crops, sig, kw = _cross_setup()
+    ref = PixelPGD(x0.to(dev), mk(), **kw)
+    for t in range(3):
+        ref.forward(batches, [z.to(dev) for z in zs[t]], blur_sigma=sig[t], crop=crops[t])
+        ref.backward_update([g.to(dev) / b * ref.loss_scale(i) for i, (g, b) in enumerate(zip(gs[t], batches))])
+    rst = ref.stats_dict()
+    err = float((p0 - ref.p.cpu()).norm() / ref.p.cpu().norm())
+    assert err < 1e-5, err
+    assert n0 == pytest.approx(rst["grad_norm"], rel=1e-5) and s0 == pytest.approx(rst["sigma_next"], rel=1e-6)
