@@ -15,8 +15,17 @@ shared image gradient (1.355 MB) is all-reduced once per step over RCCL.
 
 `value` = prompts * steps / s over all ranks.  The VLM forward/backward (PyTorch-ROCm,
 ~1e15 FLOP per 64-prompt step) is NOT inside this number - see DESIGN.md "Measurement".
+
+Cache state.  The two B*P_out tensors of a step (86.7 MB each) fit the 256 MiB Infinity Cache, and a loop
+that reuses ONE gradient tensor and ONE output block never leaves it; in the real loop a 7B VLM runs between
+the two launches.  The timed region therefore ROTATES through `--ring` (default 8) distinct gradient tensors
+and output blocks (1.39 GB, 5x the cache): every byte of both streams comes from / goes to DRAM
+("cold", the headline `value` and `roofline.frac`).  The same K steps on one resident pair are timed right
+after it and reported as `in_cache` (`roofline.frac_in_cache`).  `--scaling strong` keeps the GLOBAL batch at
+64 prompts (64/N per rank, SURVEY 8(e) form A) instead of 64 per rank.
 """
 import argparse
+import collections
 import json
 import os
 import sys
@@ -33,11 +42,30 @@ BATCH = 64
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def host_cores():
+    """Cores this process may run on: the affinity mask, capped by a cgroup CPU quota if one is set
+    (threads beyond the quota only add context switches).  -> (usable, os.cpu_count())."""
+    total = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = total
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            usable = max(1, min(usable, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return usable, total
+
+
 def cpu_baseline(seconds_budget=15.0):
-    """The oracle (torch-CPU restatement of the reference's step, 'port') on host cores."""
+    """The oracle (torch-CPU restatement of the reference's step, 'port') on ALL host cores this process
+    may use; `cores` = the threads actually used."""
     from oracle.pgd import PGDOracle
     from oracle.processors import LlavaOracle
-    threads = max(1, min(os.cpu_count() or 1, 16))
+    threads, machine = host_cores()
     torch.set_num_threads(threads)
     gen = torch.Generator().manual_seed(0)
     x0 = torch.rand(3, H, W, generator=gen)
@@ -58,7 +86,7 @@ def cpu_baseline(seconds_budget=15.0):
         dt = time.perf_counter() - t0
         if dt > seconds_budget or n >= 200:
             break
-    return dict(value=round(n * BATCH / dt, 2), unit="prompt-steps/s", cores=threads, kind="port",
+    return dict(value=round(n * BATCH / dt, 2), unit="prompt-steps/s", cores=threads, host_cpu_count=machine, kind="port",
                 sample=f"{n} steps of the same workload (336x336x3, B=64), {dt:.1f} s", steps_per_s=round(n / dt, 3))
 
 
@@ -96,6 +124,12 @@ def main():
     ap.add_argument("--io", default="f32", choices=["f32", "f16", "bf16"],
                     help="dtype of pixel_values / their gradient at the VLM boundary (f32 = the reference's own "
                          "boundary and the headline; f16/bf16 = emit in the model's dtype, pair chain only)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak = 64 prompts per GPU (default); strong = 64 prompts in total, 64/N per GPU")
+    ap.add_argument("--cache", default="both", choices=["both", "cold", "hot"],
+                    help="cold = rotate through --ring gradient / output buffers (beyond the Infinity Cache; the headline), "
+                         "hot = one resident pair (the round-1 loop), both = cold timed first, hot reported as in_cache")
+    ap.add_argument("--ring", type=int, default=8, help="distinct gradient tensors / output blocks of the cold loop")
     args = ap.parse_args()
     io_dtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.io]
     io_bytes = 4 if args.io == "f32" else 2
@@ -134,9 +168,15 @@ def main():
     from adversarialvlm_amd.pgd import PixelPGD
     from adversarialvlm_amd.plan import Plan
 
+    if args.scaling == "strong":
+        if BATCH % world:
+            raise SystemExit(f"--scaling strong: {BATCH} prompts do not divide over {world} ranks")
+        B = BATCH // world
+    else:
+        B = BATCH
+    ring = max(1, args.ring) if args.cache != "hot" else 1
     gen = torch.Generator().manual_seed(0)
     x0 = torch.rand(3, H, W, generator=gen).to(dev)
-    g = torch.randn(BATCH, 3, H, W, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     plan = Plan.llava(H, W)
     eng = PixelPGD(x0, [plan], epsilon=0.5, lr=1e-2, sigma0=1e-3, seed=1234 + rank, process_group=pg,
                    allow_fused=not args.no_fused, fused_mode=args.chain, force_exchange=args.force_exchange, io_dtype=io_dtype,
@@ -148,37 +188,62 @@ def main():
         timing = getattr(eng.peer, "peer_vs_host_seconds", None)
         if timing is not None:
             exchange += f"; at start-up peer {timing[0] * 1e6:.1f} us vs {args.backend} {timing[1] * 1e6:.1f} us per all-reduce"
-    # every rank pre-scales its share so that the SUM all-reduce is the DP average
-    gs = (g * eng.loss_scale(0)).to(io_dtype)
+    # the synthetic upstream gradients: `ring` distinct tensors, every rank its own; each rank pre-scales its share
+    # so that the SUM all-reduce is the DP average
+    dgen = torch.Generator(device=dev).manual_seed(1 + rank)
+    gs_ring = [(torch.randn(B, 3, H, W, generator=dgen, device=dev) * eng.loss_scale(0)).to(io_dtype) for _ in range(ring)]
+    ring_bytes = (2 * ring + 1) * B * 3 * H * W * io_bytes      # `ring` gradient tensors + `ring`+1 output blocks
 
-    def step():
-        eng.forward(BATCH)
-        eng.backward_update([gs])
+    held = collections.deque(maxlen=ring)        # keeps the last `ring` output blocks allocated
+    counter = [0]
+
+    def step_cold():
+        # the allocator can only hand out a block whose last use lies `ring` steps back
+        held.append(eng.forward(B)[0])
+        eng.backward_update([gs_ring[counter[0] % ring]])
+        counter[0] += 1
+
+    def step_hot():
+        eng.forward(B)
+        eng.backward_update([gs_ring[0]])
 
     def fence():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
     from adversarialvlm_amd import ops
-    fence()
-    # per-kernel device time: every launch of the B*P_out movers inside the timed region carries
-    # its own start/stop HIP event pair on the launch stream (advx_profile_*, hipExtLaunchKernelGGL)
-    ops.profile_begin(max(args.steps, 1), stride=16)      # every 16th launch: the loop stays unperturbed
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    prof = ops.profile_end()
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    fwd_avg, bwd_avg, step_avg = prof["fwd"][0], prof["bwd"][0], prof["step"][0]
-    # after the timed region: the replicas of p must still hold the same bits on every rank, and no
+
+    def timed(step):
+        """W warm-up steps, then exactly K steps between two fences; MAX over ranks.  Every stride-th launch of the
+        B*P_out movers carries its own start/stop HIP event pair on the launch stream (advx_profile_*,
+        hipExtLaunchKernelGGL); the stride is chosen so that at least 16 (up to 64) launches per kernel are
+        timed whatever K is."""
+        for _ in range(args.warmup):
+            step()
+        fence()
+        ops.profile_begin(max(args.steps, 1), stride=max(1, args.steps // 64))
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        prof = ops.profile_end()
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, prof
+
+    runs = {}
+    if args.cache in ("both", "cold"):
+        runs["cold"] = timed(step_cold)
+    held.clear()
+    if args.cache in ("both", "hot"):
+        runs["hot"] = timed(step_hot)
+    main_key = "cold" if "cold" in runs else "hot"
+    dt, prof = runs[main_key]
+    # after the timed regions: the replicas of p must still hold the same bits on every rank, and no
     # barrier of the peer exchange may have timed out
     replicas_identical = None
     if world > 1:
@@ -190,51 +255,88 @@ def main():
     exchange_timed_out = bool(eng.peer.timed_out()) if eng.peer is not None else None
 
     n_in = 3 * H * W
-    bytes_fwd = io_bytes * BATCH * n_in + 4 * 2 * n_in     # write B*P_out, read p,x0
-    bytes_bwd = io_bytes * BATCH * n_in + 4 * 8 * n_in     # read B*P_out; p,x0,mask,m,v in; p,m,v(+grad) out
-    bytes_step = bytes_fwd + bytes_bwd                     # 4*(2*B*P_out + 10*P_in) at f32
-    steps_per_s = args.steps / dt
-    if eng.mode == "step":
-        # one launch per step: backward of step t + forward of step t+1 in the same kernel
-        dom_name, dom_bytes, dom_ms = "k_fused_step_wave", bytes_step, step_avg
-    elif eng.mode == "pair":
-        dom_name, dom_bytes, dom_ms = (("k_fused_fwd", bytes_fwd, fwd_avg) if fwd_avg >= bwd_avg
-                                       else ("k_fused_bwd", bytes_bwd, bwd_avg))
-    else:
+    bytes_fwd = io_bytes * B * n_in + 4 * 2 * n_in     # write B*P_out, read p,x0
+    bytes_bwd = io_bytes * B * n_in + 4 * 8 * n_in     # read B*P_out; p,x0,mask,m,v in; p,m,v(+grad) out
+    bytes_step = bytes_fwd + bytes_bwd                 # 4*(2*B*P_out + 10*P_in) at f32
+
+    def dominant(run):
+        dt_, prof_ = run
+        fwd_avg, bwd_avg, step_avg = prof_["fwd"][0], prof_["bwd"][0], prof_["step"][0]
+        if eng.mode == "step":
+            # one launch per step: backward of step t + forward of step t+1 in the same kernel
+            return "k_fused_step_wave", bytes_step, step_avg
+        if eng.mode == "pair":
+            return (("k_fused_fwd", bytes_fwd, fwd_avg) if fwd_avg >= bwd_avg else ("k_fused_bwd", bytes_bwd, bwd_avg))
         # generic chain: k_emit / k_batch_reduce are not instrumented; price the whole step
-        dom_name, dom_bytes, dom_ms = "generic chain (whole step, wall)", bytes_step, dt / args.steps * 1e3
+        return "generic chain (whole step, wall)", bytes_step, dt_ / args.steps * 1e3
+
+    def kernel_ms(prof_):
+        return {"k_fused_fwd": round(prof_["fwd"][0], 5), "k_fused_bwd": round(prof_["bwd"][0], 5),
+                "k_fused_step_wave": round(prof_["step"][0], 5)}
+
+    def kernel_fracs(prof_):
+        out = {}
+        for name, nbytes, key in (("k_fused_fwd", bytes_fwd, "fwd"), ("k_fused_bwd", bytes_bwd, "bwd"),
+                                  ("k_fused_step_wave", bytes_step, "step")):
+            if prof_[key][1]:
+                out[name] = round(nbytes / (prof_[key][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        return out
+
+    steps_per_s = args.steps / dt
+    dom_name, dom_bytes, dom_ms = dominant(runs[main_key])
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
+    if os.path.exists(pmc_path) and args.scaling == "weak":
+        # measured by separate rocprofv3 --pmc passes of `bench.py --cache <state>` (tools/pmc_summary.py);
+        # keyed by cache state, kernel and boundary dtype so that it follows whichever kernel dominates here
         with open(pmc_path) as f:
-            traffic = json.load(f).get(dom_name if args.io == "f32" else f"{dom_name}:{args.io}", {}) \
-                .get("traffic_bytes_per_launch")
+            table = json.load(f)
+        table = table.get(main_key, table)
+        traffic = table.get(dom_name if args.io == "f32" else f"{dom_name}:{args.io}", {}).get("traffic_bytes_per_launch")
     if rank == 0:
+        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "cache_state": ("cold: every step reads a gradient tensor and writes an output block last touched "
+                                    f"{ring} steps ago ({ring_bytes / 2**20:.0f} MiB in rotation vs the 256 MiB Infinity Cache)"
+                                    if main_key == "cold" else "in_cache: one resident gradient tensor and output block"),
+                    "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 5),
+                    "kernel_ms": kernel_ms(prof), "kernel_frac": kernel_fracs(prof),
+                    "timed_launches": {k: v[1] for k, v in prof.items()},
+                    "step_algorithmic_bytes": bytes_step,
+                    "step_frac_of_hbm_peak": round(bytes_step * steps_per_s / 1e9 / HBM_PEAK_GBS, 4)}
         line = {
             "metric": "adversarial PGD steps/sec x prompt-batch, LLaVA-1.5-7B pixel path at 1/2/4/8 MI355X",
-            "value": round(steps_per_s * BATCH * world, 1),
+            "value": round(steps_per_s * B * world, 1),
             "unit": "prompt-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "LLaVA-1.5 tanh-clamp attack, 336x336x3 image, 64-prompt batch per GPU, "
+            "config": {"workload": f"LLaVA-1.5 tanh-clamp attack, 336x336x3 image, {B}-prompt batch per GPU, "
                                    "owned pixel path isolated (synthetic upstream gradient in HBM; VLM fwd/bwd not included)",
-                       "prompts_per_gpu": BATCH, "global_prompts": BATCH * world, "image": [3, H, W],
+                       "prompts_per_gpu": B, "global_prompts": B * world, "image": [3, H, W],
                        "noise": "in-kernel Philox4x32-10", "optimizer": "AdamW", "parallelism": f"dp{world}",
                        "path": eng.mode, "boundary_dtype": args.io, "exchange": exchange,
+                       "cache_state": main_key, "ring": ring,
                        "replicas_identical": replicas_identical, "exchange_timed_out": exchange_timed_out},
             "steps_per_s": round(steps_per_s, 1),
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 5),
-                         "kernel_ms": {"k_fused_fwd": round(fwd_avg, 5), "k_fused_bwd": round(bwd_avg, 5),
-                                       "k_fused_step_wave": round(step_avg, 5)},
-                         "timed_launches": {k: v[1] for k, v in prof.items()},
-                         "step_algorithmic_bytes": bytes_step,
-                         "step_frac_of_hbm_peak": round(bytes_step * steps_per_s / 1e9 / HBM_PEAK_GBS, 4)},
+            "roofline": roofline,
         }
+        if main_key == "cold" and "hot" in runs:
+            hdt, hprof = runs["hot"]
+            hname, hbytes, hms = dominant(runs["hot"])
+            line["in_cache"] = {"value": round(args.steps / hdt * B * world, 1), "unit": "prompt-steps/s",
+                                "ms_per_step": round(hdt / args.steps * 1e3, 5),
+                                "steps_per_s": round(args.steps / hdt, 1),
+                                "note": "same K steps on ONE resident gradient tensor / output block (both fit the "
+                                        "256 MiB Infinity Cache): the round-1 loop, an upper estimate"}
+            roofline["frac_cold"] = roofline["frac"]
+            roofline["frac_in_cache"] = round(hbytes / (hms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            roofline["kernel_in_cache"] = hname
+            roofline["kernel_ms_in_cache"] = kernel_ms(hprof)
+            roofline["kernel_frac_in_cache"] = kernel_fracs(hprof)
+            roofline["step_frac_of_hbm_peak_in_cache"] = round(bytes_step * (args.steps / hdt) / 1e9 / HBM_PEAK_GBS, 4)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Reduce rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes to per-kernel HBM traffic.
 
-    python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+    python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> \
+        [<state> <merged.json>]
+
+With <state> (cold | hot, the --cache mode of the profiled bench.py run) the per-kernel table is also
+stored under that key in <merged.json> (profiles/pmc_traffic.json), where bench.py looks its dominant
+kernel up for `roofline.traffic`.
 
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KiB;
 on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced
@@ -34,6 +39,16 @@ def main():
         out[k] = {"fetch_bytes_raw": f_raw, "fetch_bytes_corrected": 2 * f_raw, "write_bytes": w,
                   "traffic_bytes_per_launch": 2 * f_raw + w, "launches_sampled": [nf.get(k, 0), nw.get(k, 0)]}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
+    if len(sys.argv) >= 6:
+        state, merged_path = sys.argv[4], sys.argv[5]
+        try:
+            merged = json.load(open(merged_path))
+        except (OSError, ValueError):
+            merged = {}
+        if not all(k in ("cold", "hot") for k in merged):
+            merged = {}                      # a round-1 table (kernels at the top level)
+        merged[state] = out
+        json.dump(merged, open(merged_path, "w"), indent=1)
     for k, v in out.items():
         print(f"{k:20s} fetch(corr) {v['fetch_bytes_corrected'] / 1e6:8.2f} MB  write {v['write_bytes'] / 1e6:8.2f} MB  "
               f"traffic {v['traffic_bytes_per_launch'] / 1e6:8.2f} MB")
