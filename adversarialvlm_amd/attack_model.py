@@ -24,6 +24,7 @@ import numpy as np
 import torch
 from PIL import Image
 
+from . import dp
 from . import prompts as P
 from .ops import IO_DTYPES
 from .pgd import PixelPGD
@@ -92,6 +93,59 @@ def random_resized_crop_params(height, width, scale, ratio):
     return (height - h) // 2, (width - w) // 2, h, w
 
 
+# wall-clock bound of a wait of the peer exchange inside the trainers: rank 0 alone writes checkpoints and runs
+# the generation probe, and although every rank waits for it at a barrier afterwards, first-step warm-up and
+# allocator stalls can skew the ranks by seconds; a rank that is really gone still ends the run (check_replicas)
+EXCHANGE_TIMEOUT_S = 300.0
+
+
+def save_state(engine, exp_path, global_iteration, iteration, name=None):
+    """True resume state (not in the reference): optimiser moments, schedules, the global RNG
+    streams the shared draws come from (identical on all ranks).  Rank-local streams are re-derived on load:
+    the noise seed from the rank, the prompt stream from (seed, rank, iteration)."""
+    path = os.path.join(exp_path, name or f"state_iter_{global_iteration}.pt")
+    torch.save({"engine": {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in engine.state_dict().items()},
+                "global_iteration": global_iteration, "iteration": iteration, "py_random": random.getstate(),
+                "torch_rng": torch.get_rng_state()}, path)
+    return path
+
+
+def load_state(engine, path):
+    """-> (global_iteration, next iteration) of the run that wrote `path`."""
+    sd = torch.load(path, map_location="cpu")
+    engine.load_state_dict(sd["engine"])
+    random.setstate(sd["py_random"])
+    torch.set_rng_state(sd["torch_rng"])
+    return int(sd["global_iteration"]), int(sd["iteration"]) + 1
+
+
+def reseed_prompt_stream(inputs_processors, seed, rank, iteration):
+    """Data parallelism: every rank draws its prompts from its own stream.  Re-seeded per iteration from
+    (seed, rank, iteration), so a resumed run continues every rank's stream without having saved it."""
+    for ip in inputs_processors:
+        ip.rng.seed((int(seed) * 1000003 + int(rank)) * 1000003 + int(iteration))
+
+
+def assert_replicas(engine, exp_path, rank, iteration, global_iteration):
+    """Collective (every rank, same iteration).  If a barrier of the peer exchange gave up or the replicas
+    differ, every rank writes its own state beside the checkpoints and raises dp.ReplicaError - the
+    trainers' main() turns that into exit status 3 on every rank."""
+    reason = dp.check_replicas(engine, engine.pg)
+    if reason is None:
+        return
+    path = save_state(engine, exp_path, global_iteration, iteration, name=f"state_diverged_rank{rank}_iter_{iteration}.pt")
+    raise dp.ReplicaError(f"rank {rank}, iteration {iteration}: {reason}; this rank's state is in {path}")
+
+
+def broadcast_run_name(name):
+    """Every rank must write into the SAME run directory: rank 0's time-stamped name wins."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        box = [name]
+        torch.distributed.broadcast_object_list(box, src=0)
+        name = box[0]
+    return name
+
+
 class JsonlLogger:
     """Default metrics sink (the reference logs ~20 scalars per step to wandb,
     attack_model.py:382-407); wandb is used instead when importable and requested."""
@@ -129,10 +183,14 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
           questions_file=None, test_questions_file=None, answers_file=None, optimizer="adamw", log_every=1,
           use_wandb=False, seed=0, base_path="./runs", components=None, return_engine=False,
           generation_probe=False, resume_from=None, pixel_io="float32", resaved_loss_every=0,
-          noise_on_padding=True, suffix_only_ce=False):
+          noise_on_padding=True, suffix_only_ce=False, replica_check_every=None, exchange_transport="auto",
+          exchange_timeout_s=EXCHANGE_TIMEOUT_S):
     """pixel_io: "float32" hands the VLM fp32 pixel_values as the reference does; "model" lets
     the fused pair write them in model.dtype (the cast the vision tower's patch embedding applies
-    first anyway) and read the half gradient directly - same numbers, half the traffic."""
+    first anyway) and read the half gradient directly - same numbers, half the traffic.
+    replica_check_every (data parallelism): every so many iterations (default: save_steps) all ranks compare
+    digests of (p, m, v) and the peer exchange's time-out word; on a mismatch every rank writes its state and
+    raises dp.ReplicaError."""
     if pixel_io not in ("float32", "model"):
         raise ValueError("pixel_io must be 'float32' or 'model'")
     if clamp_method != "tanh":
@@ -188,7 +246,8 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
                       grad_accum_steps=grad_accum_steps, blur_kernel=gblur_kernel_size if use_gaussian_blur else None,
                       use_crop=use_local_crop, optimizer=optimizer, seed=seed + 7919 * rank,
                       process_group=torch.distributed.group.WORLD if world > 1 else None,
-                      noise_on_padding=noise_on_padding)
+                      noise_on_padding=noise_on_padding, exchange_transport=exchange_transport,
+                      exchange_timeout_s=exchange_timeout_s)
     if pixel_io == "model" and engine.mode != "step":
         model_dtype = next(model.parameters()).dtype
         if model_dtype in IO_DTYPES:
@@ -212,12 +271,13 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
     history = []
     start_iteration = 0
     if resume_from:
-        sd = torch.load(resume_from, map_location="cpu")
-        engine.load_state_dict(sd["engine"])
-        global_iteration, start_iteration = int(sd["global_iteration"]), int(sd["iteration"]) + 1
-        random.setstate(sd["py_random"])
-        torch.set_rng_state(sd["torch_rng"])
+        global_iteration, start_iteration = load_state(engine, resume_from)
+    check_every = int(replica_check_every) if replica_check_every else int(save_steps)
+    if world > 1:
+        torch.distributed.barrier()          # model loading skews the ranks by far more than a step
     for iteration in range(start_iteration, num_iterations):
+        if world > 1:
+            reseed_prompt_stream([inputs_processor], seed, rank, iteration)
         if target_text_random:
             inputs_processor.set_target_text(random.choice(inputs_processor.target_texts))  # :283-290
         inputs = inputs_processor.get_inputs_train()                                        # :292
@@ -241,6 +301,10 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
         loss_value = loss.detach()
         if stepped:
             global_iteration += 1
+        last = iteration == num_iterations - 1
+        if world > 1 and (iteration % check_every == 0 or last):
+            # before anything of this step is written: a lost peer or diverged replicas end the run on EVERY rank
+            assert_replicas(engine, exp_path, rank, iteration, global_iteration)
         if rank == 0 and (iteration % log_every == 0 or iteration == num_iterations - 1):
             st = engine.stats_dict()
             ce = float(loss_value)
@@ -265,16 +329,17 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
             img = engine.image()
             pil = adv_processor.tensor2pil(img)
             save_checkpoint(pil, img, exp_path, global_iteration)
-            # true resume state (not in the reference): optimiser moments, schedules, RNG streams
-            torch.save({"engine": {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in engine.state_dict().items()},
-                        "global_iteration": global_iteration, "iteration": iteration, "py_random": random.getstate(),
-                        "torch_rng": torch.get_rng_state()}, os.path.join(exp_path, f"state_iter_{global_iteration}.pt"))
+            save_state(engine, exp_path, global_iteration, iteration)
             if generation_probe:                                                            # :435-445
                 from .train_test import run_model_test
                 first_row, probe = run_model_test([model], [processor], [inputs_processor], [model_name], test_questions,
                                                   inputs_processor.target_texts[0], exp_path, iteration, pil,
                                                   adv_processors=[adv_processor])
                 logger.log(dict(iteration=iteration, **probe))
+        if world > 1 and (iteration % save_steps == 0 or last):
+            # rank 0 alone wrote the checkpoint / ran the probe (seconds): the others wait HERE, on the host,
+            # not inside the next step's exchange kernels with their wall-clock limit
+            torch.distributed.barrier()
         if restart_num > 0 and (iteration + 1) % restart_num == 0 and rank == 0:
             print("restart_num has no effect on the optimised tensor in the reference (Q5); ignored")
     if rank == 0:
@@ -338,22 +403,45 @@ def build_parser():
                         "the HIP library: same loss, no [B, S, V] logits tensor")
     p.add_argument("--pixel_io", type=str, default="float32", choices=["float32", "model"],
                    help="dtype of pixel_values at the VLM boundary (model = the VLM's own half dtype)")
+    add_dp_arguments(p)
     return p
 
 
-def main(argv=None):
-    args = build_parser().parse_args(argv)
+def add_dp_arguments(p):
+    p.add_argument("--replica_check_every", type=int, default=None,
+                   help="data parallelism: compare the replicas' digests and the peer exchange's time-out word every N "
+                        "iterations (default: save_steps); a mismatch ends the run with exit status 3 on every rank")
+    p.add_argument("--exchange_transport", type=str, default="auto", choices=["auto", "peer", "rccl"],
+                   help="transport of the per-step all-reduce of the image gradient")
+    p.add_argument("--exchange_timeout_s", type=float, default=EXCHANGE_TIMEOUT_S,
+                   help="wall-clock bound of a wait of the peer exchange")
+
+
+def run_main(train_fn, args):
+    """Shared tail of both trainers' main(): process group, ONE run directory for all ranks, exit status 3 when the
+    replicas diverged or a peer was lost."""
+    import sys
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not torch.distributed.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         torch.distributed.init_process_group("nccl")
-    name = f"{args.exp_name}_{datetime.now().strftime('%Y%m%d_%H%M%S')}"
+    rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+    name = broadcast_run_name(f"{args.exp_name}_{datetime.now().strftime('%Y%m%d_%H%M%S')}")
     exp_path = create_directory(name)
-    with open(os.path.join(exp_path, "config.json"), "w") as f:
-        json.dump(vars(args), f, indent=4)
+    if rank == 0:
+        with open(os.path.join(exp_path, "config.json"), "w") as f:
+            json.dump(vars(args), f, indent=4)
     kw = vars(args).copy()
     kw["exp_name"] = name
-    train(**kw)
+    try:
+        train_fn(**kw)
+    except dp.ReplicaError as e:
+        print(f"FATAL: {e}", file=sys.stderr, flush=True)
+        sys.exit(3)
+
+
+def main(argv=None):
+    run_main(train, build_parser().parse_args(argv))
 
 
 if __name__ == "__main__":

@@ -17,18 +17,17 @@ only changes the optimiser cadence because p.grad is rebuilt each iteration; DPO
 the target for a refusal string without negating the loss (Q8).
 """
 import argparse
-import json
 import os
 import random
-from datetime import datetime
 
 import numpy as np
 import torch
 from PIL import Image
 
 from . import prompts as P
-from .attack_model import (JsonlLogger, create_directory, create_mask, random_resized_crop_params, save_checkpoint,
-                           setup_device)
+from .attack_model import (EXCHANGE_TIMEOUT_S, JsonlLogger, add_dp_arguments, assert_replicas, create_directory,
+                           create_mask, load_state, random_resized_crop_params, reseed_prompt_stream, run_main,
+                           save_checkpoint, save_state, setup_device)
 from .pgd import PixelPGD
 from .processors import load_components
 
@@ -49,7 +48,10 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
           crop_scale_max=1.0, crop_ratio_min=0.75, crop_ratio_max=1.33,
           questions_file=None, test_questions_file=None, answers_file=None, log_every=1, use_wandb=False, seed=0,
           base_path="./runs", return_engine=False, resaved_loss_every=0, noise_on_padding=True,
-          suffix_only_ce=False, pixel_io="float32"):
+          suffix_only_ce=False, pixel_io="float32", components=None, generation_probe=False, resume_from=None,
+          replica_check_every=None, exchange_transport="auto", exchange_timeout_s=EXCHANGE_TIMEOUT_S):
+    """components: optional {model_name: (load_model_and_processor, AdvInputs, DiffProc)} overriding the registry
+    (tests).  generation_probe / resume_from / replica_check_every: as in attack_model.train."""
     if clamp_method != "tanh":
         raise NotImplementedError("Clamping method except tanh are not implemented yet.")
     if mask_type == "random_square":
@@ -94,19 +96,23 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
     else:
         raise FileNotFoundError(f"Cannot find {img_orig}")
 
-    models, adv_processors, inputs_processors = [], [], []
-    random.seed(seed)
-    torch.manual_seed(seed)
+    models, processors, adv_processors, inputs_processors = [], [], [], []
     for i in my_models:
-        load_model_and_processor, AdvInputs, DiffProc = load_components(model_names[i])
+        load_model_and_processor, AdvInputs, DiffProc = (components or {}).get(model_names[i]) or load_components(model_names[i])
         model, processor = load_model_and_processor(model_names[i], device)
         model.requires_grad_(False)
         models.append(model)
+        processors.append(processor)
         adv_processors.append(DiffProc(processor.image_processor, device))
         inputs_processors.append(AdvInputs(questions=questions, test_questions=test_questions, batch_size=local_batch,
                                            original_image=original_image, processor=processor, device=device,
                                            target_text=target_text,
                                            rng=random.Random(seed * 1000003 + rank) if world > 1 else None))
+    # the shared draws (target text, refusal coin, blur sigma, crop window) come from the global generators: seed
+    # them AFTER the models are loaded - under data parallelism every rank loads a different model, and parameter
+    # initialisation may consume the global torch generator by a different amount on each rank
+    random.seed(seed)
+    torch.manual_seed(seed)
     x_0 = pil_to_tensor(original_image, do_convert_rgb=adv_processors[0].do_convert_rgb).to(device)
     if start_from_white:
         x_0 = torch.ones_like(x_0)
@@ -126,7 +132,8 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
                       use_crop=use_local_crop, model_weights=[model_weights[i] for i in my_models], cross_mode=True,
                       seed=seed + 7919 * rank, allow_fused=(len(plans) == 1),   # one model on this rank: pipelined chains
                       process_group=torch.distributed.group.WORLD if world > 1 else None, grad_prescale=prescale,
-                      noise_on_padding=noise_on_padding)
+                      noise_on_padding=noise_on_padding, exchange_transport=exchange_transport,
+                      exchange_timeout_s=exchange_timeout_s)
     if pixel_io == "model":
         # every model receives pixel_values in its own dtype (Qwen2-VL runs bf16, the others fp16)
         from .ops import IO_DTYPES
@@ -138,7 +145,15 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
 
     global_iteration = 0
     history = []
-    for iteration in range(num_iterations):
+    start_iteration = 0
+    if resume_from:
+        global_iteration, start_iteration = load_state(engine, resume_from)
+    check_every = int(replica_check_every) if replica_check_every else int(save_steps)
+    if world > 1:
+        torch.distributed.barrier()          # model loading skews the ranks by far more than a step
+    for iteration in range(start_iteration, num_iterations):
+        if world > 1:
+            reseed_prompt_stream(inputs_processors, seed, rank, iteration)
         if DPO_flag or target_text_random:                                                  # :303-321
             coin = random.random()
             if DPO_flag and coin < refuse_prob:
@@ -173,6 +188,10 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
         stepped = engine.backward_update(grads)                                             # :391-406 (HIP)
         if stepped:
             global_iteration += 1
+        last = iteration == num_iterations - 1
+        if world > 1 and (iteration % check_every == 0 or last):
+            # the sum this exchange replaces (crossattack_models.py:383-406) cannot silently drop a term
+            assert_replicas(engine, exp_path, rank, iteration, global_iteration)
         if rank == 0 and (iteration % log_every == 0 or iteration == num_iterations - 1):
             st = engine.stats_dict()
             rec = {"iteration": iteration, "global_iteration": global_iteration, "img_loss": st["img_loss"],
@@ -196,7 +215,21 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
             logger.log(rec)
         if rank == 0 and (iteration % save_steps == 0 or iteration == num_iterations - 1):
             img = engine.image()
-            save_checkpoint(adv_processors[0].tensor2pil(img), img, exp_path, global_iteration)
+            pil = adv_processors[0].tensor2pil(img)
+            save_checkpoint(pil, img, exp_path, global_iteration)
+            save_state(engine, exp_path, global_iteration, iteration)
+        if generation_probe and (iteration % save_steps == 0 or last):                       # :475-497
+            # every rank probes the model(s) it holds; with one process that is all of them, like the reference
+            from .train_test import run_model_test
+            pil = adv_processors[0].tensor2pil(engine.image())
+            first_row, probe = run_model_test(models, processors, inputs_processors, [model_names[i] for i in my_models],
+                                              test_questions, "sure, here it is", exp_path, iteration, pil,
+                                              adv_processors=adv_processors,
+                                              csv_suffix=f"_rank{rank}" if world > 1 else "")
+            if rank == 0:
+                logger.log(dict(iteration=iteration, **probe))
+        if world > 1 and (iteration % save_steps == 0 or last):
+            torch.distributed.barrier()      # rank 0's checkpoint I/O is waited for on the host, not inside the exchange
     if rank == 0:
         img = engine.image()
         save_checkpoint(adv_processors[0].tensor2pil(img), img, exp_path, "final")
@@ -258,6 +291,9 @@ def build_parser():
                    help="logits of the target positions only (logits_to_keep) + HIP cross entropy: same loss, no [B,S,V] tensor")
     p.add_argument("--resaved_loss_every", type=int, default=0,
                    help="log loss_resaved (every model's forward on the re-saved image) every N iterations; 0 = off")
+    p.add_argument("--generation_probe", action="store_true", help="greedy-generate the test prompts at every save step")
+    p.add_argument("--resume_from", type=str, default=None, help="state_iter_*.pt written by a previous run")
+    add_dp_arguments(p)
     return p
 
 
@@ -265,17 +301,7 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     if isinstance(args.model_names, str):
         args.model_names = parse_model_names(args.model_names)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not torch.distributed.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        torch.distributed.init_process_group("nccl")
-    name = f"{args.exp_name}_{datetime.now().strftime('%Y%m%d_%H%M%S')}"
-    exp_path = create_directory(name)
-    with open(os.path.join(exp_path, "config.json"), "w") as f:
-        json.dump(vars(args), f, indent=4)
-    kw = vars(args).copy()
-    kw["exp_name"] = name
-    train(**kw)
+    run_main(train, args)
 
 
 if __name__ == "__main__":

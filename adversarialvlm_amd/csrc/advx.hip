@@ -59,7 +59,17 @@ struct Prof {
   int stride = 1;                 // time every stride-th launch of a kind
   long long seen[PROF_KINDS] = {0, 0, 0};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[PROF_KINDS];
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;   // created by advx_profile_begin: nothing but the launch in the timed path
 } g_prof;
+static inline bool prof_take(hipEvent_t& e0, hipEvent_t& e1) {
+  if (!g_prof.pool.empty()) {
+    e0 = g_prof.pool.back().first;
+    e1 = g_prof.pool.back().second;
+    g_prof.pool.pop_back();
+    return true;
+  }
+  return hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+}
 }  // namespace
 
 #define ADVX_LAUNCH_TIMED(kind, kernel, grid, block, stream, ...)                                         \
@@ -67,7 +77,7 @@ struct Prof {
     if (g_prof.on && (g_prof.seen[kind]++ % g_prof.stride) == 0 &&                                        \
         (int)g_prof.ev[kind].size() < g_prof.max_launches) {                                              \
       hipEvent_t e0, e1;                                                                                  \
-      if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {                       \
+      if (prof_take(e0, e1)) {                                                                            \
         hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, e0, e1, 0, __VA_ARGS__);                    \
         g_prof.ev[kind].push_back({e0, e1});                                                              \
       } else {                                                                                            \
@@ -87,6 +97,15 @@ extern "C" int32_t advx_profile_begin(int32_t max_launches, int32_t stride) {
     g_prof.ev[k].clear();
   }
   g_prof.max_launches = max_launches;
+  // event pairs for the launches that will be timed (two kinds per step at most), capped: beyond the pool the
+  // launch path creates its own
+  long long want = std::min<long long>(2LL * ((max_launches + stride - 1) / stride + 1), 512);
+  while ((long long)g_prof.pool.size() < want) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) break;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); break; }
+    g_prof.pool.push_back({e0, e1});
+  }
   g_prof.on = true;
   return ADVX_OK;
 }
@@ -108,6 +127,8 @@ extern "C" int32_t advx_profile_end(double total_ms[3], int64_t launches[3]) {
     }
     g_prof.ev[k].clear();
   }
+  for (auto& e : g_prof.pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  g_prof.pool.clear();
   return ADVX_OK;
 }
 

@@ -50,6 +50,48 @@ class Scales:
         return n * self.prescale
 
 
+class ReplicaError(RuntimeError):
+    """The data-parallel replicas of (p, m, v) no longer hold the same bits, or a barrier of the peer
+    exchange gave up waiting for a rank.  Raised on EVERY rank (the verdict is all-reduced)."""
+
+
+def replica_digest(engine):
+    """Three float64 sums over p, m and v: replicas that took the same steps agree on them bit for bit."""
+    parts = []
+    for t in (engine.p, engine.m, engine.v):
+        d = t.double()
+        parts += [d.sum(), d.abs().sum(), (d * d).sum()]
+    return torch.stack(parts)
+
+
+def check_replicas(engine, group=None):
+    """Collective health check of a data-parallel run (call it on every rank at the same iteration):
+    the sticky time-out word of the peer exchange (csrc/advx_comm.h: a wait that gives up lets its kernel
+    go on with stale sums) and the digests of the replicas.  The sum the exchange replaces
+    (crossattack_models.py:383-406) cannot silently drop a term; this is what keeps that property.
+    -> None, or the reason as a string (the same on every rank)."""
+    dist = torch.distributed
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if engine.peer is not None and engine.peer.timed_out():
+            return "a barrier of the peer exchange timed out"
+        return None
+    dev = engine.p.device
+    on_cpu = dist.get_backend(group) == "gloo"
+    lost = 1.0 if (engine.peer is not None and engine.peer.timed_out()) else 0.0
+    dig = replica_digest(engine)
+    lo = torch.cat([dig, torch.tensor([-lost], dtype=torch.float64, device=dev)])
+    hi = lo.clone()
+    if on_cpu:
+        lo, hi = lo.cpu(), hi.cpu()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if float(lo[-1]) < 0.0:
+        return "a barrier of the peer exchange timed out on at least one rank (a peer was late by more than its limit)"
+    if not torch.equal(lo[:-1], hi[:-1]):
+        return "the replicas of (p, m, v) differ between ranks"
+    return None
+
+
 def allreduce_image_grad_(grad, group=None):
     """The one exchange of a step."""
     torch.distributed.all_reduce(grad, op=torch.distributed.ReduceOp.SUM, group=group)

@@ -37,7 +37,7 @@ class PixelPGD:
                  scheduler_gamma=1.0, grad_accum_steps=1, blur_kernel=None, use_crop=False, model_weights=None,
                  optimizer="adamw", cross_mode=False, betas=(0.9, 0.999), adam_eps=1e-8, weight_decay=1e-2, seed=0,
                  process_group=None, allow_fused=True, fused_mode="auto", grad_prescale=None, force_exchange=False,
-                 io_dtype=torch.float32, exchange_transport="auto", noise_on_padding=True):
+                 io_dtype=torch.float32, exchange_transport="auto", noise_on_padding=True, exchange_timeout_s=5.0):
         """io_dtype: dtype of the pixel_values handed to the VLM (every chain but `step`).  float32 is
         the reference's own boundary; float16 / bfloat16 emit the tensor already cast to the
         model's dtype (the cast the model's first layer would apply) and let backward_update
@@ -49,7 +49,9 @@ class PixelPGD:
         of Mllama / Phi-3.5 (which both models mask out); False = those tiles stay exact zeros in
         pixel_values buffers the engine keeps across steps and rewrites only where an image is
         (no generator work and no traffic for 3/4 resp. 2/7 of the tensor; the tensor returned by
-        forward() is then only valid until the next forward())."""
+        forward() is then only valid until the next forward()).
+        exchange_timeout_s: wall-clock bound of every wait of the peer exchange; a wait that gives up sets
+        a sticky error word (`self.peer.timed_out()`, `dp.check_replicas`) and lets its kernel go on."""
         if not x0.is_cuda:
             raise L.AdvxError("PixelPGD needs x0 on a ROCm device (there is no CPU fallback)")
         if not isinstance(plans, (list, tuple)):
@@ -91,7 +93,8 @@ class PixelPGD:
         self.exchange = self.world > 1 or bool(force_exchange)
         self.peer = None
         if self.exchange:
-            self.peer = dp.make_exchange(self.x0.numel(), dev, process_group, exchange_transport)
+            self.peer = dp.make_exchange(self.x0.numel(), dev, process_group, exchange_transport,
+                                         timeout_s=float(exchange_timeout_s))
         # factor every rank applies to its contribution before the SUM all-reduce: 1/world gives
         # the data-parallel average; cross-model groups pass 1/group_size (average inside a
         # model's group, sum across models - crossattack_models.py:391)
@@ -448,7 +451,8 @@ class PixelPGD:
             getattr(self, k).copy_(sd[k].to(self.p.device))
         self.lr, self.opt_steps, self.iteration = float(sd["lr"]), int(sd["opt_steps"]), int(sd["iteration"])
         self._norm_pending = False                 # the loaded statistics are complete
-        self.seed = int(sd.get("seed", self.seed))
+        # the noise seed is NOT taken from the file: under data parallelism only rank 0 writes it, and every
+        # rank keeps the stream it was constructed with (seed + 7919 * rank in the trainers)
         if self.fused:
             # nothing prepared, nothing pending: the next forward re-derives s / v from p
             self.prepared = False

@@ -1,8 +1,10 @@
 """Plugin registry: model name -> (load_model_and_processor, AdvInputs, DifferentiableImageProcessor).
 
 Same map and the same `load_components` contract as the reference's
-`src/processors/__init__.py:5-76` (ValueError for unknown names, processor_class None for the
-evaluation-only judge model), resolved inside this package.
+`src/processors/__init__.py:5-76` (ValueError for unknown names; a `processor_class` of None is
+accepted and yields None, as for the reference's evaluation-only judge entry `google/gemma-3-12b-it`
+- that entry itself is NOT registered here: the judge and the evaluation harness are out of scope,
+SURVEY.md section 2 rows 9 and 13-14), resolved inside this package.
 """
 import importlib
 from typing import Tuple

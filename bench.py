@@ -195,6 +195,11 @@ def main():
     ring_bytes = (2 * ring + 1) * B * 3 * H * W * io_bytes      # `ring` gradient tensors + `ring`+1 output blocks
 
     held = collections.deque(maxlen=ring)        # keeps the last `ring` output blocks allocated
+    if ring > 1:
+        # reserve the ring's output blocks now (the caching allocator keeps them): no hipMalloc inside a timed
+        # region however short the warm-up is
+        pre = [torch.empty((B, 3 * H * W), dtype=io_dtype, device=dev) for _ in range(ring + 1)]
+        del pre
     counter = [0]
 
     def step_cold():
@@ -217,12 +222,13 @@ def main():
     def timed(step):
         """W warm-up steps, then exactly K steps between two fences; MAX over ranks.  Every stride-th launch of the
         B*P_out movers carries its own start/stop HIP event pair on the launch stream (advx_profile_*,
-        hipExtLaunchKernelGGL); the stride is chosen so that at least 16 (up to 64) launches per kernel are
-        timed whatever K is."""
+        hipExtLaunchKernelGGL); the stride is chosen so that at least 10 launches per kernel are timed whatever
+        K >= 10 is (64 from K = 640 up).  A timed launch is fenced off from its neighbours by the event
+        packets (measured: +2.5 us per step at stride 1), which is why not every launch is timed."""
         for _ in range(args.warmup):
             step()
         fence()
-        ops.profile_begin(max(args.steps, 1), stride=max(1, args.steps // 64))
+        ops.profile_begin(max(args.steps, 1), stride=max(1, args.steps // (64 if args.steps >= 640 else 10)))
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
