@@ -114,3 +114,34 @@ def test_cross_model_groups_sum_like_single_process():
         ups = [torch.randn(2 * s[0], *s[1:], generator=gen2) * 0.01 for s in [(1, 3, 24, 24), (4, 1176)]]
         ref.backward_update(ups)
     assert float((p0 - ref.p.detach()).norm() / ref.p.detach().norm()) < 1e-5
+
+
+def _check_rank(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from types import SimpleNamespace
+    dp.init_from_env("gloo")
+    gen = torch.Generator().manual_seed(1)
+    eng = SimpleNamespace(p=torch.randn(3, 8, 8, generator=gen), m=torch.randn(3, 8, 8, generator=gen),
+                          v=torch.rand(3, 8, 8, generator=gen), peer=None)
+    res = [dp.check_replicas(eng)]
+    if rank == 1:
+        eng.m[2, 3, 4] += 1e-6              # one element of one moment, on one rank
+    res.append(dp.check_replicas(eng))
+    # a peer exchange whose sticky time-out word is set on ONE rank ends the run on every rank
+    eng.peer = SimpleNamespace(timed_out=lambda: rank == 0)
+    res.append(dp.check_replicas(eng))
+    out[rank] = res
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_replica_check_is_collective_and_agreed():
+    """dp.check_replicas: identical replicas pass; one differing element or one rank's time-out word is
+    reported with the same reason on EVERY rank (the trainers turn it into dp.ReplicaError / exit 3)."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_check_rank, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] == out[1]
+    ok, differ, lost = out[0]
+    assert ok is None and "differ" in differ and "timed out" in lost
