@@ -17,6 +17,7 @@ OPT_ADAMW, OPT_SIGN = 0, 1
 STAT_SIGMA, STAT_QERR_STD, STAT_QERR_MEAN, STAT_QERR_L1, STAT_IMGFIT, STAT_X_MEAN, STAT_X_STD, STAT_GRAD_NORM = range(8)
 STATS_N = 16
 MAX_STAGES = 2
+TUNE_GENERIC_KERNELS = 1
 
 
 class AdvxError(RuntimeError):
@@ -59,6 +60,7 @@ _PI32 = C.POINTER(C.c_int32)
 SIGNATURES = {
     "advx_version": (_I32, []),
     "advx_last_error": (C.c_char_p, []),
+    "advx_set_tuning": (_I32, [_I32, _I32]),
     "advx_plan_create": (_I32, [C.POINTER(PlanDesc), C.POINTER(_P)]),
     "advx_plan_destroy": (_I32, [_P]),
     "advx_plan_describe": (_I32, [_P, C.POINTER(PlanInfo)]),

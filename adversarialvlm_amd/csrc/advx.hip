@@ -13,6 +13,8 @@
 
 #include "../../include/advx.h"
 #include "advx_kernels.h"
+#include "advx_resize.h"
+#include "advx_blur.h"
 #include "advx_ce.h"
 
 using namespace advx;
@@ -38,6 +40,17 @@ static int32_t fail(int32_t code, const std::string& msg) {
   do {                           \
     if (!(cond)) return fail(code, msg); \
   } while (0)
+
+// advx_set_tuning(ADVX_TUNE_GENERIC_KERNELS, 1): take the run-time-radius / unfused kernels everywhere (the tests
+// compare the specialised kernels with them bit for bit)
+static int g_generic_kernels = 0;
+extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
+  if (what == ADVX_TUNE_GENERIC_KERNELS) {
+    g_generic_kernels = value ? 1 : 0;
+    return ADVX_OK;
+  }
+  return fail(ADVX_E_BADARG, "advx_set_tuning: unknown switch");
+}
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int grid_for(long long n, int cap = 2048) {
@@ -560,6 +573,63 @@ extern "C" int32_t advx_plan_upload(advx_plan* p, void* stream) {
   return ADVX_OK;
 }
 
+// ---------------------------------------------------------- windowed resizes (advx_resize.h)
+// T = compiled window size that holds `need` taps per axis (0: none - the run-time-loop kernels take over)
+static inline int pick_window(int need) {
+  if (g_generic_kernels) return 0;
+  // measured (profiles/r02): windows up to 4 x 4 pay (crop resize 7.3 -> 6.4 us, Phi-3.5's bicubic stage 11.7 ->
+  // 7.5); from 5 x 5 on the clamped loads of taps a row does not have cost more than the run-time loops save
+  static const int sizes[] = {2, 3, 4};
+  for (int t : sizes)
+    if (need <= t) return t;
+  return 0;
+}
+#define ADVX_WINDOW_SWITCH(T_, CALL) \
+  switch (T_) {                      \
+    case 2: CALL(2); break;          \
+    case 3: CALL(3); break;          \
+    default: CALL(4); break;         \
+  }
+
+// canvas = resize(src), pad, normalise; block 0 reduces the statistics partials (img_nblk > 0) and / or the ||g||
+// partials (norm_count != 0) an earlier launch left
+static void launch_stage_fwd(const DStage& D, const float* src, long long src_cstride, int src_rstride, float* canvas,
+                             const double* img_partials, int img_nblk, long long n_img, const double* norm_rows, int norm_count,
+                             float* stats, hipStream_t st) {
+  const int T = pick_window(std::max(D.th.stride, D.tw.stride));
+  if (T) {
+    dim3 grid((D.can_w + kRowBlock - 1) / kRowBlock, D.can_h, 3);
+#define ADVX_SF(T_)                                                                                                     \
+  hipLaunchKernelGGL((k_stage_fwd_t<T_>), grid, dim3(kRowBlock), 0, st, D, src, src_cstride, src_rstride, canvas, img_partials, \
+                     img_nblk, n_img, norm_rows, norm_count, stats)
+    ADVX_WINDOW_SWITCH(T, ADVX_SF)
+#undef ADVX_SF
+    return;
+  }
+  const long long n = 3LL * D.can_h * D.can_w;
+  if (img_nblk > 0)
+    hipLaunchKernelGGL(k_stage_fwd_img, dim3(grid_for(n)), dim3(kBlock), 0, st, D, src, src_cstride, src_rstride, canvas,
+                       img_partials, img_nblk, n_img, stats);
+  else if (norm_count != 0)
+    hipLaunchKernelGGL(k_plan_head, dim3(grid_for(n)), dim3(kBlock), 0, st, D, src, src_cstride, src_rstride, canvas, norm_rows,
+                       norm_count, stats);
+  else
+    hipLaunchKernelGGL(k_stage_fwd, dim3(grid_for(n)), dim3(kBlock), 0, st, D, src, src_cstride, src_rstride, canvas);
+}
+
+// gradient of the whole image from the gradient of the crop window's resize (zeros outside the window)
+static void launch_crop_bwd(const DStage& D, const float* gcan, float* gimg, int H, int W, int ci, int cj, hipStream_t st) {
+  const int T = pick_window(std::max(D.tth.stride, D.ttw.stride));
+  if (T) {
+    dim3 grid((W + kRowBlock - 1) / kRowBlock, H, 3);
+#define ADVX_CB(T_) hipLaunchKernelGGL((k_crop_bwd_t<T_>), grid, dim3(kRowBlock), 0, st, D, gcan, gimg, H, W, ci, cj)
+    ADVX_WINDOW_SWITCH(T, ADVX_CB)
+#undef ADVX_CB
+    return;
+  }
+  hipLaunchKernelGGL(k_crop_bwd, dim3(grid_for(3LL * H * W)), dim3(kBlock), 0, st, D, gcan, gimg, H, W, ci, cj);
+}
+
 // ------------------------------------------------------------------ emit / collect
 static void emit_slices(long long n4, int batch, int* gx, int* slices, int* b_per_slice) {
   long long bx = (n4 + kBlock - 1) / kBlock;
@@ -623,9 +693,8 @@ extern "C" int32_t advx_emit_ex(advx_plan* p, const float* argument, int32_t bat
     const DStage& D = p->dstage[k];
     const advx_stage_info& s = p->st[k].info;
     const float* src = (s.src == 0) ? argument : ws + p->dplan.canvas_off[s.src - 1];
-    long long n = 3LL * D.can_h * D.can_w;
-    hipLaunchKernelGGL(k_stage_fwd, dim3(grid_for(n)), dim3(kBlock), 0, st, D, src, (long long)D.src_h * D.src_w, D.src_w,
-                       ws + p->dplan.canvas_off[k]);
+    launch_stage_fwd(D, src, (long long)D.src_h * D.src_w, D.src_w, ws + p->dplan.canvas_off[k], nullptr, 0, 0, nullptr, 0,
+                     nullptr, st);
     LAUNCH_CHECK();
   }
   const long long n4 = (p->info.out_numel + 3) >> 2;
@@ -777,8 +846,24 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
     biggest = std::max(biggest, 3LL * p->dstage[0].can_h * p->dstage[0].can_w);
   }
   const DStage& D0 = plans[0]->dstage[0];
-  hipLaunchKernelGGL(k_stage0_fwd_multi, dim3(grid_for(biggest), n), dim3(kBlock), 0, st, mf, argument,
-                     (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats);
+  int need = 0, max_h = 0, max_w = 0;
+  for (int i = 0; i < n; ++i) {
+    need = std::max(need, std::max(mf.st[i].th.stride, mf.st[i].tw.stride));
+    max_h = std::max(max_h, mf.st[i].can_h);
+    max_w = std::max(max_w, mf.st[i].can_w);
+  }
+  const int T0 = 0 * pick_window(need);   // measured: the mixed geometries of a cross-model run lose with one window size (20.7 vs 19.1 us)
+  if (T0) {
+    dim3 grid((max_w + kRowBlock - 1) / kRowBlock, max_h, 3 * n);
+#define ADVX_SFM(T_)                                                                                                        \
+  hipLaunchKernelGGL((k_stage0_fwd_multi_t<T_>), grid, dim3(kRowBlock), 0, st, mf, argument, (long long)D0.src_h * D0.src_w, \
+                     D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats)
+    ADVX_WINDOW_SWITCH(T0, ADVX_SFM)
+#undef ADVX_SFM
+  } else {
+    hipLaunchKernelGGL(k_stage0_fwd_multi, dim3(grid_for(biggest), n), dim3(kBlock), 0, st, mf, argument,
+                       (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats);
+  }
   LAUNCH_CHECK();
   for (int i = 0; i < n; ++i) {
     advx_plan* p = plans[i];
@@ -787,8 +872,8 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
       const DStage& D = p->dstage[k];
       const advx_stage_info& s = p->st[k].info;
       const float* src = (s.src == 0) ? argument : ws + p->dplan.canvas_off[s.src - 1];
-      hipLaunchKernelGGL(k_stage_fwd, dim3(grid_for(3LL * D.can_h * D.can_w)), dim3(kBlock), 0, st, D, src,
-                         (long long)D.src_h * D.src_w, D.src_w, ws + p->dplan.canvas_off[k]);
+      launch_stage_fwd(D, src, (long long)D.src_h * D.src_w, D.src_w, ws + p->dplan.canvas_off[k], nullptr, 0, 0, nullptr, 0,
+                       nullptr, st);
       LAUNCH_CHECK();
     }
     const float* z = unit_noises ? unit_noises[i] : nullptr;
@@ -1022,8 +1107,23 @@ static int32_t image_fwd_impl(const float* p, const float* x0, int32_t H, int32_
         LAUNCH_CHECK();
       }
     }
-    hipLaunchKernelGGL((k_blur<0, 1>), grid, dim3(kBlock), 0, st, p, H, W, blur_k / 2, blur_sigma, x0, s, partials,
-                       (const float*)nullptr, eps, riding ? taps[0] : none[0], riding ? taps[1] : none[1], riding);
+    const int r = blur_k / 2;
+#define ADVX_BLUR_FWD(R_)                                                                                          \
+  hipLaunchKernelGGL((k_blur_fwd_r<1, R_>), grid, dim3(kBlock), 0, st, p, H, W, blur_sigma, x0, s, partials, eps, \
+                     riding ? taps[0] : none[0], riding ? taps[1] : none[1], riding)
+    switch ((r >= 1 && r <= kBlurFastMaxR && !g_generic_kernels) ? r : 0) {
+      case 1: ADVX_BLUR_FWD(1); break;
+      case 2: ADVX_BLUR_FWD(2); break;
+      case 3: ADVX_BLUR_FWD(3); break;
+      case 4: ADVX_BLUR_FWD(4); break;
+      case 5: ADVX_BLUR_FWD(5); break;
+      case 6: ADVX_BLUR_FWD(6); break;
+      case 7: ADVX_BLUR_FWD(7); break;
+      default:
+        hipLaunchKernelGGL((k_blur<0, 1>), grid, dim3(kBlock), 0, st, p, H, W, r, blur_sigma, x0, s, partials,
+                           (const float*)nullptr, eps, riding ? taps[0] : none[0], riding ? taps[1] : none[1], riding);
+    }
+#undef ADVX_BLUR_FWD
     LAUNCH_CHECK();
     nblk = (int)blur_tiles(H, W);
   } else {
@@ -1038,8 +1138,7 @@ static int32_t image_fwd_impl(const float* p, const float* x0, int32_t H, int32_
   if (crop) {
     // block 0 of the window's resize reduces the statistics partials: no one-block launch in between
     const float* src = s + (size_t)crop[0] * W + crop[1];
-    hipLaunchKernelGGL(k_stage_fwd_img, dim3(grid_for(n)), dim3(kBlock), 0, st, crop_stage, src, (long long)H * W, W, argument,
-                       (const double*)partials, nblk, n, stats);
+    launch_stage_fwd(crop_stage, src, (long long)H * W, W, argument, (const double*)partials, nblk, n, nullptr, 0, stats, st);
     LAUNCH_CHECK();
     return ADVX_OK;
   }
@@ -1088,6 +1187,33 @@ extern "C" int32_t advx_forward_multi(const float* p, const float* x0, int32_t H
   return rc;
 }
 
+// The image-level backward behind the plans' resizes as ONE launch (advx_blur.h) when the radius is one of
+// the compiled ones and the image has at most 2048 tiles (the norm partials' room); false = caller takes the
+// generic kernels.
+static bool blur_bwd_fusable(int r, int H, int W) {
+  if (g_generic_kernels || r < 1 || r > kBlurFastMaxR) return false;
+  return (long long)((W + kBlurTile - 1) / kBlurTile) * ((H + kBlurTile - 1) / kBlurTile) * 3 <= NormCount::kSlot;
+}
+template <bool UPDATE>
+static void launch_blur_bwd_fused(int r, const float* gsrc, const float* s, int H, int W, float sigma, float eps, float c_fit,
+                                  int accumulate, float* p, float* m, float* v, float* grad, const float* mask,
+                                  const OptScalars& o, double* partials, hipStream_t st) {
+  dim3 grid((W + kBlurTile - 1) / kBlurTile, (H + kBlurTile - 1) / kBlurTile, 3);
+#define ADVX_BWD_R(R_)                                                                                                  \
+  hipLaunchKernelGGL((k_blur_bwd_fused<R_, UPDATE>), grid, dim3(kBlock), 0, st, gsrc, s, H, W, sigma, eps, c_fit, accumulate, p, \
+                     m, v, grad, mask, o, partials)
+  switch (r) {
+    case 1: ADVX_BWD_R(1); break;
+    case 2: ADVX_BWD_R(2); break;
+    case 3: ADVX_BWD_R(3); break;
+    case 4: ADVX_BWD_R(4); break;
+    case 5: ADVX_BWD_R(5); break;
+    case 6: ADVX_BWD_R(6); break;
+    default: ADVX_BWD_R(7); break;
+  }
+#undef ADVX_BWD_R
+}
+
 extern "C" int32_t advx_image_bwd(const float* p, const float* s, const float* garg, int32_t H, int32_t W, float eps,
                                   int32_t blur_k, float blur_sigma, const int32_t* crop, float imgfit_scale,
                                   float* grad_p, int32_t accumulate, float* scratch, void* stream) {
@@ -1099,13 +1225,33 @@ extern "C" int32_t advx_image_bwd(const float* p, const float* s, const float* g
   Bump b{scratch};
   (void)b.take(partial_floats(H, W));
   const float* gs = garg;
+  if (blur_k > 0 && blur_bwd_fusable(blur_k / 2, H, W)) {
+    int32_t rc = check_blur(H, W, blur_k, blur_sigma);
+    if (rc) return rc;
+    if (crop) {
+      DStage D;
+      rc = build_crop_stage(H, W, crop, b, st, &D, /*may_reuse=*/true);
+      if (rc) return rc;
+      float* gsbuf = b.take(n);
+      launch_crop_bwd(D, garg, gsbuf, H, W, crop[0], crop[1], st);
+      LAUNCH_CHECK();
+      gs = gsbuf;
+    }
+    OptScalars none;
+    std::memset(&none, 0, sizeof(none));
+    // + imgfit', blur^T, fold, tanh' in one launch: the unmasked gradient (the all-reduce follows)
+    launch_blur_bwd_fused<false>(blur_k / 2, gs, s, H, W, blur_sigma, eps, c_fit, accumulate, const_cast<float*>(p), nullptr,
+                                 nullptr, grad_p, nullptr, none, nullptr, st);
+    LAUNCH_CHECK();
+    return ADVX_OK;
+  }
   if (crop) {
     DStage D;
     int32_t rc = build_crop_stage(H, W, crop, b, st, &D, /*may_reuse=*/true);   // the forward's tables, if still there
     if (rc) return rc;
     float* gsbuf = b.take(n);
     // gradient of the whole image: transposed resize inside the window, exact zeros outside
-    hipLaunchKernelGGL(k_crop_bwd, dim3(grid_for(n)), dim3(kBlock), 0, st, D, garg, gsbuf, H, W, crop[0], crop[1]);
+    launch_crop_bwd(D, garg, gsbuf, H, W, crop[0], crop[1], st);
     LAUNCH_CHECK();
     gs = gsbuf;
   }
@@ -1196,13 +1342,27 @@ extern "C" int32_t advx_image_bwd_update(float* p, const float* s, const float* 
     rc = build_crop_stage(H, W, crop, b, st, &D, /*may_reuse=*/true);
     if (rc) return rc;
   }
+  bool fused_done = false;
   if (blur_k > 0) {
     rc = check_blur(H, W, blur_k, blur_sigma);
     if (rc) return rc;
+    fused_done = blur_bwd_fusable(blur_k / 2, H, W);
+  }
+  if (fused_done) {
     const float* gs = garg;
     if (crop) {
       float* gsbuf = b.take(n);
-      hipLaunchKernelGGL(k_crop_bwd, dim3(grid_for(n)), dim3(kBlock), 0, st, D, garg, gsbuf, H, W, crop[0], crop[1]);
+      launch_crop_bwd(D, garg, gsbuf, H, W, crop[0], crop[1], st);
+      LAUNCH_CHECK();
+      gs = gsbuf;
+    }
+    // one launch: + imgfit', blur^T, fold, tanh', mask, ||g|| partial, optimiser
+    launch_blur_bwd_fused<true>(blur_k / 2, gs, s, H, W, blur_sigma, eps, c_fit, accumulate, p, m, v, grad_p, mask, o, partials, st);
+  } else if (blur_k > 0) {
+    const float* gs = garg;
+    if (crop) {
+      float* gsbuf = b.take(n);
+      launch_crop_bwd(D, garg, gsbuf, H, W, crop[0], crop[1], st);
       LAUNCH_CHECK();
       gs = gsbuf;
     }
@@ -1226,7 +1386,7 @@ extern "C" int32_t advx_image_bwd_update(float* p, const float* s, const float* 
   }
   LAUNCH_CHECK();
   if (finalize_norm) {
-    hipLaunchKernelGGL(k_finalize_norm, dim3(1), dim3(kBlock), 0, st, partials, nblk, stats);
+    hipLaunchKernelGGL(k_finalize_norm, dim3(1), dim3(kBlock), 0, st, partials, -1, stats);   // count: left by the producer
     LAUNCH_CHECK();
   }
   return ADVX_OK;
@@ -1237,7 +1397,7 @@ extern "C" int32_t advx_image_bwd_update(float* p, const float* s, const float* 
 extern "C" int32_t advx_update_flush(int64_t n, float* stats, float* update_scratch, void* stream) {
   REQUIRE(n > 0 && stats && update_scratch, ADVX_E_BADARG, "advx_update_flush: bad argument");
   hipLaunchKernelGGL(k_finalize_norm, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, reinterpret_cast<const double*>(update_scratch),
-                     grid_for(n, 2048), stats);
+                     -1, stats);          // the number of partials is whatever the last producer left beside them
   LAUNCH_CHECK();
   return ADVX_OK;
 }
@@ -1538,8 +1698,25 @@ extern "C" int32_t advx_blur_fwd(const float* x, int32_t H, int32_t W, int32_t k
   int32_t rc = check_blur(H, W, k, sigma);
   if (rc) return rc;
   dim3 grid((W + kBlurTile - 1) / kBlurTile, (H + kBlurTile - 1) / kBlurTile, 3);
-  hipLaunchKernelGGL(k_blur<0>, grid, dim3(kBlock), 0, (hipStream_t)stream, x, H, W, k / 2, sigma, (const float*)nullptr, y,
-                     (double*)nullptr);
+  const int r = k / 2;
+  TapBuild none;
+  std::memset(&none, 0, sizeof(none));
+#define ADVX_BLUR_FWD0(R_)                                                                                              \
+  hipLaunchKernelGGL((k_blur_fwd_r<0, R_>), grid, dim3(kBlock), 0, (hipStream_t)stream, x, H, W, sigma, (const float*)nullptr, \
+                     y, (double*)nullptr, 0.0f, none, none, 0)
+  switch ((r >= 1 && r <= kBlurFastMaxR && !g_generic_kernels) ? r : 0) {
+    case 1: ADVX_BLUR_FWD0(1); break;
+    case 2: ADVX_BLUR_FWD0(2); break;
+    case 3: ADVX_BLUR_FWD0(3); break;
+    case 4: ADVX_BLUR_FWD0(4); break;
+    case 5: ADVX_BLUR_FWD0(5); break;
+    case 6: ADVX_BLUR_FWD0(6); break;
+    case 7: ADVX_BLUR_FWD0(7); break;
+    default:
+      hipLaunchKernelGGL(k_blur<0>, grid, dim3(kBlock), 0, (hipStream_t)stream, x, H, W, r, sigma, (const float*)nullptr, y,
+                         (double*)nullptr);
+  }
+#undef ADVX_BLUR_FWD0
   LAUNCH_CHECK();
   return ADVX_OK;
 }
@@ -1564,8 +1741,8 @@ extern "C" int32_t advx_crop_resize_fwd(const float* src, int32_t H, int32_t W, 
   DStage D;
   int32_t rc = build_crop_stage(H, W, crop, b, (hipStream_t)stream, &D);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_stage_fwd, dim3(grid_for(3LL * H * W)), dim3(kBlock), 0, (hipStream_t)stream, D,
-                     src + (size_t)crop[0] * W + crop[1], (long long)H * W, W, dst);
+  launch_stage_fwd(D, src + (size_t)crop[0] * W + crop[1], (long long)H * W, W, dst, nullptr, 0, 0, nullptr, 0, nullptr,
+                   (hipStream_t)stream);
   LAUNCH_CHECK();
   return ADVX_OK;
 }
@@ -1576,8 +1753,7 @@ extern "C" int32_t advx_crop_resize_bwd(const float* gdst, int32_t H, int32_t W,
   DStage D;
   int32_t rc = build_crop_stage(H, W, crop, b, (hipStream_t)stream, &D);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_crop_bwd, dim3(grid_for(3LL * H * W)), dim3(kBlock), 0, (hipStream_t)stream, D, gdst, gsrc, H, W,
-                     crop[0], crop[1]);
+  launch_crop_bwd(D, gdst, gsrc, H, W, crop[0], crop[1], (hipStream_t)stream);
   LAUNCH_CHECK();
   return ADVX_OK;
 }
@@ -1848,14 +2024,14 @@ static const float* prepared_upper_bwd(advx_plan* p, const float* gsum, float* w
 static void prepared_canvases(advx_plan* p, const float* s_img, float* ws, const double* norm_rows, int norm_count,
                               float* stats, hipStream_t st) {
   const DStage& D0 = p->dstage[0];
-  hipLaunchKernelGGL(k_plan_head, dim3(grid_for(3LL * D0.can_h * D0.can_w)), dim3(kBlock), 0, st, D0, s_img,
-                     (long long)D0.src_h * D0.src_w, D0.src_w, ws + p->dplan.canvas_off[0], norm_rows, norm_count, stats);
+  launch_stage_fwd(D0, s_img, (long long)D0.src_h * D0.src_w, D0.src_w, ws + p->dplan.canvas_off[0], nullptr, 0, 0, norm_rows,
+                   norm_count, stats, st);
   for (int k = 1; k < p->info.n_stage; ++k) {
     const DStage& D = p->dstage[k];
     const advx_stage_info& s = p->st[k].info;
     const float* src = ws + p->dplan.canvas_off[s.src - 1];
-    hipLaunchKernelGGL(k_stage_fwd, dim3(grid_for(3LL * D.can_h * D.can_w)), dim3(kBlock), 0, st, D, src,
-                       (long long)D.src_h * D.src_w, D.src_w, ws + p->dplan.canvas_off[k]);
+    launch_stage_fwd(D, src, (long long)D.src_h * D.src_w, D.src_w, ws + p->dplan.canvas_off[k], nullptr, 0, 0, nullptr, 0, nullptr,
+                     st);
   }
 }
 

@@ -1,0 +1,290 @@
+// advx_blur.h - the Gaussian-blur kernels of the trainers' hot chains, radius known at compile time.
+//
+// k_blur (advx_kernels.h) handles any radius up to 15 with run-time loops; the reference's presets use
+// kernel sizes 5 and 9 (attack_model.py:510, attack_clamp_tanh_llava_gblur.sh:37, attack_cross.sh).  With the
+// radius a template parameter
+//   * every thread forms the k normalised weights in registers (same expressions, same order as k_blur: no
+//     LDS round trip, no section in which one thread normalises for the block),
+//   * the tile loads are a fixed number per thread, issued back to back before the first use (k_blur's
+//     run-time loop pays one memory round trip per element),
+//   * the per-pixel state of the epilogue is fetched before the two LDS passes.
+// Element for element the arithmetic is k_blur's (and k_crop_bwd's, k_bwd_update<1>'s, k_tanh_bwd<true>'s): the
+// results are bit-identical, which the GPU tests check against the generic kernels.
+#pragma once
+#include "advx_kernels.h"
+
+namespace advx {
+
+constexpr int kBlurFastMaxR = 7;   // kernel sizes 3..15
+
+template <int R>
+__device__ inline void blur_weights(float sigma, float (&w)[2 * R + 1]) {
+  constexpr int K = 2 * R + 1;
+  // torchvision _get_gaussian_kernel1d: exp(-0.5 (t/sigma)^2) / sum
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    float t = (float)(i - R);
+    float q = t / sigma;
+    w[i] = expf(-0.5f * (q * q));
+  }
+  float sum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < K; ++i) sum += w[i];
+#pragma unroll
+  for (int i = 0; i < K; ++i) w[i] = w[i] / sum;
+}
+
+// ------------------------------------------------------------------------------ forward
+// k_blur<0, IN> with x0 epilogue: s = x0 + blur(IN == 1 ? eps*tanh(in) : in), statistics partials per tile.
+// blockIdx.z == 3: tap-table builder blocks riding in the launch (as in k_blur<0, 1>).
+template <int IN, int R>
+__global__ void __launch_bounds__(kBlock) k_blur_fwd_r(const float* __restrict__ in, int H, int W, float sigma,
+                                                       const float* __restrict__ x0, float* __restrict__ out,
+                                                       double* __restrict__ partials, float scalar, TapBuild taps0,
+                                                       TapBuild taps1, int tap_blocks) {
+  if (blockIdx.z == 3) {
+    const int tb = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    if (tb < 2 * tap_blocks) {
+      const int axis = tb / tap_blocks;
+      build_taps_row(axis == 0 ? taps0 : taps1, (tb - axis * tap_blocks) * (int)blockDim.x + (int)threadIdx.x);
+    }
+    return;
+  }
+  constexpr int K = 2 * R + 1, TS = kBlurTile + 2 * R, NE = TS * TS, NL = (NE + kBlock - 1) / kBlock;
+  constexpr int NR = (TS * kBlurTile + kBlock - 1) / kBlock, NO = kBlurTile * kBlurTile / kBlock;
+  __shared__ float tile[TS][TS + 1];
+  __shared__ float tmp[TS][kBlurTile + 1];
+  float w[K];
+  blur_weights<R>(sigma, w);
+  const int c = blockIdx.z;
+  const int oy0 = blockIdx.y * kBlurTile, ox0 = blockIdx.x * kBlurTile;
+  const float* src = in + (size_t)c * H * W;
+  float v[NL];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int e = (int)threadIdx.x + j * kBlock;
+    v[j] = 0.0f;
+    if (e < NE) {
+      const int ty = e / TS, tx = e - ty * TS;
+      v[j] = src[(size_t)reflect_index(oy0 - R + ty, H) * W + reflect_index(ox0 - R + tx, W)];
+    }
+  }
+  // the epilogue's x0 (four pixels per thread) travels while the tile is transformed and filtered
+  float xv[NO];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {
+    const int e = (int)threadIdx.x + j * kBlock;
+    const int oy = oy0 + e / kBlurTile, ox = ox0 + (e & (kBlurTile - 1));
+    xv[j] = (x0 != nullptr && oy < H && ox < W) ? x0[((size_t)c * H + oy) * W + ox] : 0.0f;
+  }
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int e = (int)threadIdx.x + j * kBlock;
+    if (e < NE) {
+      const int ty = e / TS, tx = e - ty * TS;
+      float t = v[j];
+      if (IN == 1) t = scalar * tanhf(t);
+      tile[ty][tx] = t;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const int e = (int)threadIdx.x + j * kBlock;
+    if (e < TS * kBlurTile) {
+      const int ty = e / kBlurTile, x = e & (kBlurTile - 1);
+      float a = 0.0f;
+#pragma unroll
+      for (int t = 0; t < K; ++t) a += w[t] * tile[ty][x + t];
+      tmp[ty][x] = a;
+    }
+  }
+  __syncthreads();
+  double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {
+    const int e = (int)threadIdx.x + j * kBlock;
+    const int y = e / kBlurTile, x = e & (kBlurTile - 1);
+    const int oy = oy0 + y, ox = ox0 + x;
+    if (oy < H && ox < W) {
+      float a = 0.0f;
+#pragma unroll
+      for (int t = 0; t < K; ++t) a += w[t] * tmp[y + t][x];
+      const size_t o = ((size_t)c * H + oy) * W + ox;
+      if (x0 != nullptr) {
+        const float s = xv[j] + a;
+        out[o] = s;
+        stat_accumulate(s, a, acc);
+      } else {
+        out[o] = a;
+      }
+    }
+  }
+  if (partials != nullptr) {
+    const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    block_sum_store<kStatSlots>(acc, partials + blk * kStatSlots);
+  }
+}
+
+// ----------------------------------------------------------------------------- backward
+// The image-level backward behind the plans' transposed resizes, in ONE launch:
+//   + imgfit'(s)  ->  blur adjoint = zero-padded correlation on the extended domain (k_blur<1, 2>) and fold of
+//   the reflected border (blur_fold)  ->
+//   tanh', [accumulate], and UPDATE: mask, ||g|| partial, optimiser (k_bwd_update<1>) | else the unmasked
+//   gradient (k_tanh_bwd<true>, data parallelism: the all-reduce follows).
+// One block = one 32x32 tile of the IMAGE.  It computes the correlation on the window of the extended
+// domain its pixels fold from: its own rows, rows -R..-1 if it holds rows 1..R, rows up to H-1+R if it holds
+// rows of [H-1-R, H-2] (same for columns) - 32^2 outputs from (32+2R)^2 inputs inside the image, at most
+// (32+3R)^2 from (32+5R)^2 where both borders fold into one tile; zeros outside the image.  No extended-domain
+// buffer in memory, no second pass over the image.  (A crop window's transposed resize stays a launch of its
+// own, k_crop_bwd_t: gathered while the tiles load it cost 36 us instead of 10.6 + 14.)
+struct NormCount {      // slot behind the 2048 norm partials: how many the last producer left (advx_update_flush)
+  static constexpr int kSlot = 2048;
+};
+
+template <int R, bool UPDATE>
+__global__ void __launch_bounds__(kBlock) k_blur_bwd_fused(const float* __restrict__ gsrc, const float* __restrict__ s,
+                                                           int H, int W, float sigma,
+                                                           float eps, float c_fit, int accumulate, float* __restrict__ p,
+                                                           float* __restrict__ m, float* __restrict__ v,
+                                                           float* __restrict__ grad, const float* __restrict__ mask,
+                                                           OptScalars o, double* __restrict__ partials) {
+  // worst case: tile 0 of an image of 32 < H <= 32 + R rows folds from both borders: H + 2R <= 32 + 3R output rows
+  constexpr int K = 2 * R + 1, TI = kBlurTile + 5 * R, TO = kBlurTile + 3 * R;
+  constexpr int NL = (TI * TI + kBlock - 1) / kBlock, NO = kBlurTile * kBlurTile / kBlock;
+  __shared__ float tile[TI][TI + 1];
+  __shared__ float tmp[TI][TO + 1];
+  __shared__ float c2t[TO][TO + 1];
+  float w[K];
+  blur_weights<R>(sigma, w);
+  const int c = blockIdx.z;
+  const int oy0 = blockIdx.y * kBlurTile, ox0 = blockIdx.x * kBlurTile;
+  const int ty_hi = min(oy0 + kBlurTile, H) - 1, tx_hi = min(ox0 + kBlurTile, W) - 1;
+  // output window of the extended domain (inclusive bounds)
+  const int wy0 = (oy0 == 0) ? -R : oy0;
+  const int wx0 = (ox0 == 0) ? -R : ox0;
+  const int wy1 = (ty_hi >= H - 1 - R && oy0 <= H - 2) ? 2 * (H - 1) - max(oy0, H - 1 - R) : ty_hi;
+  const int wx1 = (tx_hi >= W - 1 - R && ox0 <= W - 2) ? 2 * (W - 1) - max(ox0, W - 1 - R) : tx_hi;
+  const int wh = wy1 - wy0 + 1, ww = wx1 - wx0 + 1;          // <= TO
+  const int ih = wh + 2 * R, iw = ww + 2 * R;                // <= TI
+  const size_t plane = (size_t)H * W;
+  // this thread's pixels: state fetched first, used last
+  float pp[NO], mk[NO], mm[NO], vv[NO], g0[NO];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {
+    const int e = (int)threadIdx.x + j * kBlock;
+    const int y = oy0 + e / kBlurTile, x = ox0 + (e & (kBlurTile - 1));
+    pp[j] = mk[j] = mm[j] = vv[j] = g0[j] = 0.0f;
+    if (y < H && x < W) {
+      const size_t i = (size_t)c * plane + (size_t)y * W + x;
+      pp[j] = p[i];
+      if (accumulate) g0[j] = grad[i];
+      if (UPDATE) {
+        mk[j] = mask[i];
+        if (o.apply && o.kind == 0) {
+          mm[j] = m[i];
+          vv[j] = v[i];
+        }
+      }
+    }
+  }
+  // input tile: (gradient w.r.t. s) + imgfit'(s) inside the image, zero outside
+  const unsigned magic = (unsigned)((0x100000000ULL + (unsigned)iw - 1) / (unsigned)iw);   // e / iw for e < 2^16
+  const int ne = ih * iw;
+  float gv[NL], sv[NL];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int e = (int)threadIdx.x + j * kBlock;
+    gv[j] = 0.0f;
+    sv[j] = 0.0f;
+    if (e < ne) {
+      const int iy = (int)__umulhi((unsigned)e, magic), ix = e - iy * iw;
+      const int gy = wy0 - R + iy, gx = wx0 - R + ix;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        const size_t oidx = (size_t)c * plane + (size_t)gy * W + gx;
+        gv[j] = gsrc[oidx];
+        sv[j] = s[oidx];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int e = (int)threadIdx.x + j * kBlock;
+    if (e < ne) {
+      const int iy = (int)__umulhi((unsigned)e, magic), ix = e - iy * iw;
+      const int gy = wy0 - R + iy, gx = wx0 - R + ix;
+      float t = 0.0f;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) t = gv[j] + imgfit_grad(sv[j], c_fit);
+      tile[iy][ix] = t;
+    }
+  }
+  __syncthreads();
+  {
+    // e / ww by multiplication (exact for e < 2^16); a one-column window divides by one
+    const unsigned mw = (ww > 1) ? (unsigned)((0x100000000ULL + (unsigned)ww - 1) / (unsigned)ww) : 0u;
+    for (int e = threadIdx.x; e < ih * ww; e += kBlock) {
+      const int iy = (ww > 1) ? (int)__umulhi((unsigned)e, mw) : e, x = e - iy * ww;
+      float a = 0.0f;
+#pragma unroll
+      for (int t = 0; t < K; ++t) a += w[t] * tile[iy][x + t];
+      tmp[iy][x] = a;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < wh * ww; e += kBlock) {
+      const int y = (ww > 1) ? (int)__umulhi((unsigned)e, mw) : e, x = e - y * ww;
+      float a = 0.0f;
+#pragma unroll
+      for (int t = 0; t < K; ++t) a += w[t] * tmp[y + t][x];
+      c2t[y][x] = a;
+    }
+  }
+  __syncthreads();
+  double nacc[1] = {0.0};
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {
+    const int e = (int)threadIdx.x + j * kBlock;
+    const int y = oy0 + e / kBlurTile, x = ox0 + (e & (kBlurTile - 1));
+    if (y < H && x < W) {
+      // blur_fold: own position, the reflection about the first row / column, about the last
+      int yy[3], xx[3], ny = 0, nx = 0;
+      yy[ny++] = y;
+      if (y >= 1 && y <= R) yy[ny++] = -y;
+      if (y <= H - 2 && y >= H - 1 - R) yy[ny++] = 2 * (H - 1) - y;
+      xx[nx++] = x;
+      if (x >= 1 && x <= R) xx[nx++] = -x;
+      if (x <= W - 2 && x >= W - 1 - R) xx[nx++] = 2 * (W - 1) - x;
+      float gx = 0.0f;
+      for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) gx += c2t[yy[a] - wy0][xx[b] - wx0];
+      const size_t i = (size_t)c * plane + (size_t)y * W + x;
+      float pv = pp[j];
+      const float t = tanhf(pv);
+      float g = (gx * eps) * (1.0f - t * t);
+      if (accumulate) g = g0[j] + g;
+      if (UPDATE) {
+        g = g * mk[j];                          // attack_model.py:336
+        grad[i] = g;
+        nacc[0] += (double)g * (double)g;
+        if (o.apply) {
+          if (o.kind == 0) {
+            float m1 = mm[j], v1 = vv[j];
+            adamw_element(pv, m1, v1, g, o);
+            p[i] = pv; m[i] = m1; v[i] = v1;
+          } else {
+            float sg = (g > 0.0f) ? 1.0f : ((g < 0.0f) ? -1.0f : 0.0f);
+            p[i] = pv - o.lr * sg;
+          }
+        }
+      } else {
+        grad[i] = g;
+      }
+    }
+  }
+  if (UPDATE) {
+    const int blk = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    block_sum_store<1>(nacc, partials + blk);
+    if (blk == 0 && threadIdx.x == 0) partials[NormCount::kSlot] = (double)(gridDim.x * gridDim.y * gridDim.z);
+  }
+}
+
+}  // namespace advx

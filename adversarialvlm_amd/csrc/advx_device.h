@@ -58,7 +58,12 @@ struct DPlan {
   int n_stage;
   long long canvas_off[2];  // float offsets into the workspace
   long long dgrad_off[2];   // gradient buffers of canvases that feed a later stage (-1: none)
-  long long gsum_off;       // batch-reduced gradient in output layout
+  // batch-reduced gradient of the pixel_values, stored in CANVAS order per stage: [copies][3][can_h][can_w]
+  // (copies = temporal duplicates of QWEN, else 1).  k_batch_reduce pays the inverse layout map once per
+  // column it sums; the transposed resizes then gather from plain images instead of walking the layout map
+  // per tap (that index arithmetic was most of their instructions).  -1: the stage's canvas is not emitted.
+  long long gcan_off[2];
+  int gcan_copies[2];
 };
 
 // ------------------------------------------------------------------ layout index maps
@@ -123,8 +128,14 @@ __device__ __host__ inline unsigned emit_colpart(const DEmit& e, int x) {
 __device__ __host__ inline int emit_copies(const DEmit& e) { return e.kind == ADVX_EMIT_QWEN ? e.temporal : 1; }
 __device__ __host__ inline long long emit_copy_stride(const DEmit& e) { return (long long)e.patch * e.patch; }
 
-// inverse: flat index (inside this emit's range) -> canvas element
+// inverse: flat index (inside this emit's range) -> canvas element (and which temporal copy of it)
+__device__ __host__ inline void emit_inverse_t(const DEmit& e, long long idx, int& c, int& y, int& x, int& t);
 __device__ __host__ inline void emit_inverse(const DEmit& e, long long idx, int& c, int& y, int& x) {
+  int t;
+  emit_inverse_t(e, idx, c, y, x, t);
+}
+__device__ __host__ inline void emit_inverse_t(const DEmit& e, long long idx, int& c, int& y, int& x, int& t) {
+  t = 0;
   unsigned r = (unsigned)(idx - e.out_begin);
   if (e.kind == ADVX_EMIT_PLAIN) {
     unsigned W = (unsigned)e.can_w, plane = (unsigned)e.can_h * W;
@@ -138,12 +149,12 @@ __device__ __host__ inline void emit_inverse(const DEmit& e, long long idx, int&
   }
   if (e.kind == ADVX_EMIT_TILES) {
     unsigned T = (unsigned)e.tile, tt = T * T;
-    unsigned t = r / (3u * tt);
-    unsigned q = r - t * 3u * tt;
+    unsigned ti = r / (3u * tt);
+    unsigned q = r - ti * 3u * tt;
     unsigned cc = q / tt;
     q -= cc * tt;
     unsigned ty = q / T, tx = q - ty * T;
-    unsigned tyi = t / (unsigned)e.tiles_w, txi = t - tyi * (unsigned)e.tiles_w;
+    unsigned tyi = ti / (unsigned)e.tiles_w, txi = ti - tyi * (unsigned)e.tiles_w;
     c = (int)cc;
     y = (int)(tyi * T + ty);
     x = (int)(txi * T + tx);
@@ -156,6 +167,7 @@ __device__ __host__ inline void emit_inverse(const DEmit& e, long long idx, int&
   unsigned ct = col / pp;
   unsigned q = col - ct * pp;
   c = (int)(ct / (unsigned)e.temporal);
+  t = (int)(ct - (unsigned)c * (unsigned)e.temporal);
   unsigned ph = q / P, pw = q - ph * P;
   unsigned mw = row % M;
   unsigned r2 = row / M;
@@ -165,6 +177,21 @@ __device__ __host__ inline void emit_inverse(const DEmit& e, long long idx, int&
   unsigned by = blk / bw, bx = blk - by * bw;
   y = (int)((by * M + mh) * P + ph);
   x = (int)((bx * M + mw) * P + pw);
+}
+
+// where the batch-reduced gradient of flat output index idx goes: float offset into the plan workspace
+// (canvas order of the emit's stage), or -1 for the constant padding no emit covers
+__device__ __host__ inline long long gcan_dest(const DPlan& pl, long long idx) {
+  for (int k = 0; k < pl.n_emit; ++k) {
+    const DEmit& e = pl.e[k];
+    if (idx >= e.out_begin && idx < e.out_begin + e.out_count) {
+      if (e.kind == ADVX_EMIT_PLAIN) return pl.gcan_off[e.stage] + (idx - e.out_begin);   // canvas order IS flat order
+      int c, y, x, t;
+      emit_inverse_t(e, idx, c, y, x, t);
+      return pl.gcan_off[e.stage] + (((long long)t * 3 + c) * e.can_h + y) * e.can_w + x;
+    }
+  }
+  return -1;
 }
 
 // ------------------------------------------------------------------------- reductions

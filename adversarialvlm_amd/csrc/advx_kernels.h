@@ -857,10 +857,14 @@ __global__ void __launch_bounds__(kBlock) k_update(float* __restrict__ p, float*
     }
   }
   block_sum_store<1>(acc, partials + blockIdx.x);
+  if (blockIdx.x == 0 && threadIdx.x == 0) partials[2048] = (double)gridDim.x;
 }
 
+// nblk < 0: the producer (k_update, k_bwd_update, k_blur_bwd_fused) left its number of partials in slot kNormCountSlot
+constexpr int kNormCountSlot = 2048;
 __global__ void __launch_bounds__(kBlock) k_finalize_norm(const double* __restrict__ partials, int nblk,
                                                           float* __restrict__ stats) {
+  if (nblk < 0) nblk = (int)partials[kNormCountSlot];
   finalize_norm_block(partials, nblk, stats);
 }
 
@@ -909,6 +913,7 @@ __global__ void __launch_bounds__(kBlock) k_bwd_update(const float* __restrict__
     }
   }
   block_sum_store<1>(acc, partials + blockIdx.x);
+  if (blockIdx.x == 0 && threadIdx.x == 0) partials[2048] = (double)gridDim.x;
 }
 
 // ================================================================= fused (identity plan)

@@ -10,6 +10,17 @@ import torch
 from . import _lib as L
 
 
+class generic_kernels:
+    """Context manager (tests): every call inside takes the general kernels - run-time blur radius, one launch
+    per operation - instead of the specialised / merged ones.  Results must be bit-identical."""
+
+    def __enter__(self):
+        L.check(L.load().advx_set_tuning(L.TUNE_GENERIC_KERNELS, 1), "advx_set_tuning")
+
+    def __exit__(self, *exc):
+        L.check(L.load().advx_set_tuning(L.TUNE_GENERIC_KERNELS, 0), "advx_set_tuning")
+
+
 def _require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:

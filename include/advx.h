@@ -112,6 +112,12 @@ typedef struct advx_plan_info {
 int32_t advx_version(void);
 const char* advx_last_error(void);
 
+/* Development switch.  ADVX_TUNE_GENERIC_KERNELS = 1 makes every call take the general kernels (run-time blur
+ * radius, one launch per operation) instead of the specialised / merged ones; results are bit-identical, which
+ * is what the tests use it for.  Process-wide, not thread-safe. */
+#define ADVX_TUNE_GENERIC_KERNELS 1
+int32_t advx_set_tuning(int32_t what, int32_t value);
+
 /* ------------------------------------------------------------------ plans
  * A plan holds the integer geometry and the float32 tap tables of one
  * (H, W) -> processor layout, computed on the HOST exactly as ATen / the reference do
