@@ -446,8 +446,15 @@ extern "C" int32_t advx_plan_create(const advx_plan_desc* d, advx_plan** out) {
         off += (3LL * p->st[sc].info.can_h * p->st[sc].info.can_w + 63) / 64 * 64;
       }
     }
-  L.gsum_off = off;
-  off += (I.out_numel + 63) / 64 * 64;
+  // batch-reduced gradient, canvas order, one block per emitted stage (DPlan::gcan_off)
+  for (int k = 0; k < 2; ++k) { L.gcan_off[k] = -1; L.gcan_copies[k] = 0; }
+  for (int k = 0; k < L.n_emit; ++k) {
+    const DEmit& e = L.e[k];
+    if (L.gcan_off[e.stage] >= 0) { delete p; return fail(ADVX_E_UNSUPPORTED, "advx_plan_create: two emits publish one canvas"); }
+    L.gcan_off[e.stage] = off;
+    L.gcan_copies[e.stage] = emit_copies(e);
+    off += ((long long)emit_copies(e) * 3LL * e.can_h * e.can_w + 63) / 64 * 64;
+  }
   I.workspace_floats = off;
   *out = p;
   return ADVX_OK;
@@ -726,12 +733,16 @@ extern "C" int32_t advx_emit(advx_plan* p, const float* argument, int32_t batch,
                       stream);
 }
 
-// [live_lo, live_hi): flat indices of a sample whose gradient is needed (defaults: all of it)
+// [live_lo, live_hi): flat indices of a sample whose gradient is needed (defaults: all of it).
+// plan != null: the sums go, in canvas order, into the plan workspace `out` (DPlan::gcan_off); else out[i].
 static int32_t launch_batch_reduce(const float* g, int batch, long long n, float* out, hipStream_t st,
-                                   long long live_lo = 0, long long live_hi = -1, int io = 0) {
+                                   long long live_lo = 0, long long live_hi = -1, int io = 0, const DPlan* plan = nullptr) {
   REQUIRE(aligned16(g) && aligned16(out), ADVX_E_BADARG, "batch_reduce: pointers must be 16-byte aligned");
   REQUIRE(io == 0 || (n & 3) == 0, ADVX_E_UNSUPPORTED, "batch_reduce: half gradients need rows that are a multiple of 4");
   if (live_hi < 0 || live_hi > n) live_hi = n;
+  DPlan none;
+  std::memset(&none, 0, sizeof(none));
+  const DPlan& pl = plan ? *plan : none;
   if ((n & 3) == 0) {
     long long q_lo = live_lo >> 2, q_hi = (live_hi + 3) >> 2;
     if (q_hi <= q_lo) return ADVX_OK;
@@ -739,8 +750,11 @@ static int32_t launch_batch_reduce(const float* g, int batch, long long n, float
     // what is read here, B x (live columns) x 16 bytes: beyond the Infinity Cache it is streamed past it
     const double read_bytes = (double)batch * (double)(q_hi - q_lo) * (io == 0 ? 16.0 : 8.0);
     const int code = io + ((read_bytes > 256.0 * 1024 * 1024) ? 3 : 0);   // io_load4: +3 = non-temporal
-#define ADVX_BR(T) \
-  hipLaunchKernelGGL(k_batch_reduce<T>, dim3(blocks), dim3(kBlock), 0, st, (const void*)g, batch, n, out, q_lo, q_hi)
+#define ADVX_BR(T)                                                                                                             \
+  do {                                                                                                                         \
+    if (plan) hipLaunchKernelGGL((k_batch_reduce<T, true>), dim3(blocks), dim3(kBlock), 0, st, (const void*)g, batch, n, out, q_lo, q_hi, pl); \
+    else hipLaunchKernelGGL((k_batch_reduce<T, false>), dim3(blocks), dim3(kBlock), 0, st, (const void*)g, batch, n, out, q_lo, q_hi, pl);     \
+  } while (0)
     switch (code) {
       case 0: ADVX_BR(0); break;
       case 1: ADVX_BR(1); break;
@@ -752,10 +766,22 @@ static int32_t launch_batch_reduce(const float* g, int batch, long long n, float
 #undef ADVX_BR
   } else {
     // rows are not 16-byte aligned: scalar columns (test-sized inputs only)
-    hipLaunchKernelGGL(k_batch_reduce_scalar, dim3(grid_for(n)), dim3(kBlock), 0, st, g, batch, n, out);
+    if (plan) hipLaunchKernelGGL(k_batch_reduce_scalar<true>, dim3(grid_for(n)), dim3(kBlock), 0, st, g, batch, n, out, pl);
+    else hipLaunchKernelGGL(k_batch_reduce_scalar<false>, dim3(grid_for(n)), dim3(kBlock), 0, st, g, batch, n, out, pl);
   }
   LAUNCH_CHECK();
   return ADVX_OK;
+}
+
+// batch-reduce the gradient of a plan's pixel_values into its workspace (canvas order; a half gradient is widened)
+static int32_t reduce_to_canvas(advx_plan* p, const void* grad_out, int batch, float* ws, hipStream_t st) {
+  long long lo, hi;
+  plan_live_range(p, &lo, &hi);   // what lies outside is constant padding whose gradient goes nowhere
+  return launch_batch_reduce(reinterpret_cast<const float*>(grad_out), batch, p->info.out_numel, ws, st, lo, hi, p->io, &p->dplan);
+}
+static CanvasGrad stage_grad(const advx_plan* p, int k, const float* ws) {
+  const float* dgrad = (p->dplan.dgrad_off[k] >= 0) ? ws + p->dplan.dgrad_off[k] : nullptr;
+  return canvas_grad_of(p->dplan, k, p->dstage[k].can_h, p->dstage[k].can_w, ws, dgrad);
 }
 
 extern "C" int32_t advx_collect(advx_plan* p, const float* grad_out, int32_t batch, float* grad_argument,
@@ -766,26 +792,16 @@ extern "C" int32_t advx_collect(advx_plan* p, const float* grad_out, int32_t bat
   int32_t rc = advx_plan_upload(p, stream);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const float* gsum = grad_out;
-  if (batch > 1 || p->io != 0) {   // a half gradient is widened by the (one-row) reduction
-    // the emits cover [lo, hi); what lies outside is constant padding whose gradient goes nowhere
-    long long lo, hi;
-    plan_live_range(p, &lo, &hi);
-    rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st, lo, hi, p->io);
-    if (rc) return rc;
-    gsum = ws + p->dplan.gsum_off;
-  }
+  rc = reduce_to_canvas(p, grad_out, batch, ws, st);
+  if (rc) return rc;
   for (int k = p->info.n_stage - 1; k >= 0; --k) {
     const DStage& D = p->dstage[k];
     const advx_stage_info& s = p->st[k].info;
-    const float* dgrad = (p->dplan.dgrad_off[k] >= 0) ? ws + p->dplan.dgrad_off[k] : nullptr;
     float* gsrc = (s.src == 0) ? grad_argument : ws + p->dplan.dgrad_off[s.src - 1];
     int acc = (s.src == 0) ? accumulate : 0;
-    long long n = 3LL * D.src_h * D.src_w;
-    (void)n;
     const int rowblk = 128;   // two waves along x: little waste on the last chunk of a 336 / 512 / 672-wide row
-    hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D, p->dplan, k, gsum, dgrad, gsrc,
-                       (long long)D.src_h * D.src_w, D.src_w, acc);
+    hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D, stage_grad(p, k, ws),
+                       gsrc, (long long)D.src_h * D.src_w, D.src_w, acc);
     LAUNCH_CHECK();
   }
   return ADVX_OK;
@@ -861,7 +877,7 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
     ADVX_WINDOW_SWITCH(T0, ADVX_SFM)
 #undef ADVX_SFM
   } else {
-    hipLaunchKernelGGL(k_stage0_fwd_multi, dim3(grid_for(biggest), n), dim3(kBlock), 0, st, mf, argument,
+    hipLaunchKernelGGL(k_stage0_fwd_multi, dim3((max_w + kRowBlock - 1) / kRowBlock, max_h, n), dim3(kRowBlock), 0, st, mf, argument,
                        (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats);
   }
   LAUNCH_CHECK();
@@ -925,18 +941,10 @@ extern "C" int32_t advx_collect_multi(int32_t n, advx_plan* const* plans, const 
     REQUIRE(grad_outs[i], ADVX_E_BADARG, "advx_collect_multi: null gradient");
     rc = advx_plan_upload(p, stream);
     if (rc) return rc;
-    const float* gsum = reinterpret_cast<const float*>(grad_outs[i]);
-    if (batches[i] > 1 || p->io != 0) {
-      long long lo, hi;
-      plan_live_range(p, &lo, &hi);
-      rc = launch_batch_reduce(gsum, batches[i], p->info.out_numel, wss[i] + p->dplan.gsum_off, st, lo, hi, p->io);
-      if (rc) return rc;
-      gsum = wss[i] + p->dplan.gsum_off;
-    }
+    rc = reduce_to_canvas(p, grad_outs[i], batches[i], wss[i], st);
+    if (rc) return rc;
     mb.st[i] = p->dstage[0];
-    mb.pl[i] = p->dplan;
-    mb.gsum[i] = gsum;
-    mb.dgrad[i] = (p->dplan.dgrad_off[0] >= 0) ? wss[i] + p->dplan.dgrad_off[0] : nullptr;
+    mb.cg[i] = stage_grad(p, 0, wss[i]);
   }
   const int rowblk = 128;
   for (int i = 0; i < n; ++i) {
@@ -945,10 +953,9 @@ extern "C" int32_t advx_collect_multi(int32_t n, advx_plan* const* plans, const 
       const DStage& D = p->dstage[k];
       const advx_stage_info& s = p->st[k].info;
       REQUIRE(s.src >= 1, ADVX_E_UNSUPPORTED, "advx_collect_multi: only stage 0 may read the image");
-      const float* dgrad = (p->dplan.dgrad_off[k] >= 0) ? wss[i] + p->dplan.dgrad_off[k] : nullptr;
       float* gsrc = wss[i] + p->dplan.dgrad_off[s.src - 1];
-      hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D, p->dplan, k,
-                         mb.gsum[i], dgrad, gsrc, (long long)D.src_h * D.src_w, D.src_w, 0);
+      hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D,
+                         stage_grad(p, k, wss[i]), gsrc, (long long)D.src_h * D.src_w, D.src_w, 0);
       LAUNCH_CHECK();
     }
   }
@@ -2005,19 +2012,17 @@ extern "C" int32_t advx_prepared_rows(const advx_plan* p, int32_t* rows_after_pr
   return ADVX_OK;
 }
 
-// backward of the stages above stage 0 (Phi-3.5's global view) into their dgrad buffers; returns
-// the gradient that reaches canvas 0 from them (null for one-stage plans)
-static const float* prepared_upper_bwd(advx_plan* p, const float* gsum, float* ws, hipStream_t st) {
+// backward of the stages above stage 0 (Phi-3.5's global view) into their dgrad buffers (stage 0 then reads them
+// through stage_grad)
+static void prepared_upper_bwd(advx_plan* p, float* ws, hipStream_t st) {
   for (int k = p->info.n_stage - 1; k >= 1; --k) {
     const DStage& D = p->dstage[k];
     const advx_stage_info& s = p->st[k].info;
-    const float* dgrad = (p->dplan.dgrad_off[k] >= 0) ? ws + p->dplan.dgrad_off[k] : nullptr;
     float* gsrc = ws + p->dplan.dgrad_off[s.src - 1];
     const int rowblk = 128;
-    hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D, p->dplan, k, gsum,
-                       dgrad, gsrc, (long long)D.src_h * D.src_w, D.src_w, 0);
+    hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D, stage_grad(p, k, ws),
+                       gsrc, (long long)D.src_h * D.src_w, D.src_w, 0);
   }
-  return (p->dplan.dgrad_off[0] >= 0) ? ws + p->dplan.dgrad_off[0] : nullptr;
 }
 
 // canvases of the next step from s: head (stage 0, with the pending ||g|| reduction) + later stages
@@ -2102,14 +2107,11 @@ extern "C" int32_t advx_prepared_bwd(advx_plan* p, const float* grad_out, int32_
   REQUIRE(rows_in >= 0 && rows_in <= std::max(f.tail_blocks, f.prep_blocks), ADVX_E_BADARG, "advx_prepared_bwd: rows_in out of range");
   const DStage& D = p->dstage[0];
   const long long n = 3LL * p->info.in_h * p->info.in_w;
-  long long lo, hi;
-  plan_live_range(p, &lo, &hi);
-  rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st, lo, hi, p->io);
+  rc = reduce_to_canvas(p, grad_out, batch, ws, st);
   if (rc) return rc;
-  const float* gsum = ws + p->dplan.gsum_off;
-  const float* dgrad0 = prepared_upper_bwd(p, gsum, ws, st);
+  prepared_upper_bwd(p, ws, st);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_plan_tail, dim3(f.tail_blocks), dim3(kBlock), 0, st, D, p->dplan, gsum, dgrad0, pp, x0, eps,
+  hipLaunchKernelGGL(k_plan_tail, dim3(f.tail_blocks), dim3(kBlock), 0, st, D, stage_grad(p, 0, ws), pp, x0, eps,
                      imgfit_scale / (float)n, mask, m, v, grad_p, to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows,
                      (const double*)f.img_rows[parity], (int)rows_in, stats);
   LAUNCH_CHECK();
@@ -2136,15 +2138,12 @@ static int32_t prepared_grad_impl(advx_plan* p, const float* grad_out, int32_t b
           "advx_prepared_bwd_grad: rows_in out of range");
   const DStage& D = p->dstage[0];
   const long long n = 3LL * p->info.in_h * p->info.in_w;
-  long long lo, hi;
-  plan_live_range(p, &lo, &hi);
-  int32_t rc = launch_batch_reduce(grad_out, batch, p->info.out_numel, ws + p->dplan.gsum_off, st, lo, hi, p->io);
+  int32_t rc = reduce_to_canvas(p, grad_out, batch, ws, st);
   if (rc) return rc;
-  const float* dgrad0 = prepared_upper_bwd(p, ws + p->dplan.gsum_off, ws, st);
+  prepared_upper_bwd(p, ws, st);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_plan_tail_grad, dim3(f.tail_blocks), dim3(kBlock), 0, st, D, p->dplan,
-                     (const float*)(ws + p->dplan.gsum_off), dgrad0, pp, x0, eps, imgfit_scale / (float)n, grad_p,
-                     (const double*)f.img_rows[parity], (int)rows_in, stats);
+  hipLaunchKernelGGL(k_plan_tail_grad, dim3(f.tail_blocks), dim3(kBlock), 0, st, D, stage_grad(p, 0, ws), pp, x0, eps,
+                     imgfit_scale / (float)n, grad_p, (const double*)f.img_rows[parity], (int)rows_in, stats);
   LAUNCH_CHECK();
   return ADVX_OK;
 }

@@ -433,95 +433,59 @@ __global__ void __launch_bounds__(kBlock) k_stage_fwd_img(DStage st, const float
 }
 
 // ========================================================================== stage bwd
-// gradient of canvas element (c,y,x): sum over the emits that publish it (+ temporal
-// copies) plus the gradient that a later stage propagated into this canvas.
-__device__ inline float canvas_grad_at(const DPlan& pl, int stage, const float* __restrict__ gsum,
-                                       const float* __restrict__ dgrad, int can_h, int can_w, int c, int y, int x) {
+// Gradient of one stage's canvas as the transposed resizes read it: `copies` images in canvas order left by
+// k_batch_reduce (DPlan::gcan_off; QWEN publishes every canvas element `temporal` times) plus the gradient a
+// later stage propagated into this canvas (dgrad).
+struct CanvasGrad {
+  const float* g;        // [copies][3][can_h][can_w], null when the canvas is not emitted
+  int copies;
+  long long copy_stride; // 3 * can_h * can_w
+  const float* dgrad;    // [3][can_h][can_w] or null
+};
+__device__ __host__ inline CanvasGrad canvas_grad_of(const DPlan& pl, int stage, int can_h, int can_w, const float* ws,
+                                                     const float* dgrad) {
+  CanvasGrad cg;
+  cg.g = (pl.gcan_off[stage] >= 0) ? ws + pl.gcan_off[stage] : nullptr;
+  cg.copies = (pl.gcan_off[stage] >= 0) ? pl.gcan_copies[stage] : 0;
+  cg.copy_stride = 3LL * can_h * can_w;
+  cg.dgrad = dgrad;
+  return cg;
+}
+
+// gradient of canvas element at offset o = (c*can_h + y)*can_w + x: the copies in order, then dgrad
+__device__ inline float canvas_grad_at(const CanvasGrad& cg, size_t o) {
   float g = 0.0f;
-  for (int k = 0; k < pl.n_emit; ++k) {
-    const DEmit& e = pl.e[k];
-    if (e.stage != stage) continue;
-    long long idx = emit_index(e, c, y, x);
-    int copies = emit_copies(e);
-    long long cs = emit_copy_stride(e);
-    for (int t = 0; t < copies; ++t) g += gsum[idx + t * cs];
-  }
-  if (dgrad != nullptr) g += dgrad[((size_t)c * can_h + y) * can_w + x];
+  for (int t = 0; t < cg.copies; ++t) g += cg.g[(size_t)t * cg.copy_stride + o];
+  if (cg.dgrad != nullptr) g += cg.dgrad[o];
   return g;
 }
 
-constexpr int kBwdCols = 8;   // widest window the separable index path of k_stage_bwd keeps in registers
-
 // gradient of SOURCE element (c, ys, xs) of a stage: transposed-tap gather over the canvas
 // gradient (no atomics), divided by std where the stage normalises
-__device__ inline float stage_bwd_value(const DStage& st, const DPlan& pl, int stage, const float* __restrict__ gsum,
-                                        const float* __restrict__ dgrad, int c, int ys, int xs) {
-  {
-    int oy = st.tth.start[ys], oyc = st.tth.count[ys];
-    int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
-    const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
-    const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
-    float v = 0.0f;
-    if (oxc <= kBwdCols) {
-      // the layout map is separable (row part + column part): the divisions are paid once per
-      // visited row / column of the window instead of once per element; same summation order
-      // as canvas_grad_at
-      unsigned colp[2][kBwdCols];
-      bool live[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        live[k] = (k < pl.n_emit) && (pl.e[k].stage == stage);
-#pragma unroll
-        for (int b = 0; b < kBwdCols; ++b)
-          colp[k][b] = (live[k] && b < oxc) ? (unsigned)pl.e[k].out_begin + emit_colpart(pl.e[k], st.off_x + ox + b) : 0u;
-      }
-      for (int a = 0; a < oyc; ++a) {
-        const int y = st.off_y + oy + a;
-        unsigned rowp[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) rowp[k] = live[k] ? emit_rowpart(pl.e[k], c, y) : 0u;
-        float h = 0.0f;
-#pragma unroll
-        for (int b = 0; b < kBwdCols; ++b) {
-          if (b < oxc) {
-            float g = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-              if (!live[k]) continue;
-              const unsigned idx = rowp[k] + colp[k][b];
-              const int copies = emit_copies(pl.e[k]);
-              const unsigned cs = (unsigned)emit_copy_stride(pl.e[k]);
-              for (int t = 0; t < copies; ++t) g += gsum[idx + (unsigned)t * cs];
-            }
-            if (dgrad != nullptr) g += dgrad[((size_t)c * st.can_h + y) * st.can_w + st.off_x + ox + b];
-            h += wx[b] * g;
-          }
-        }
-        v += wy[a] * h;
-      }
-    } else {
-      for (int a = 0; a < oyc; ++a) {
-        float h = 0.0f;
-        for (int b = 0; b < oxc; ++b)
-          h += wx[b] * canvas_grad_at(pl, stage, gsum, dgrad, st.can_h, st.can_w, c, st.off_y + oy + a, st.off_x + ox + b);
-        v += wy[a] * h;
-      }
-    }
-    if (st.normalise) v = v / st.stdv[c];
-    return v;
+__device__ inline float stage_bwd_value(const DStage& st, const CanvasGrad& cg, int c, int ys, int xs) {
+  const int oy = st.tth.start[ys], oyc = st.tth.count[ys];
+  const int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
+  const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
+  const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
+  float v = 0.0f;
+  for (int a = 0; a < oyc; ++a) {
+    const size_t row = ((size_t)c * st.can_h + (st.off_y + oy + a)) * st.can_w + st.off_x + ox;
+    float h = 0.0f;
+    for (int b = 0; b < oxc; ++b) h += wx[b] * canvas_grad_at(cg, row + b);
+    v += wy[a] * h;
   }
+  if (st.normalise) v = v / st.stdv[c];
+  return v;
 }
 
 // one thread per SOURCE element.  Grid = (column chunks, source rows, channels): the row of a
-// workgroup is uniform, so its taps, weights and the row part of the layout map are scalar
-// work, and no thread divides to find its pixel.
-__global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, DPlan pl, int stage, const float* __restrict__ gsum,
-                                                      const float* __restrict__ dgrad, float* __restrict__ gsrc,
+// workgroup is uniform, so its taps and weights are scalar work, and no thread divides to find its pixel.
+__global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, CanvasGrad cg, float* __restrict__ gsrc,
                                                       long long gsrc_cstride, int gsrc_rstride, int accumulate) {
   const int c = blockIdx.z, ys = blockIdx.y;
   const int xs = blockIdx.x * blockDim.x + threadIdx.x;
   if (xs < st.src_w) {
-    float v = stage_bwd_value(st, pl, stage, gsum, dgrad, c, ys, xs);
+    float v = stage_bwd_value(st, cg, c, ys, xs);
     size_t o = (size_t)c * gsrc_cstride + (size_t)ys * gsrc_rstride + xs;
     gsrc[o] = accumulate ? (gsrc[o] + v) : v;
   }
@@ -543,29 +507,76 @@ struct MultiFwd {
 struct MultiBwd {
   int n;
   DStage st[kMaxMulti];
-  DPlan pl[kMaxMulti];
-  const float* gsum[kMaxMulti];
-  const float* dgrad[kMaxMulti];
+  CanvasGrad cg[kMaxMulti];
 };
 
+// canvas[c,y,x] for c = 0..2 of one position: taps and weights looked up once (stage_fwd_value per channel)
+__device__ inline void stage_fwd_value3(const DStage& st, const float* __restrict__ src, long long src_cstride, int src_rstride,
+                                        int y, int x, float (&out)[3]) {
+  const int ry = y - st.off_y, rx = x - st.off_x;
+  float v[3];
+  if (ry >= 0 && ry < st.res_h && rx >= 0 && rx < st.res_w) {
+    const int ys = st.th.start[ry], yc = st.th.count[ry];
+    const int xs = st.tw.start[rx], xc = st.tw.count[rx];
+    const float* wy = st.th.w + (size_t)ry * st.th.stride;
+    const float* wx = st.tw.w + (size_t)rx * st.tw.stride;
+    v[0] = v[1] = v[2] = 0.0f;
+    if (!st.inner_axis_h) {
+      for (int a = 0; a < yc; ++a) {
+        const float* rowp = src + (size_t)(ys + a) * src_rstride + xs;
+        const float wa = wy[a];
+        float h[3] = {0.0f, 0.0f, 0.0f};
+        for (int b = 0; b < xc; ++b) {
+          const float wb = wx[b];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) h[c] += wb * rowp[(size_t)c * src_cstride + b];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] += wa * h[c];
+      }
+    } else {
+      for (int b = 0; b < xc; ++b) {
+        const float wb = wx[b];
+        float h[3] = {0.0f, 0.0f, 0.0f};
+        for (int a = 0; a < yc; ++a) {
+          const float wa = wy[a];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) h[c] += wa * src[(size_t)c * src_cstride + (size_t)(ys + a) * src_rstride + xs + b];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] += wb * h[c];
+      }
+    }
+  } else {
+    v[0] = v[1] = v[2] = st.pad_value;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[c] = st.normalise ? (v[c] - st.mean[c]) / st.stdv[c] : v[c];
+}
+
+// grid = (column chunks of the widest canvas, rows of the tallest, plans)
 __global__ void __launch_bounds__(kBlock) k_stage0_fwd_multi(MultiFwd mf, const float* __restrict__ src, long long src_cstride,
                                                              int src_rstride, const double* __restrict__ img_partials, int nblk,
                                                              long long n_img, float* __restrict__ stats) {
-  // nblk > 0: the image kernels of the same call left statistics partials; block (0,0) reduces them
+  // nblk > 0: the image kernels of the same call left statistics partials; block (0,0,0) reduces them
   // here (k_emit, the consumer of sigma, is a later launch)
-  if (blockIdx.x == 0 && blockIdx.y == 0 && nblk > 0) finalize_image_block<true>(img_partials, nblk, n_img, stats);
-  const int k = blockIdx.y;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && nblk > 0) finalize_image_block<true>(img_partials, nblk, n_img, stats);
+  const int k = blockIdx.z;
   const DStage& st = mf.st[k];
-  const long long n = 3LL * st.can_h * st.can_w;
-  float* __restrict__ canvas = mf.canvas[k];
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    int c = (int)((unsigned)i / ((unsigned)st.can_h * (unsigned)st.can_w));
-    int rem = (int)((unsigned)i - (unsigned)c * (unsigned)st.can_h * (unsigned)st.can_w);
-    int y = rem / st.can_w, x = rem - y * st.can_w;
-    canvas[i] = stage_fwd_value(st, src, src_cstride, src_rstride, c, y, x);
+  const int y = blockIdx.y;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (y < st.can_h && x < st.can_w) {
+    float v[3];
+    stage_fwd_value3(st, src, src_cstride, src_rstride, y, x, v);
+    float* __restrict__ canvas = mf.canvas[k];
+    const size_t plane = (size_t)st.can_h * st.can_w;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) canvas[(size_t)c * plane + (size_t)y * st.can_w + x] = v[c];
   }
 }
 
+// backward: one thread per (c, y, x) - at 113 k positions a thread per position leaves the SIMDs two waves each
+// and the three-channel form (stage_bwd_value3) is latency-bound: measured 47 us against 27
 __global__ void __launch_bounds__(kBlock) k_stage0_bwd_multi(MultiBwd mb, float* __restrict__ gsrc, long long gsrc_cstride,
                                                              int gsrc_rstride, int accumulate) {
   const int c = blockIdx.z, ys = blockIdx.y;
@@ -575,7 +586,7 @@ __global__ void __launch_bounds__(kBlock) k_stage0_bwd_multi(MultiBwd mb, float*
 #pragma unroll
     for (int k = 0; k < kMaxMulti; ++k) {
       if (k < mb.n) {
-        const float t = stage_bwd_value(mb.st[k], mb.pl[k], 0, mb.gsum[k], mb.dgrad[k], c, ys, xs);
+        const float t = stage_bwd_value(mb.st[k], mb.cg[k], c, ys, xs);
         v = (k == 0) ? t : v + t;
       }
     }
@@ -782,20 +793,60 @@ __device__ inline float4 batch_column_sum(const void* __restrict__ g, int batch,
 
 // Only the float4 columns [q_lo, q_hi) are reduced: the gradient of the constant padding tiles
 // (llama32processor.py:344-346, phi3processor.py:232-235) is never read.
-template <int IO>   // io_load4 code: 0 / 1 / 2 cached f32 / f16 / bf16, 3 / 4 / 5 the same non-temporal
+// CANVAS: the sums are stored in canvas order into the plan workspace `out` (gcan_dest) - one inverse layout
+// map per column here instead of one per tap in the transposed resizes that read them; else out[i] = sum.
+// -> workspace offset of flat index i0 if i0..i0+3 are four consecutive canvas elements of one emit, else -1
+__device__ inline long long reduce_dest4(const DPlan& pl, long long i0) {
+  // common case: the four indices lie in one emit and in one run of consecutive canvas elements (a whole PLAIN
+  // canvas; a tile row whose width is a multiple of 4; the inside of a 14-pixel patch row) - ONE inverse map
+  for (int k = 0; k < pl.n_emit; ++k) {
+    const DEmit& e = pl.e[k];
+    if (i0 >= e.out_begin && i0 + 3 < e.out_begin + e.out_count) {
+      if (e.kind == ADVX_EMIT_PLAIN) return pl.gcan_off[e.stage] + (i0 - e.out_begin);
+      int c, y, x, tc;
+      emit_inverse_t(e, i0, c, y, x, tc);
+      const unsigned run = (e.kind == ADVX_EMIT_TILES) ? (unsigned)e.tile : (unsigned)e.patch;
+      if ((unsigned)x % run + 3u < run) return pl.gcan_off[e.stage] + (((long long)tc * 3 + c) * e.can_h + y) * e.can_w + x;
+      return -1;
+    }
+  }
+  return -1;
+}
+__device__ inline void reduce_store4(const DPlan& pl, float* __restrict__ ws, long long i0, long long d0, float4 t) {
+  if (d0 >= 0) {
+    if ((d0 & 3) == 0) {
+      *reinterpret_cast<float4*>(ws + d0) = t;
+    } else {
+      ws[d0] = t.x; ws[d0 + 1] = t.y; ws[d0 + 2] = t.z; ws[d0 + 3] = t.w;
+    }
+    return;
+  }
+  const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long d = gcan_dest(pl, i0 + k);
+    if (d >= 0) ws[d] = tv[k];
+  }
+}
+
+template <int IO, bool CANVAS>   // io_load4 code: 0 / 1 / 2 cached f32 / f16 / bf16, 3 / 4 / 5 the same non-temporal
 __global__ void __launch_bounds__(kBlock) k_batch_reduce(const void* __restrict__ g, int batch, long long n,
-                                                         float* __restrict__ out, long long q_lo, long long q_hi) {
+                                                         float* __restrict__ out, long long q_lo, long long q_hi, DPlan pl) {
   __shared__ float4 part[kBlock / kWave][kWave];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   const long long q = q_lo + (long long)blockIdx.x * kWave + lane;  // float4 column
   const long long n4 = n >> 2;
+  // CANVAS: where this column's sums go (one inverse layout map), worked out while the stream is in flight
+  long long dest = -1;
+  if (CANVAS && wid == 0 && q < q_hi) dest = reduce_dest4(pl, q << 2);
   float4 a = make_float4(0, 0, 0, 0);
   if (q < q_hi) a = batch_column_sum<IO>(g, batch, n, q << 2, wid, kBlock / kWave);
   part[wid][lane] = a;
   __syncthreads();
   if (wid == 0 && q < q_hi) {
     float4 t = f4add(f4add(f4add(part[0][lane], part[1][lane]), part[2][lane]), part[3][lane]);
-    *reinterpret_cast<float4*>(out + (q << 2)) = t;
+    if (CANVAS) reduce_store4(pl, out, q << 2, dest, t);
+    else *reinterpret_cast<float4*>(out + (q << 2)) = t;
   }
   // scalar tail (n not a multiple of 4; float32 only): last block, first threads
   if ((IO == 0 || IO == 3) && q_hi == n4 && blockIdx.x == gridDim.x - 1) {
@@ -804,19 +855,30 @@ __global__ void __launch_bounds__(kBlock) k_batch_reduce(const void* __restrict_
     if (i < n) {
       float s = 0.0f;
       for (int b = 0; b < batch; ++b) s += reinterpret_cast<const float*>(g)[(size_t)b * n + i];
-      out[i] = s;
+      if (CANVAS) {
+        const long long d = gcan_dest(pl, i);
+        if (d >= 0) out[d] = s;
+      } else {
+        out[i] = s;
+      }
     }
   }
 }
 
 // rows not 16-byte aligned (n % 4 != 0): one thread per column, test-sized inputs only
+template <bool CANVAS>
 __global__ void __launch_bounds__(kBlock) k_batch_reduce_scalar(const float* __restrict__ g, int batch, long long n,
-                                                                float* __restrict__ out) {
+                                                                float* __restrict__ out, DPlan pl) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     float s = 0.0f;
     for (int b = 0; b < batch; ++b) s += g[(size_t)b * n + i];
-    out[i] = s;
+    if (CANVAS) {
+      const long long d = gcan_dest(pl, i);
+      if (d >= 0) out[d] = s;
+    } else {
+      out[i] = s;
+    }
   }
 }
 
@@ -1153,8 +1215,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_update(float* __restrict__ p, 
 // A plan with a second stage fed by the first canvas (Phi-3.5: bicubic global view of the HD
 // canvas) adds k_stage_bwd of that stage before the tail (its gradient reaches the tail through
 // `dgrad`) and k_stage_fwd of it after the head.
-__global__ void __launch_bounds__(kBlock) k_plan_tail(DStage st, DPlan pl, const float* __restrict__ gsum,
-                                                      const float* __restrict__ dgrad, float* __restrict__ p, const float* __restrict__ x0, float eps,
+__global__ void __launch_bounds__(kBlock) k_plan_tail(DStage st, CanvasGrad cg, float* __restrict__ p, const float* __restrict__ x0, float eps,
                                                       float c_fit, const float* __restrict__ mask, float* __restrict__ m,
                                                       float* __restrict__ v, float* __restrict__ grad_p, OptScalars o,
                                                       float* __restrict__ s_next, double* __restrict__ img_rows_out,
@@ -1179,7 +1240,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_tail(DStage st, DPlan pl, const
     const int ys = (int)(rem / (unsigned)st.src_w), xs = (int)(rem - (unsigned)ys * (unsigned)st.src_w);
     const float t = tanhf(pp);
     const float s = xv + eps * t;
-    const float gs = stage_bwd_value(st, pl, 0, gsum, dgrad, c, ys, xs);
+    const float gs = stage_bwd_value(st, cg, c, ys, xs);
     float gp = ((gs + imgfit_grad(s, c_fit)) * eps) * (1.0f - t * t);
     gp = gp * mk;
     nacc[0] = (double)gp * (double)gp;
@@ -1206,8 +1267,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_tail(DStage st, DPlan pl, const
 //                      (block 0 still reduces the statistics of the current image);
 //   <all-reduce>
 //   k_plan_update    : mask, ||g|| partial, optimiser, s_next and its statistics partials.
-__global__ void __launch_bounds__(kBlock) k_plan_tail_grad(DStage st, DPlan pl, const float* __restrict__ gsum,
-                                                           const float* __restrict__ dgrad, const float* __restrict__ p, const float* __restrict__ x0,
+__global__ void __launch_bounds__(kBlock) k_plan_tail_grad(DStage st, CanvasGrad cg, const float* __restrict__ p, const float* __restrict__ x0,
                                                            float eps, float c_fit, float* __restrict__ grad_p,
                                                            const double* __restrict__ img_rows_in, int img_rows_in_count,
                                                            float* __restrict__ stats) {
@@ -1221,7 +1281,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_tail_grad(DStage st, DPlan pl, 
     const int ys = (int)(rem / (unsigned)st.src_w), xs = (int)(rem - (unsigned)ys * (unsigned)st.src_w);
     const float t = tanhf(p[i]);
     const float s = x0[i] + eps * t;
-    const float gs = stage_bwd_value(st, pl, 0, gsum, dgrad, c, ys, xs);
+    const float gs = stage_bwd_value(st, cg, c, ys, xs);
     grad_p[i] = ((gs + imgfit_grad(s, c_fit)) * eps) * (1.0f - t * t);
   }
 }
