@@ -397,7 +397,8 @@ def build_parser():
                    help="log loss_resaved (the reference's second forward on the re-saved image) every N iterations; 0 = off")
     p.add_argument("--no_noise_on_padding", dest="noise_on_padding", action="store_false",
                    help="keep the constant padding tiles of Mllama / Phi-3.5 exact zeros instead of adding noise to them "
-                        "as the reference does (both models mask those tiles out)")
+                        "as the reference does; a deviation: the Llama-3.2 vision encoder does attend to its padding tiles, "
+                        "tests/test_mllama_padding_visibility.py)")
     p.add_argument("--suffix_only_ce", action="store_true",
                    help="compute the logits of the target positions only (logits_to_keep) and their cross entropy in "
                         "the HIP library: same loss, no [B, S, V] logits tensor")

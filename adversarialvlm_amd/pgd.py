@@ -46,7 +46,8 @@ class PixelPGD:
         "peer" (advx_comm_*: IPC-mapped segments over xGMI, in-library kernels), "rccl"
         (torch.distributed) or "auto" (peer if it sets up and passes its self-test here).
         noise_on_padding: True = the reference's tensor, noise also on the constant padding tiles
-        of Mllama / Phi-3.5 (which both models mask out); False = those tiles stay exact zeros in
+        of Mllama / Phi-3.5; False = a deviation from it (Llama-3.2's vision encoder does attend to its padding
+        tiles, tests/test_mllama_padding_visibility.py): those tiles stay exact zeros in
         pixel_values buffers the engine keeps across steps and rewrites only where an image is
         (no generator work and no traffic for 3/4 resp. 2/7 of the tensor; the tensor returned by
         forward() is then only valid until the next forward()).

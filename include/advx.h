@@ -169,8 +169,10 @@ int32_t advx_emit(advx_plan* plan, const float* argument, int32_t batch, const f
                   float* out, float* workspace, int64_t workspace_floats, void* stream);
 /* The constant padding tiles of Mllama / Phi-3.5 (llama32processor.py:344-346,
  * phi3processor.py:232-235) are 3/4 resp. 2/7 of `out`.  The reference adds noise to them too
- * (randn_like of the whole tensor, attack_model.py:320) although both models mask those tiles
- * out, so neither loss nor gradient can see them.
+ * (randn_like of the whole tensor, attack_model.py:320).  Keeping them zero is a DEVIATION, not a free
+ * optimisation: Phi-3.5 drops the crops beyond image_sizes, but the Llama-3.2 vision encoder masks only
+ * padding-to-padding attention, so the real tile's tokens attend to the padding tiles and the loss depends
+ * (weakly) on their pixels - tests/test_mllama_padding_visibility.py shows it on a random model.
  *   ADVX_PAD_NOISE : advx_emit's behaviour - the whole tensor is written, padding = 0 + noise.
  *   ADVX_PAD_KEEP  : only the elements the plan's emits cover are written; the caller keeps
  *                    `out` across steps and has zeroed its padding once (padding stays exactly
