@@ -261,6 +261,8 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
                                  original_image=original_image, processor=processor, device=device,
                                  target_text=target_text,
                                  rng=random.Random(seed * 1000003 + rank) if world > 1 else None)
+    if hasattr(inputs_processor, "bind_geometry"):
+        inputs_processor.bind_geometry(adv_processor, H, W)     # index tensors from the plan, not from an HF image pass
     logger = JsonlLogger(os.path.join(exp_path, "metrics.jsonl"), use_wandb and rank == 0,
                          config=dict(learning_rate=lr, batch_size=batch_size, epsilon=epsilon, sigma=sigma), name=exp_name) \
         if rank == 0 else None

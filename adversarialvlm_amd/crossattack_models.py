@@ -126,6 +126,9 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
         Image.fromarray((mask.permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8)).save(os.path.join(exp_path, "mask.png"))
 
     plans = [ap.plan_for(H, W) for ap in adv_processors]
+    for ip, ap in zip(inputs_processors, adv_processors):
+        if hasattr(ip, "bind_geometry"):
+            ip.bind_geometry(ap, H, W)                           # index tensors from the plan, not from an HF image pass
     engine = PixelPGD(x_0, plans, epsilon=attack_norm, lr=lr, sigma0=0.001, mask=mask,                   # :299 hard-codes 0.001
                       scheduler_step_size=scheduler_step_size, scheduler_gamma=scheduler_gamma,
                       grad_accum_steps=grad_accum_steps, blur_kernel=gblur_kernel_size if use_gaussian_blur else None,

@@ -52,6 +52,11 @@ class DifferentiableProcessorBase:
     def _extras(self, plan: Plan) -> dict:
         return {}
 
+    def index_tensors(self, H: int, W: int, batch: int) -> dict:
+        """Integer side tensors of `batch` copies of an H x W image as the HF image processor of this model family
+        returns them (none for LLaVA)."""
+        return {}
+
     def process(self, image: torch.Tensor) -> dict:
         """image: float tensor [3,H,W] in [0,1] on a ROCm device (may require grad)."""
         plan = self.plan_for(image.shape[1], image.shape[2])
@@ -101,6 +106,7 @@ class AdvInputsBase:
             self.target_texts = [target_text]
             self.target_text = target_text
         self._cache: Dict[Tuple[str, str], dict] = {}
+        self._geometry = None       # (differentiable processor, H, W): source of the index tensors, see bind_geometry
         self.update_target_tokens()
 
     # ---- per-plugin hooks
@@ -143,6 +149,16 @@ class AdvInputsBase:
         out = model(**inputs, logits_to_keep=self.suffix_length + 1)
         return suffix_cross_entropy(out.logits, self.target)
 
+    # ---- index tensors from the plan geometry
+    def bind_geometry(self, adv_processor, H: int, W: int):
+        """The integer side tensors of a batch (Mllama aspect_ratio_ids / aspect_ratio_mask and the tile axis of
+        cross_attention_mask, Qwen2-VL image_grid_thw, Phi-3.5 image_sizes) then come from the SAME geometry the
+        pixel_values are made with (`adv_processor.index_tensors`, pinned bit for bit against the HF image
+        processors by tests/test_index_tensors.py) instead of from an HF pass over the original image - the
+        reference keeps whatever its per-step processor(...) call returned (llama32processor.py:119-147,
+        qwen2VLprocessor.py:68-96, phi3processor.py:88-95)."""
+        self._geometry = (adv_processor, int(H), int(W))
+
     # ---- cached batch assembly (replaces llavaprocessor.py:80-108)
     def _sample(self, question: str) -> dict:
         key = (question, self.target_text)
@@ -179,16 +195,31 @@ class AdvInputsBase:
                 continue
             if torch.is_tensor(v):
                 if k == "cross_attention_mask":
-                    # [1, S, images, tiles]: per-token; pad along S like the ids
+                    # [1, S, images, tiles]: per-token; pad along S like the ids.  Left padding: pad tokens precede
+                    # the image, rows of zeros.  Right padding: HF lets the last image's span run to the padded
+                    # length (convert_sparse_cross_attention_mask_to_dense), i.e. the last row repeats.
                     rows = []
                     for s in samples:
                         c = s[k][0]
                         padn = L - int(c.shape[0])
-                        z = torch.zeros((padn,) + tuple(c.shape[1:]), dtype=c.dtype)
-                        rows.append(torch.cat([z, c], 0) if left else torch.cat([c, z], 0))
+                        if left:
+                            z = torch.zeros((padn,) + tuple(c.shape[1:]), dtype=c.dtype)
+                            rows.append(torch.cat([z, c], 0))
+                        else:
+                            rows.append(torch.cat([c, c[-1:].expand((padn,) + tuple(c.shape[1:]))], 0))
                     data[k] = torch.stack(rows)
                 else:
                     data[k] = torch.cat([s[k] for s in samples], dim=0)
+        if self._geometry is not None:
+            adv, H, W = self._geometry
+            own = adv.index_tensors(H, W, len(samples))
+            for k, v in own.items():
+                if k in data and torch.is_tensor(v):
+                    data[k] = v.to(data[k].dtype)
+            if "cross_attention_mask" in data and "aspect_ratio_mask" in own:
+                # which tokens see the image comes from the tokenizer pass; WHICH TILES exist from the plan
+                seen = (data["cross_attention_mask"].amax(dim=-1, keepdim=True) > 0).to(data["cross_attention_mask"].dtype)
+                data["cross_attention_mask"] = seen * own["aspect_ratio_mask"][:, None, :, :].to(seen.dtype)
         return BatchFeature(data).to(torch.device(self.device))
 
     def get_inputs_inference(self, img, question: Optional[str] = None):

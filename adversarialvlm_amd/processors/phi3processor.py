@@ -67,3 +67,8 @@ class DifferentiablePhi3VImageProcessor(DifferentiableProcessorBase):
     def _extras(self, plan):
         i = plan.info
         return {"image_sizes": [[int(i.image_h), int(i.image_w)]], "num_img_tokens": [int(i.num_img_tokens)]}
+
+    def index_tensors(self, H, W, batch):
+        """image_sizes [B,2] (height, width of the HD canvas; phi3processor.py:244-248, :281)."""
+        i = self.plan_for(H, W).info
+        return {"image_sizes": torch.tensor([[int(i.image_h), int(i.image_w)]] * batch, dtype=torch.long)}

@@ -372,9 +372,52 @@ def golden_mllama_restated():
     save("mllama_restated.npz", **arrays)
 
 
+MLLAMA_GEOMETRIES = [  # (H, W, tile, max_image_tiles)
+    (336, 336, 560, 4), (512, 512, 560, 4), (300, 1000, 560, 4), (1000, 300, 560, 4), (700, 700, 560, 4), (200, 1500, 560, 4),
+    (1352, 1988, 560, 4), (90, 70, 560, 4), (561, 560, 560, 4), (1120, 1120, 560, 4), (1121, 400, 560, 4), (2000, 2000, 560, 4),
+    (560, 1680, 560, 4), (60, 90, 32, 4), (150, 500, 64, 4), (448, 448, 448, 4), (300, 1000, 224, 6), (900, 250, 224, 8),
+]
+QWEN_GEOMETRIES = [  # (H, W, min_pixels, max_pixels), patch 14 / merge 2 / temporal 2 as in the released configs
+    (336, 336, 56 * 56, 28 * 28 * 1280), (512, 512, 56 * 56, 28 * 28 * 1280), (60, 90, 28 * 28, 28 * 28 * 16),
+    (120, 150, 28 * 28, 28 * 28 * 36), (70, 70, 28 * 28, 28 * 28 * 36), (1352, 1988, 56 * 56, 28 * 28 * 1280),
+    (40, 1000, 56 * 56, 28 * 28 * 1280), (1000, 40, 56 * 56, 28 * 28 * 1280), (28, 28, 56 * 56, 28 * 28 * 1280),
+    (2000, 3000, 56 * 56, 28 * 28 * 1280), (337, 335, 56 * 56, 28 * 28 * 1280), (97, 130, 28 * 28, 28 * 28 * 64),
+]
+
+
+def golden_index_tensors():
+    """the integer side tensors the HF image processors hand to the models, from the HF classes
+    themselves (PIL backends, constructed offline with explicit parameters): Mllama aspect_ratio_ids /
+    aspect_ratio_mask / num_tiles (the reference keeps them from processor(...) at llama32processor.py:119-147) and
+    Qwen2-VL image_grid_thw (qwen2VLprocessor.py:68-96).  The plans' geometry and the plugins' index_tensors()
+    must reproduce them exactly (tests/test_index_tensors.py)."""
+    from PIL import Image
+    from transformers.models.mllama.image_processing_pil_mllama import MllamaImageProcessorPil
+    from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
+    ids, masks, tiles = [], [], []
+    for H, W, tile, max_tiles in MLLAMA_GEOMETRIES:
+        ip = MllamaImageProcessorPil(size={"height": tile, "width": tile}, max_image_tiles=max_tiles, image_mean=CLIP_MEAN,
+                                     image_std=CLIP_STD)
+        out = ip(images=[Image.fromarray(np.full((H, W, 3), 128, np.uint8))], return_tensors="pt")
+        assert tuple(out["pixel_values"].shape) == (1, 1, max_tiles, 3, tile, tile)
+        ids.append(int(out["aspect_ratio_ids"][0, 0]))
+        m = out["aspect_ratio_mask"][0, 0].tolist()
+        masks.append(m + [-1] * (8 - len(m)))
+        tiles.append(int(out["num_tiles"][0][0]))
+    grids = []
+    for H, W, lo, hi in QWEN_GEOMETRIES:
+        qp = Qwen2VLImageProcessorPil(patch_size=14, merge_size=2, temporal_patch_size=2, min_pixels=lo, max_pixels=hi)
+        out = qp(images=[Image.fromarray(np.full((H, W, 3), 128, np.uint8))], return_tensors="pt")
+        grids.append(out["image_grid_thw"][0].tolist() + [int(out["pixel_values"].shape[0]), int(out["pixel_values"].shape[1])])
+    save("index_tensors.npz", mllama_geometry=np.asarray(MLLAMA_GEOMETRIES, np.int64), mllama_aspect_ratio_ids=np.asarray(ids, np.int64),
+         mllama_aspect_ratio_mask=np.asarray(masks, np.int64), mllama_num_tiles=np.asarray(tiles, np.int64),
+         qwen_geometry=np.asarray(QWEN_GEOMETRIES, np.int64), qwen_grid_thw_rows_cols=np.asarray(grids, np.int64))
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present: fixtures can only be regenerated in the build container")
+    golden_index_tensors()        # before the torchvision stub of import_reference() exists
     llava, qwen, phi3 = import_reference()
     golden_llava(llava)
     golden_qwen(qwen)
