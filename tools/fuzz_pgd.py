@@ -144,12 +144,13 @@ def oracle_sensitivity(x0, procs, batches, steps, mask, kw, perturb):
 def run_case(T, dev, rng, seed):
     """-> (verdict, desc, worst): verdict is "ok", "ill-conditioned" or a failure text.
 
-    "ill-conditioned": everything that is a smooth function of the inputs agrees (pixel_values, the
-    gradient, its norm, the image-fit loss: 1e-7 level) and the quantities that moved past the bar
-    move just as far between two runs of the ORACLE whose upstream gradients differ by 3e-7 - the
-    size of the rounding differences between the two implementations (`oracle_sensitivity`).  Seen
-    for AdamW's g/(|g|+1e-8) at a pixel whose gradient is of the order of adam_eps (edge tap of a
-    crop window, border of a mask), and for one pixel's uint8 truncation flipping in the quantiser."""
+    Pixels of p at which the optimiser is discontinuous (|g| of the order of adam_eps: edge tap of a crop window,
+    border of a mask) are handled inside `_trajectory` (`_check_p`: the gradient must agree elementwise at the pixel
+    and have been tiny there; every accepted pixel is printed).  "ill-conditioned" remains for the statistics: everything
+    that is a smooth function of the inputs agrees (the gradient, its norm, the image-fit loss: 1e-7 level) and the
+    quantities that moved past the bar (sigma, qerr_mean: one pixel's uint8 truncation flipping in the quantiser) move
+    just as far between two runs of the ORACLE whose upstream gradients differ by 3e-7 - the size of the rounding
+    differences between the two implementations (`oracle_sensitivity`)."""
     desc, procs, batches, steps, mask, kw = draw_case(rng)
     x0 = torch.rand(3, desc["H"], desc["W"], generator=torch.Generator().manual_seed(seed)) * 1.1 - 0.05
     try:
