@@ -14,6 +14,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: full-size GPU cases whose oracle takes tens of seconds of CPU")
 
 
 def pytest_collection_modifyitems(config, items):
