@@ -92,6 +92,10 @@ SIGNATURES = {
     "advx_fused_fwd_io": (_I32, [_P, _P, _P, _F, _I32, _P, _I32, _U64, _U64, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P]),
     "advx_fused_bwd_io": (_I32, [_P, _P, _I32, _I32, _P, _P, _F, _F, _P, _P, _P, _P, C.POINTER(OptScalars), _P, _P, _P, _P,
                                  _P]),
+    "advx_sched_bytes": (_I64, [_I32]),
+    "advx_sched_fill": (_I32, [_P, _I32, C.POINTER(OptScalars), _U64]),
+    "advx_fused_fwd_sched": (_I32, [_P, _P, _P, _F, _I32, _U64, _U64, _P, _I32, _P, _P, _P, _P, _P, _P]),
+    "advx_fused_bwd_sched": (_I32, [_P, _P, _I32, _I32, _P, _P, _F, _F, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P]),
     "advx_fused_update": (_I32, [_P, _P, _P, _P, _P, _P, _P, _F, C.POINTER(OptScalars), _P, _P, _P, _P]),
     "advx_fused_scratch_floats": (_I64, [_P]),
     "advx_fused_flush": (_I32, [_P, _P, _P, _I32, _P]),

@@ -1466,7 +1466,7 @@ static FusedGeom fused_geom(const advx_plan* p) {
 static int32_t fused_fwd_impl(advx_plan* p, const float* pp, const float* x0, float eps, int32_t batch,
                               const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset, void* out,
                               int32_t io, float* s_buf, float* v_buf, int32_t prepared, int32_t parity, float* stats,
-                              float* scratch, void* stream) {
+                              float* scratch, void* stream, SchedDev* sched = nullptr) {
   REQUIRE(p && pp && x0 && out && stats && scratch && s_buf && v_buf, ADVX_E_BADARG, "advx_fused_fwd: null argument");
   REQUIRE(io >= 0 && io <= 2, ADVX_E_BADARG, "advx_fused_fwd: io_dtype must be ADVX_IO_F32 / F16 / BF16");
   REQUIRE(parity == 0 || parity == 1, ADVX_E_BADARG, "advx_fused_fwd: parity must be 0 or 1");
@@ -1491,7 +1491,7 @@ static int32_t fused_fwd_impl(advx_plan* p, const float* pp, const float* x0, fl
 #define ADVX_FF(N, T)                                                                                            \
   ADVX_LAUNCH_TIMED(PROF_FWD, (k_fused_fwd<N, T>), grid, dim3(kBlock), st, (const float*)v_buf, (const float*)s_buf, x0, n, \
                     batch, bps, stats, unit_noise, seed, offset, out, f.hdr, f.img_rows[parity],                  \
-                    (const double*)f.norm_partials)
+                    (const double*)f.norm_partials, sched)
 #define ADVX_FF_IO(N) \
   do { if (io == 0) ADVX_FF(N, 0); else if (io == 1) ADVX_FF(N, 1); else ADVX_FF(N, 2); } while (0)
   if (noise == 0) ADVX_FF_IO(0); else if (noise == 1) ADVX_FF_IO(1); else ADVX_FF_IO(2);
@@ -1520,7 +1520,7 @@ extern "C" int32_t advx_fused_fwd_io(advx_plan* p, const float* pp, const float*
 static int32_t fused_bwd_impl(advx_plan* p, const void* g, int32_t io, int32_t batch, float* pp, const float* x0, float eps,
                               float imgfit_scale, const float* mask, float* m, float* v, float* grad_p,
                               const advx_opt_scalars* opt, float* s_next, float* v_buf, float* stats, float* scratch,
-                              void* stream) {
+                              void* stream, SchedDev* sched = nullptr) {
   REQUIRE(p && g && pp && x0 && grad_p && scratch && stats, ADVX_E_BADARG, "advx_fused_bwd: null argument");
   REQUIRE(io >= 0 && io <= 2, ADVX_E_BADARG, "advx_fused_bwd: io_dtype must be ADVX_IO_F32 / F16 / BF16");
   REQUIRE(advx_fused_supported(p), ADVX_E_UNSUPPORTED, "advx_fused_bwd: plan is not an identity LLaVA plan");
@@ -1538,7 +1538,7 @@ static int32_t fused_bwd_impl(advx_plan* p, const void* g, int32_t io, int32_t b
 #define ADVX_FB(U, T, O)                                                                                          \
   ADVX_LAUNCH_TIMED(PROF_BWD, (k_fused_bwd<U, T>), dim3(f.bwd_blocks), dim3(kBlock), st, g, batch, pp, x0, eps,    \
                     fused_geom(p), c_fit, mask, m, v, grad_p, O, s_next, v_buf, f.norm_partials, stats, f.hdr,     \
-                    (const double*)f.img_partials)
+                    (const double*)f.img_partials, sched)
 #define ADVX_FB_IO(U, O) \
   do { if (io == 0) ADVX_FB(U, 0, O); else if (io == 1) ADVX_FB(U, 1, O); else ADVX_FB(U, 2, O); } while (0)
     ADVX_FB_IO(true, to_dev(opt));
@@ -1572,6 +1572,50 @@ extern "C" int32_t advx_fused_bwd_io(advx_plan* p, const void* g, int32_t io_dty
 // grid of the one-launch step: one wave per 64 pixels, four waves per block, at most 2048
 // blocks (then waves loop over several groups); never more blocks than the row buffers hold
 // (one partial row per block, f.bwd_blocks rows)
+// ------------------------------------------------------------- hipGraph replay of the pair
+// The per-step scalars of the pair (Philox offset, optimiser scalars) come from device memory (SchedDev), so the
+// SAME launches can be replayed by a graph: capture advx_fused_bwd_sched + advx_fused_fwd_sched for two steps
+// (the s buffers alternate) and replay.
+extern "C" int64_t advx_sched_bytes(int32_t n_opt) { return (int64_t)sizeof(SchedDev) + (int64_t)std::max(n_opt, 1) * (int64_t)sizeof(OptScalars); }
+extern "C" int32_t advx_sched_fill(void* host_buf, int32_t n_opt, const advx_opt_scalars* table, uint64_t first_step) {
+  REQUIRE(host_buf && table && n_opt >= 1, ADVX_E_BADARG, "advx_sched_fill: bad argument");
+  SchedDev h;
+  std::memset(&h, 0, sizeof(h));
+  h.fwd_step = first_step;
+  h.bwd_step = first_step;
+  h.first_step = first_step;
+  h.n_opt = n_opt;
+  std::memcpy(host_buf, &h, sizeof(h));
+  OptScalars* o = reinterpret_cast<OptScalars*>(reinterpret_cast<char*>(host_buf) + sizeof(SchedDev));
+  for (int k = 0; k < n_opt; ++k) {
+    int32_t rc = check_opt(&table[k], reinterpret_cast<const float*>(1), reinterpret_cast<const float*>(1));
+    if (rc) return rc;
+    REQUIRE(table[k].apply, ADVX_E_UNSUPPORTED, "advx_sched_fill: the fused update always steps");
+    o[k] = to_dev(&table[k]);
+  }
+  return ADVX_OK;
+}
+extern "C" int32_t advx_fused_fwd_sched(advx_plan* p, const float* pp, const float* x0, float eps, int32_t batch, uint64_t seed,
+                                        uint64_t offset_base, void* out, int32_t io_dtype, float* s_buf, float* v_buf,
+                                        float* stats, float* scratch, void* sched, void* stream) {
+  REQUIRE(sched, ADVX_E_BADARG, "advx_fused_fwd_sched: null schedule");
+  return fused_fwd_impl(p, pp, x0, eps, batch, nullptr, 1, seed, offset_base, out, io_dtype, s_buf, v_buf, /*prepared=*/1, 0,
+                        stats, scratch, stream, reinterpret_cast<SchedDev*>(sched));
+}
+extern "C" int32_t advx_fused_bwd_sched(advx_plan* p, const void* g, int32_t io_dtype, int32_t batch, float* pp, const float* x0,
+                                        float eps, float imgfit_scale, const float* mask, float* m, float* v, float* grad_p,
+                                        int32_t opt_kind, float* s_next, float* v_buf, float* stats, float* scratch,
+                                        void* sched, void* stream) {
+  REQUIRE(sched, ADVX_E_BADARG, "advx_fused_bwd_sched: null schedule");
+  advx_opt_scalars any;          // validated per entry by advx_sched_fill; the kernel replaces it
+  std::memset(&any, 0, sizeof(any));
+  any.kind = opt_kind;
+  any.apply = 1;
+  any.bias2_sqrt = 1.0f;
+  return fused_bwd_impl(p, g, io_dtype, batch, pp, x0, eps, imgfit_scale, mask, m, v, grad_p, &any, s_next, v_buf, stats,
+                        scratch, stream, reinterpret_cast<SchedDev*>(sched));
+}
+
 static int step_grid(long long n) {
   const int cap = 2048;
   long long groups = (n + kWave - 1) / kWave;

@@ -991,6 +991,21 @@ __global__ void __launch_bounds__(kBlock) k_bwd_update(const float* __restrict__
 //                    the UPDATED p: s_{t+1}, v_{t+1}.  Block 0 reduces the statistics of s_t
 //                    (rotating SIGMA <- old QERR_STD first), beside the other blocks' stream.
 // k_fused_prep does the preparation alone (first step, or after p changed elsewhere).
+// Per-step scalars in DEVICE memory, for hipGraph replay of the pair (advx_fused_*_sched): a captured launch
+// cannot receive a new Philox offset or new optimiser scalars as kernel arguments, so the forward reads its step
+// index from `fwd_step` (offset = offset_base + fwd_step) and the backward takes opt[bwd_step - first_step].  The
+// hand-over needs no atomics: every block of the forward reads fwd_step while its block (0,0) publishes it as
+// bwd_step; every block of the backward reads bwd_step while its block 0 writes fwd_step = bwd_step + 1; kernel
+// boundaries order the rest.
+struct SchedDev {
+  unsigned long long fwd_step;
+  unsigned long long bwd_step;
+  unsigned long long first_step;   // step index of opt[0]
+  int n_opt;                       // entries of opt[]; a backward beyond them reuses the last one
+  int pad;
+  // followed by OptScalars opt[n_opt]
+};
+
 struct FusedGeom {
   int plane;        // H*W, multiple of 4
   float mean[3];
@@ -1018,9 +1033,14 @@ __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ 
                                                       unsigned long long seed, unsigned long long offset,
                                                       void* __restrict__ out, FusedHeader* __restrict__ hdr,
                                                       double* __restrict__ img_partials,
-                                                      const double* __restrict__ norm_partials) {
+                                                      const double* __restrict__ norm_partials, SchedDev* sched) {
   const long long n4 = n >> 2;
   const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (sched != nullptr) {
+    const unsigned long long t = sched->fwd_step;       // uniform: a scalar load
+    offset += t;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sched->bwd_step = t;
+  }
   // sigma of THIS step = quantise error of the previous image = slot QERR_STD (1); it is
   // only rewritten by the next k_fused_bwd.  Block (0,0) below writes slot 7 only.
   const float sigma = (NOISE != 0) ? stats[1] : 0.0f;
@@ -1081,8 +1101,16 @@ __global__ void __launch_bounds__(kBlock) k_fused_bwd(const void* __restrict__ g
                                                       float* __restrict__ s_next, float* __restrict__ v_buf,
                                                       double* __restrict__ norm_partials, float* __restrict__ stats,
                                                       FusedHeader* __restrict__ hdr,
-                                                      const double* __restrict__ img_partials) {
+                                                      const double* __restrict__ img_partials, SchedDev* sched) {
   __shared__ float4 part4[kBlock / kWave][kWave];
+  if (sched != nullptr) {
+    const unsigned long long t = sched->bwd_step;
+    long long k = (long long)(t - sched->first_step);
+    if (k < 0) k = 0;
+    if (k > sched->n_opt - 1) k = sched->n_opt - 1;
+    o = reinterpret_cast<const OptScalars*>(sched + 1)[k];
+    if (blockIdx.x == 0 && threadIdx.x == 0) sched->fwd_step = t + 1;
+  }
   const long long n = 3LL * geo.plane;
   const long long n4 = n >> 2;
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;

@@ -340,6 +340,39 @@ def fused_bwd_dp(plan, exchange, grad_out, batch, p, x0, epsilon, imgfit_scale, 
                                        float(exchange.timeout_s), _stream(p)), "advx_fused_bwd_dp")
 
 
+def make_sched(opt_table, first_step, device):
+    """Device copy of the per-step scalars of `len(opt_table)` steps starting at `first_step` (advx_sched_fill)."""
+    n = len(opt_table)
+    lib = L.load()
+    host = C.create_string_buffer(int(lib.advx_sched_bytes(n)))
+    arr = (L.OptScalars * n)(*opt_table)
+    L.check(lib.advx_sched_fill(host, n, arr, int(first_step)), "advx_sched_fill")
+    return torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(device)
+
+
+def fused_fwd_sched(plan, p, x0, epsilon, batch, seed, out, s_buf, v_buf, stats, scratch, sched, offset_base=0):
+    """advx_fused_fwd_io (prepared, in-kernel noise) with the Philox offset read from `sched`: replayable."""
+    _require_cuda(p, x0, out, s_buf, v_buf, stats, scratch, sched)
+    if not out.is_contiguous() or out.numel() != batch * plan.out_numel:
+        raise L.AdvxError("out must be a contiguous [batch, out_numel] tensor")
+    L.check(L.load().advx_fused_fwd_sched(plan.handle, L.ptr(p), L.ptr(x0), float(epsilon), int(batch), int(seed), int(offset_base),
+                                          L.ptr(out), io_code(out.dtype), L.ptr(s_buf), L.ptr(v_buf), L.ptr(stats),
+                                          L.ptr(scratch), L.ptr(sched), _stream(p)), "advx_fused_fwd_sched")
+    return out
+
+
+def fused_bwd_sched(plan, grad_out, batch, p, x0, epsilon, imgfit_scale, mask, m, v, grad_p, opt_kind, s_next, v_buf, stats,
+                    scratch, sched):
+    """advx_fused_bwd_io with the optimiser scalars of this step read from `sched`: replayable."""
+    _require_cuda(grad_out, p, x0, mask, grad_p, s_next, v_buf, stats, scratch, sched)
+    if not grad_out.is_contiguous() or grad_out.numel() != batch * plan.out_numel:
+        raise L.AdvxError("grad_out must be a contiguous [batch, out_numel] tensor")
+    L.check(L.load().advx_fused_bwd_sched(plan.handle, L.ptr(grad_out), io_code(grad_out.dtype), int(batch), L.ptr(p), L.ptr(x0),
+                                          float(epsilon), float(imgfit_scale), L.ptr(mask), L.ptr(m), L.ptr(v), L.ptr(grad_p),
+                                          int(opt_kind), L.ptr(s_next), L.ptr(v_buf), L.ptr(stats), L.ptr(scratch),
+                                          L.ptr(sched), _stream(p)), "advx_fused_bwd_sched")
+
+
 def fused_update(plan, p, m, v, grad_p, mask, x0, epsilon, opt, s_next, v_buf, scratch):
     """DP tail of the pair: mask, ||g|| partials, optimiser step, preparation of the next forward."""
     _require_cuda(p, grad_p, mask, x0, s_next, v_buf, scratch)

@@ -405,6 +405,49 @@ class PixelPGD:
         self._last = None
         return take_step
 
+    # ------------------------------------------------- hipGraph replay of the pair
+    def make_schedule(self, n_steps):
+        """Per-step scalars of the next `n_steps` optimiser steps in device memory (Philox offsets are the step
+        indices, the AdamW / StepLR scalars are derived here in double exactly as backward_update derives them):
+        what forward_sched / backward_update_sched read instead of kernel arguments, so that their launches can be
+        captured once and replayed (torch.cuda.graph).  Pair chain, one rank, in-kernel noise."""
+        if self.mode != "pair" or self.exchange:
+            raise L.AdvxError("make_schedule: the replayable form exists for the single-rank pair chain")
+        keep = (self.lr, self.opt_steps)
+        table = []
+        for _ in range(int(n_steps)):
+            table.append(self._opt_scalars(True))
+            self._scheduler_step()
+        self.lr, self.opt_steps = keep
+        return ops.make_sched(table, self.iteration, self.p.device)
+
+    def forward_sched(self, batch, sched, out):
+        """forward() of the pair into the caller's `out` [batch, out_numel], Philox offset from `sched`."""
+        if not self.prepared:
+            raise L.AdvxError("forward_sched needs a prepared engine: run one eager forward() first")
+        ops.fused_fwd_sched(self.plans[0], self.p, self.x0, self.eps, batch, self.seed, out, self.s_bufs[self.s_cur], self.v_buf,
+                            self.stats, self.fused_scratch, sched)
+        self.s = self.s_bufs[self.s_cur]
+        self._last = dict(batches=[batch])
+        return out
+
+    def backward_update_sched(self, grad, sched):
+        """backward_update() of the pair with the optimiser scalars of the step from `sched`.  Host-side counters
+        (iteration, scheduler) are NOT advanced here - a replay would not advance them either: call
+        `advance(steps)` after running or replaying."""
+        B = self._last["batches"][0] if self._last else grad.shape[0]
+        nxt = 1 - self.s_cur
+        ops.fused_bwd_sched(self.plans[0], grad, B, self.p, self.x0, self.eps, self.imgfit_scale(), self.mask, self.m, self.v,
+                            self.grad, self.opt_kind, self.s_bufs[nxt], self.v_buf, self.stats, self.fused_scratch, sched)
+        self.s_cur = nxt
+        self._last = None
+
+    def advance(self, steps):
+        """Bring the host-side counters in line with `steps` steps taken through a schedule (eagerly or by replay)."""
+        for _ in range(int(steps)):
+            self._scheduler_step()
+            self.iteration += 1
+
     # ------------------------------------------------------------------ readout
     def stats_dict(self):
         """Synchronising readout of the device statistics (logging cadence only).

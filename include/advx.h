@@ -14,8 +14,11 @@
  *    stated otherwise (tensor.data_ptr()).  The library allocates device memory only
  *    inside opaque plans (tap/index tables of one geometry).
  *  - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); launches are
- *    asynchronous, never synchronise, and are safe to capture in a hipGraph once the plan
- *    has been uploaded (advx_plan_upload).
+ *    asynchronous and never synchronise.  They can be captured in a hipGraph once the plan
+ *    has been uploaded (advx_plan_upload), but a REPLAY repeats the captured kernel arguments:
+ *    entry points that take per-step scalars by value (Philox offset, optimiser scalars, crop
+ *    window) replay the step they were captured with.  advx_fused_fwd_sched / advx_fused_bwd_sched
+ *    read those scalars from device memory and are the forms meant for replay.
  *  - image tensors are CHW, 3 channels; "stats" is a device float[ADVX_STATS_N].
  */
 #ifndef ADVX_H
@@ -328,6 +331,25 @@ int32_t advx_fused_bwd_io(advx_plan* plan, const void* grad_out, int32_t io_dtyp
                           float* stats, float* scratch, void* stream);
 int64_t advx_fused_scratch_floats(const advx_plan* plan);
 int32_t advx_fused_flush(advx_plan* plan, float* stats, float* scratch, int32_t image_too, void* stream);
+
+/* hipGraph replay of the pair.  A captured launch cannot be handed a new Philox offset or new optimiser scalars,
+ * so these two forms read them from DEVICE memory: `sched` = advx_sched_bytes(n) bytes, filled on the host by
+ * advx_sched_fill (step counters + the optimiser scalars of steps first_step .. first_step + n - 1, derived by
+ * the host in double exactly as for advx_fused_bwd) and copied to the device by the caller.  The forward uses
+ * offset = offset_base + step, the backward table entry step - first_step, and the pair advances the counter
+ * itself (no atomics: each kernel reads one word and writes the other; kernel boundaries order them).  Results
+ * are those of advx_fused_fwd_io (prepared = 1, in-kernel noise) / advx_fused_bwd_io with the same scalars, bit
+ * for bit.  Capture: advx_fused_bwd_sched(t), advx_fused_fwd_sched(t+1), advx_fused_bwd_sched(t+1),
+ * advx_fused_fwd_sched(t+2) with the two s buffers alternating, then replay (tests/test_gpu_graph.py). */
+int64_t advx_sched_bytes(int32_t n_opt);
+int32_t advx_sched_fill(void* host_buf, int32_t n_opt, const advx_opt_scalars* table, uint64_t first_step);
+int32_t advx_fused_fwd_sched(advx_plan* plan, const float* p, const float* x0, float epsilon, int32_t batch,
+                             uint64_t seed, uint64_t offset_base, void* out, int32_t io_dtype, float* s_buf,
+                             float* v_buf, float* stats, float* scratch, void* sched, void* stream);
+int32_t advx_fused_bwd_sched(advx_plan* plan, const void* grad_out, int32_t io_dtype, int32_t batch, float* p,
+                             const float* x0, float epsilon, float imgfit_scale, const float* mask, float* m,
+                             float* v, float* grad_p, int32_t opt_kind, float* s_next, float* v_buf, float* stats,
+                             float* scratch, void* sched, void* stream);
 
 /* One launch per step (single GPU): advx_fused_step = advx_fused_bwd(step t) followed by
  * advx_fused_fwd(step t+1) for the same pixels inside one kernel - grad_out of step t in,
