@@ -198,3 +198,29 @@ def test_loss_resaved_is_the_forward_of_the_png_image(tmp_path):
     assert got.shape == want.shape and float((got - want).abs().max()) < 2e-6
     # a noiseless forward of (nearly) the same image: close to, but not the same as, the training loss
     assert abs(hist[2]["loss_resaved"] - hist[2]["ce_loss"]) < 0.5
+
+
+def test_batched_generation_probe_equals_the_serial_one(tmp_path):
+    """one left-padded `generate` per model instead of one per question - same decoded text, same CSV,
+    same statistics as the reference's serial loop (train_test.py:42-65), with prompts of different lengths and a
+    chunk size that does not divide their number."""
+    import csv
+    from adversarialvlm_amd.processors import load_components
+    from adversarialvlm_amd.train_test import run_model_test
+    dev = torch.device("cuda:0")
+    model, proc = _tiny(dev)
+    _, AdvInputs, DiffProc = load_components("synthetic/tiny-llava")
+    questions = ["what is in the image", "hi", "describe the scene in a few words please", "and now", "tell me more about it",
+                 "one two three four five six seven", "why"]
+    ip = AdvInputs(questions=questions, test_questions=questions, batch_size=2, original_image=None, processor=proc, device=dev,
+                   target_text="sure here it is")
+    ap = DiffProc(proc.image_processor, dev)
+    img = Image.fromarray((np.random.default_rng(3).random((56, 56, 3)) * 255).astype(np.uint8))
+    tmp = str(tmp_path)
+    res = {}
+    for name, kw in (("serial", dict(batched=False)), ("batched", dict(batched=True, probe_batch=3))):
+        first, log = run_model_test([model], [proc], [ip], ["synthetic/tiny-llava"], questions, "sure here it is", tmp, name, img,
+                                    adv_processors=[ap], max_new_tokens=12, **kw)
+        res[name] = (first, log, list(csv.reader(open(os.path.join(tmp, f"test_results_iter_{name}.csv")))))
+    assert res["serial"] == res["batched"]
+    assert len(res["batched"][2]) == 1 + len(questions) and len({len(r[1].split()) for r in res["batched"][2][1:]}) > 1
