@@ -881,6 +881,7 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
                        (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats);
   }
   LAUNCH_CHECK();
+  // the stages above stage 0 (Phi-3.5's global view), then the emits of all plans
   for (int i = 0; i < n; ++i) {
     advx_plan* p = plans[i];
     float* ws = wss[i];
@@ -892,21 +893,54 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
                        nullptr, st);
       LAUNCH_CHECK();
     }
+  }
+  MultiEmit me;
+  std::memset(&me, 0, sizeof(me));
+  me.n = n;
+  int noise_all = -1, max_gx = 0, max_slices = 0;
+  bool same_noise = true;
+  for (int i = 0; i < n; ++i) {
+    advx_plan* p = plans[i];
     const float* z = unit_noises ? unit_noises[i] : nullptr;
     const int noise = z ? 1 : (use_philox ? 2 : 0);
+    if (noise_all < 0) noise_all = noise;
+    same_noise = same_noise && noise == noise_all;
+    EmitArgs& a = me.a[i];
+    a.pl = p->dplan;
+    a.ws = wss[i];
+    a.unit_noise = z;
+    a.out = outs[i];
+    a.offset = offsets[i];
+    a.batch = batches[i];
+    a.io = p->io;
     const long long n4 = (p->info.out_numel + 3) >> 2;
-    long long q_lo = 0, q_hi = n4, live_lo = 0, live_hi = n4 << 2;
+    a.q_lo = 0; a.q_hi = n4; a.live_lo = 0; a.live_hi = n4 << 2;
     if (pad_mode == ADVX_PAD_KEEP) {
-      plan_live_range(p, &live_lo, &live_hi);
-      q_lo = live_lo >> 2;
-      q_hi = (live_hi + 3) >> 2;
+      plan_live_range(p, &a.live_lo, &a.live_hi);
+      a.q_lo = a.live_lo >> 2;
+      a.q_hi = (a.live_hi + 3) >> 2;
     }
-    int gx, slices, bps;
-    emit_slices(q_hi - q_lo, batches[i], &gx, &slices, &bps);
-    dim3 grid(gx, slices);
-#define ADVX_EMIT_T(N, T)                                                                                             \
-  hipLaunchKernelGGL((k_emit<N, T>), grid, dim3(kBlock), 0, st, p->dplan, ws, batches[i], bps, sigma_dev, z, seed, \
-                     offsets[i], outs[i], q_lo, q_hi, live_lo, live_hi)
+    emit_slices(a.q_hi - a.q_lo, batches[i], &a.gx, &a.slices, &a.b_per_slice);
+    max_gx = std::max(max_gx, a.gx);
+    max_slices = std::max(max_slices, a.slices);
+  }
+  if (n > 1 && same_noise && !g_generic_kernels) {
+    // one launch for all plans: the plans fill each other's tails (same values: same counters, same offsets)
+    dim3 grid(max_gx, max_slices, n);
+    if (noise_all == 0) hipLaunchKernelGGL(k_emit_multi<0>, grid, dim3(kBlock), 0, st, me, sigma_dev, seed);
+    else if (noise_all == 1) hipLaunchKernelGGL(k_emit_multi<1>, grid, dim3(kBlock), 0, st, me, sigma_dev, seed);
+    else hipLaunchKernelGGL(k_emit_multi<2>, grid, dim3(kBlock), 0, st, me, sigma_dev, seed);
+    LAUNCH_CHECK();
+    return ADVX_OK;
+  }
+  for (int i = 0; i < n; ++i) {
+    advx_plan* p = plans[i];
+    const EmitArgs& a = me.a[i];
+    const int noise = a.unit_noise ? 1 : (use_philox ? 2 : 0);
+    dim3 grid(a.gx, a.slices);
+#define ADVX_EMIT_T(N, T)                                                                                                 \
+  hipLaunchKernelGGL((k_emit<N, T>), grid, dim3(kBlock), 0, st, p->dplan, a.ws, a.batch, a.b_per_slice, sigma_dev, a.unit_noise, \
+                     seed, a.offset, a.out, a.q_lo, a.q_hi, a.live_lo, a.live_hi)
 #define ADVX_EMIT(N) \
   do { if (p->io == 0) ADVX_EMIT_T(N, 0); else if (p->io == 1) ADVX_EMIT_T(N, 1); else ADVX_EMIT_T(N, 2); } while (0)
     if (noise == 0) ADVX_EMIT(0); else if (noise == 1) ADVX_EMIT(1); else ADVX_EMIT(2);
@@ -941,10 +975,15 @@ extern "C" int32_t advx_collect_multi(int32_t n, advx_plan* const* plans, const 
     REQUIRE(grad_outs[i], ADVX_E_BADARG, "advx_collect_multi: null gradient");
     rc = advx_plan_upload(p, stream);
     if (rc) return rc;
-    rc = reduce_to_canvas(p, grad_outs[i], batches[i], wss[i], st);
-    if (rc) return rc;
     mb.st[i] = p->dstage[0];
     mb.cg[i] = stage_grad(p, 0, wss[i]);
+  }
+  // one batch reduction per plan.  (All plans in ONE launch was tried: the merged kernel - six load variants behind a
+  // switch, the per-plan arguments selected from a kernel-argument array - went through scratch memory and took
+  // 850 us instead of 45.)
+  for (int i = 0; i < n; ++i) {
+    rc = reduce_to_canvas(plans[i], grad_outs[i], batches[i], wss[i], st);
+    if (rc) return rc;
   }
   const int rowblk = 128;
   for (int i = 0; i < n; ++i) {

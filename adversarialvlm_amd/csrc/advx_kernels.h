@@ -702,11 +702,10 @@ __device__ inline float emit_value(const DPlan& pl, const float* __restrict__ ws
 
 // NOISE: 0 none, 1 unit-noise tensor supplied, 2 in-kernel Philox
 template <int NOISE, int IO>   // IO: boundary dtype of `out` (0 f32, 1 f16, 2 bf16; halves need n % 4 == 0)
-__global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restrict__ ws, int batch, int b_per_slice,
-                                                 const float* __restrict__ sigma_dev, const float* __restrict__ unit_noise,
-                                                 unsigned long long seed, unsigned long long offset,
-                                                 void* __restrict__ out, long long q_lo, long long q_hi,
-                                                 long long live_lo, long long live_hi) {
+__device__ inline void emit_body(const DPlan& pl, const float* __restrict__ ws, int batch, int b_per_slice,
+                                 const float* __restrict__ sigma_dev, const float* __restrict__ unit_noise,
+                                 unsigned long long seed, unsigned long long offset, void* __restrict__ out, long long q_lo,
+                                 long long q_hi, long long live_lo, long long live_hi, unsigned block_x, unsigned block_y) {
   // Only the float4 columns [q_lo, q_hi) are written.  The default is all of them, noise
   // included on the constant padding tiles, as the reference does (attack_model.py:320 adds
   // randn_like to the WHOLE tensor).  A caller that keeps `out` across steps with its padding
@@ -714,7 +713,7 @@ __global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restri
   // range: elements outside it inside a boundary column are written as exact zeros.
   const long long n = pl.out_numel;
   const long long n4 = (n + 3) >> 2;
-  const long long q = q_lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long q = q_lo + (long long)block_x * blockDim.x + threadIdx.x;
   if (q >= q_hi) return;
   const long long i0 = q << 2;
   float v[4];
@@ -730,7 +729,7 @@ __global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restri
   }
   const bool edge = (i0 < live_lo) || (i0 + 4 > live_hi);
   const float sigma = (NOISE != 0) ? sigma_dev[0] : 0.0f;
-  const int b0 = blockIdx.y * b_per_slice;
+  const int b0 = (int)block_y * b_per_slice;
   const int b1 = min(batch, b0 + b_per_slice);
   for (int b = b0; b < b1; ++b) {
     float o[4] = {v[0], v[1], v[2], v[3]};
@@ -758,6 +757,51 @@ __global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restri
       for (int k = 0; k < 4; ++k)
         if (i0 + k < n) reinterpret_cast<float*>(out)[(size_t)b * n + i0 + k] = o[k];
     }
+  }
+}
+
+template <int NOISE, int IO>
+__global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restrict__ ws, int batch, int b_per_slice,
+                                                 const float* __restrict__ sigma_dev, const float* __restrict__ unit_noise,
+                                                 unsigned long long seed, unsigned long long offset,
+                                                 void* __restrict__ out, long long q_lo, long long q_hi,
+                                                 long long live_lo, long long live_hi) {
+  emit_body<NOISE, IO>(pl, ws, batch, b_per_slice, sigma_dev, unit_noise, seed, offset, out, q_lo, q_hi, live_lo, live_hi,
+                       blockIdx.x, blockIdx.y);
+}
+
+// Cross-model runs: the emits of all plans in ONE launch (blockIdx.z = plan).  Each emit alone ends in a tail in which
+// the last workgroups run on a mostly idle device; side by side the plans fill each other's tails.  Per element the
+// work is k_emit's (same counters, same offsets): identical tensors.
+struct EmitArgs {
+  DPlan pl;
+  const float* ws;
+  const float* unit_noise;
+  void* out;
+  unsigned long long offset;
+  long long q_lo, q_hi, live_lo, live_hi;
+  int batch, b_per_slice, gx, slices, io;
+};
+struct MultiEmit {
+  int n;
+  EmitArgs a[kMaxMulti];
+};
+template <int NOISE>
+__global__ void __launch_bounds__(kBlock) k_emit_multi(MultiEmit me, const float* __restrict__ sigma_dev, unsigned long long seed) {
+#pragma unroll
+  for (int k = 0; k < kMaxMulti; ++k) {
+    if (k != (int)blockIdx.z) continue;          // static indices into the kernel arguments
+    const EmitArgs& a = me.a[k];
+    if ((int)blockIdx.x >= a.gx || (int)blockIdx.y >= a.slices) return;
+    if (a.io == 0)
+      emit_body<NOISE, 0>(a.pl, a.ws, a.batch, a.b_per_slice, sigma_dev, a.unit_noise, seed, a.offset, a.out, a.q_lo, a.q_hi,
+                          a.live_lo, a.live_hi, blockIdx.x, blockIdx.y);
+    else if (a.io == 1)
+      emit_body<NOISE, 1>(a.pl, a.ws, a.batch, a.b_per_slice, sigma_dev, a.unit_noise, seed, a.offset, a.out, a.q_lo, a.q_hi,
+                          a.live_lo, a.live_hi, blockIdx.x, blockIdx.y);
+    else
+      emit_body<NOISE, 2>(a.pl, a.ws, a.batch, a.b_per_slice, sigma_dev, a.unit_noise, seed, a.offset, a.out, a.q_lo, a.q_hi,
+                          a.live_lo, a.live_hi, blockIdx.x, blockIdx.y);
   }
 }
 
@@ -830,11 +874,11 @@ __device__ inline void reduce_store4(const DPlan& pl, float* __restrict__ ws, lo
 }
 
 template <int IO, bool CANVAS>   // io_load4 code: 0 / 1 / 2 cached f32 / f16 / bf16, 3 / 4 / 5 the same non-temporal
-__global__ void __launch_bounds__(kBlock) k_batch_reduce(const void* __restrict__ g, int batch, long long n,
-                                                         float* __restrict__ out, long long q_lo, long long q_hi, DPlan pl) {
+__device__ inline void reduce_body(const void* __restrict__ g, int batch, long long n, float* __restrict__ out, long long q_lo,
+                                   long long q_hi, const DPlan& pl, unsigned block_x, unsigned grid_x) {
   __shared__ float4 part[kBlock / kWave][kWave];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  const long long q = q_lo + (long long)blockIdx.x * kWave + lane;  // float4 column
+  const long long q = q_lo + (long long)block_x * kWave + lane;  // float4 column
   const long long n4 = n >> 2;
   // CANVAS: where this column's sums go (one inverse layout map), worked out while the stream is in flight
   long long dest = -1;
@@ -849,7 +893,7 @@ __global__ void __launch_bounds__(kBlock) k_batch_reduce(const void* __restrict_
     else *reinterpret_cast<float4*>(out + (q << 2)) = t;
   }
   // scalar tail (n not a multiple of 4; float32 only): last block, first threads
-  if ((IO == 0 || IO == 3) && q_hi == n4 && blockIdx.x == gridDim.x - 1) {
+  if ((IO == 0 || IO == 3) && q_hi == n4 && block_x == grid_x - 1) {
     long long tail0 = n4 << 2;
     long long i = tail0 + threadIdx.x;
     if (i < n) {
@@ -863,6 +907,12 @@ __global__ void __launch_bounds__(kBlock) k_batch_reduce(const void* __restrict_
       }
     }
   }
+}
+
+template <int IO, bool CANVAS>
+__global__ void __launch_bounds__(kBlock) k_batch_reduce(const void* __restrict__ g, int batch, long long n,
+                                                         float* __restrict__ out, long long q_lo, long long q_hi, DPlan pl) {
+  reduce_body<IO, CANVAS>(g, batch, n, out, q_lo, q_hi, pl, blockIdx.x, gridDim.x);
 }
 
 // rows not 16-byte aligned (n % 4 != 0): one thread per column, test-sized inputs only
