@@ -31,13 +31,17 @@ def run(name, plans, H, W, B, blur=None, crop=None, steps=50, cross=False, pad_n
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    # write B*P_out (+ padding tiles as the reference writes them), read the gradient of
-    # the elements an image reaches (the padding's gradient goes nowhere)
+    # Two byte counts.  "tensor": what the reference's tensor costs - B*P_out written (padding tiles included: the
+    # reference adds noise to them and Llama-3.2's vision encoder does see them, tests/test_mllama_padding_visibility.py)
+    # plus the gradient of the elements an image reaches.  "algorithmic" (SURVEY 8(d)): the live elements only, both ways -
+    # the figure the roofline fraction is quoted against; for Mllama it counts one tile of four (495 MB at B = 64).
     live = [pl.live_range()[1] - pl.live_range()[0] for pl in plans]
     wr = sum(pl.out_numel if pad_noise else lv for pl, lv in zip(plans, live))
-    by = (4 if io == torch.float32 else 2) * B * (wr + sum(live)) + 4 * 10 * 3 * H * W
-    print(f"{name:52s} B={B:3d}  {dt * 1e6:9.1f} us/step  {1 / dt:9.1f} steps/s  algorithmic {by / 1e6:8.1f} MB  "
-          f"{by / dt / 1e12:5.2f} TB/s ({by / dt / 8e12:4.2f} of HBM peak)", flush=True)
+    eb = 4 if io == torch.float32 else 2
+    tensor_bytes = eb * B * (wr + sum(live)) + 4 * 10 * 3 * H * W
+    algo_bytes = eb * B * 2 * sum(live) + 4 * 10 * 3 * H * W
+    print(f"{name:52s} B={B:3d}  {dt * 1e6:9.1f} us/step  {1 / dt:9.1f} steps/s  algorithmic {algo_bytes / 1e6:8.1f} MB = "
+          f"{algo_bytes / dt / 8e12:4.2f} of HBM peak; tensor {tensor_bytes / 1e6:8.1f} MB = {tensor_bytes / dt / 8e12:4.2f}", flush=True)
 
 
 if __name__ == "__main__":
