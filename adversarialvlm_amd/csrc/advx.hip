@@ -44,9 +44,14 @@ static int32_t fail(int32_t code, const std::string& msg) {
 // advx_set_tuning(ADVX_TUNE_GENERIC_KERNELS, 1): take the run-time-radius / unfused kernels everywhere (the tests
 // compare the specialised kernels with them bit for bit)
 static int g_generic_kernels = 0;
+static int g_pair_nt_loads = 0;
 extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
   if (what == ADVX_TUNE_GENERIC_KERNELS) {
     g_generic_kernels = value ? 1 : 0;
+    return ADVX_OK;
+  }
+  if (what == ADVX_TUNE_PAIR_NT_LOADS) {
+    g_pair_nt_loads = value ? 1 : 0;
     return ADVX_OK;
   }
   return fail(ADVX_E_BADARG, "advx_set_tuning: unknown switch");
@@ -1527,15 +1532,17 @@ static int32_t fused_fwd_impl(advx_plan* p, const float* pp, const float* x0, fl
   emit_slices(n4, batch, &gx, &slices, &bps);
   dim3 grid(gx, slices + 1);  // y == 0: statistics blocks, y >= 1: batch slices
   int noise = unit_noise ? 1 : (use_philox ? 2 : 0);
-#define ADVX_FF(N, T)                                                                                            \
-  ADVX_LAUNCH_TIMED(PROF_FWD, (k_fused_fwd<N, T>), grid, dim3(kBlock), st, (const float*)v_buf, (const float*)s_buf, x0, n, \
+#define ADVX_FF_S(N, T, S)                                                                                       \
+  ADVX_LAUNCH_TIMED(PROF_FWD, (k_fused_fwd<N, T, S>), grid, dim3(kBlock), st, (const float*)v_buf, (const float*)s_buf, x0, n, \
                     batch, bps, stats, unit_noise, seed, offset, out, f.hdr, f.img_rows[parity],                  \
                     (const double*)f.norm_partials, sched)
+#define ADVX_FF(N, T) do { if (sched) ADVX_FF_S(N, T, true); else ADVX_FF_S(N, T, false); } while (0)
 #define ADVX_FF_IO(N) \
   do { if (io == 0) ADVX_FF(N, 0); else if (io == 1) ADVX_FF(N, 1); else ADVX_FF(N, 2); } while (0)
   if (noise == 0) ADVX_FF_IO(0); else if (noise == 1) ADVX_FF_IO(1); else ADVX_FF_IO(2);
 #undef ADVX_FF_IO
 #undef ADVX_FF
+#undef ADVX_FF_S
   LAUNCH_CHECK();
   return ADVX_OK;
 }
@@ -1574,12 +1581,19 @@ static int32_t fused_bwd_impl(advx_plan* p, const void* g, int32_t io, int32_t b
     REQUIRE(opt->apply, ADVX_E_UNSUPPORTED, "advx_fused_bwd: the fused update always steps (use the generic path to accumulate)");
     int32_t rc = check_opt(opt, m, v);
     if (rc) return rc;
-#define ADVX_FB(U, T, O)                                                                                          \
-  ADVX_LAUNCH_TIMED(PROF_BWD, (k_fused_bwd<U, T>), dim3(f.bwd_blocks), dim3(kBlock), st, g, batch, pp, x0, eps,    \
+#define ADVX_FB_S(U, T, O, S)                                                                                     \
+  ADVX_LAUNCH_TIMED(PROF_BWD, (k_fused_bwd<U, T, S>), dim3(f.bwd_blocks), dim3(kBlock), st, g, batch, pp, x0, eps, \
                     fused_geom(p), c_fit, mask, m, v, grad_p, O, s_next, v_buf, f.norm_partials, stats, f.hdr,     \
                     (const double*)f.img_partials, sched)
-#define ADVX_FB_IO(U, O) \
-  do { if (io == 0) ADVX_FB(U, 0, O); else if (io == 1) ADVX_FB(U, 1, O); else ADVX_FB(U, 2, O); } while (0)
+#define ADVX_FB(U, T, O) do { if (sched) ADVX_FB_S(U, T, O, true); else ADVX_FB_S(U, T, O, false); } while (0)
+#define ADVX_FB_IO(U, O)                                                                                   \
+  do {                                                                                                     \
+    if (g_pair_nt_loads) {                                                                                 \
+      if (io == 0) ADVX_FB(U, 3, O); else if (io == 1) ADVX_FB(U, 4, O); else ADVX_FB(U, 5, O);            \
+    } else {                                                                                               \
+      if (io == 0) ADVX_FB(U, 0, O); else if (io == 1) ADVX_FB(U, 1, O); else ADVX_FB(U, 2, O);            \
+    }                                                                                                      \
+  } while (0)
     ADVX_FB_IO(true, to_dev(opt));
   } else {
     OptScalars none;
@@ -1587,6 +1601,7 @@ static int32_t fused_bwd_impl(advx_plan* p, const void* g, int32_t io, int32_t b
     ADVX_FB_IO(false, none);
 #undef ADVX_FB_IO
 #undef ADVX_FB
+#undef ADVX_FB_S
   }
   LAUNCH_CHECK();
   return ADVX_OK;

@@ -1076,7 +1076,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_prep(const float* __restrict__
 }
 
 // NOISE: 0 none, 1 unit-noise tensor supplied, 2 in-kernel Philox
-template <int NOISE, int IO>
+template <int NOISE, int IO, bool SCHED = false>   // SCHED: step scalars from device memory (graph replay), else arguments
 __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ v_buf, const float* __restrict__ s_buf,
                                                       const float* __restrict__ x0, long long n, int batch,
                                                       int b_per_slice, float* stats, const float* __restrict__ unit_noise,
@@ -1086,7 +1086,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ 
                                                       const double* __restrict__ norm_partials, SchedDev* sched) {
   const long long n4 = n >> 2;
   const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (sched != nullptr) {
+  if (SCHED) {
     const unsigned long long t = sched->fwd_step;       // uniform: a scalar load
     offset += t;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sched->bwd_step = t;
@@ -1142,7 +1142,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ 
 // block = 64 float4 columns (256 pixels); the 4 waves split the batch and meet in LDS; then
 // thread t owns pixel t of the block.  Its per-pixel state is prefetched before the batch
 // loop so that no dependent load sits on the tail.
-template <bool UPDATE, int IO>
+template <bool UPDATE, int IO, bool SCHED = false>
 __global__ void __launch_bounds__(kBlock) k_fused_bwd(const void* __restrict__ g, int batch, float* __restrict__ p,
                                                       const float* __restrict__ x0, float eps, FusedGeom geo,
                                                       float c_fit, const float* __restrict__ mask,
@@ -1153,7 +1153,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_bwd(const void* __restrict__ g
                                                       FusedHeader* __restrict__ hdr,
                                                       const double* __restrict__ img_partials, SchedDev* sched) {
   __shared__ float4 part4[kBlock / kWave][kWave];
-  if (sched != nullptr) {
+  if (SCHED) {
     const unsigned long long t = sched->bwd_step;
     long long k = (long long)(t - sched->first_step);
     if (k < 0) k = 0;

@@ -130,6 +130,7 @@ def main():
                     help="cold = rotate through --ring gradient / output buffers (beyond the Infinity Cache; the headline), "
                          "hot = one resident pair (the round-1 loop), both = cold timed first, hot reported as in_cache")
     ap.add_argument("--ring", type=int, default=8, help="distinct gradient tensors / output blocks of the cold loop")
+    ap.add_argument("--nt-loads", action="store_true", help="experiment: the pair's backward reads grad_out non-temporally")
     args = ap.parse_args()
     io_dtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.io]
     io_bytes = 4 if args.io == "f32" else 2
@@ -167,6 +168,9 @@ def main():
         torch.distributed.barrier()
     from adversarialvlm_amd.pgd import PixelPGD
     from adversarialvlm_amd.plan import Plan
+    if args.nt_loads:
+        from adversarialvlm_amd import _lib
+        _lib.check(_lib.load().advx_set_tuning(2, 1), "advx_set_tuning")
 
     if args.scaling == "strong":
         if BATCH % world:

@@ -119,6 +119,7 @@ const char* advx_last_error(void);
  * radius, one launch per operation) instead of the specialised / merged ones; results are bit-identical, which
  * is what the tests use it for.  Process-wide, not thread-safe. */
 #define ADVX_TUNE_GENERIC_KERNELS 1
+#define ADVX_TUNE_PAIR_NT_LOADS 2   /* advx_fused_bwd reads grad_out with non-temporal loads (same results) */
 int32_t advx_set_tuning(int32_t what, int32_t value);
 
 /* ------------------------------------------------------------------ plans
