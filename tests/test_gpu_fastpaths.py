@@ -211,3 +211,19 @@ def test_cross_chain_windowed_equals_general():
     for a, b in zip(fast, ref):
         for u, v in zip(a, b):
             assert torch.equal(u, v), float((u - v).abs().max())
+
+
+def test_large_image_takes_the_general_backward():
+    """Beyond 2048 tiles (here 33 x 33 x 3) the merged backward has no room for its ||g|| partials and the host falls
+    back to k_blur<1,2> + k_bwd_update<1>; the forward stays radius-templated.  Same bits either way."""
+    fast, st_f = _run(1040, 1040, 5, False, 2, generic=False, masked=False)
+    ref, st_r = _run(1040, 1040, 5, False, 2, generic=True, masked=False)
+    for a, b in zip(fast, ref):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    assert st_f["grad_norm"] == pytest.approx(st_r["grad_norm"], rel=1e-6)
+
+
+def test_unknown_tuning_switch_is_an_error():
+    from adversarialvlm_amd import _lib as L
+    assert L.load().advx_set_tuning(99, 1) != 0 and b"unknown switch" in L.load().advx_last_error()

@@ -1,1 +1,4 @@
-for f in "" "--nt-loads"; do python bench.py --no-cpu-baseline $f 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$f', d['ms_per_step'], r['kernel_ms'], d['in_cache']['ms_per_step'], r['kernel_ms_in_cache'])"; done
+set -o pipefail
+for sc in weak strong; do
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo --scaling $sc 2>gpurun_out/bench2.err | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$sc', d['n_gpus'], d['value'], d['ms_per_step'], d['scaling'], d['config']['prompts_per_gpu'], d['config']['exchange'][:60], d['config']['replicas_identical'], d['config']['exchange_timed_out'], d['roofline']['frac'], d.get('in_cache',{}).get('ms_per_step'))" || tail -20 gpurun_out/bench2.err
+done
