@@ -852,7 +852,6 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
   MultiFwd mf;
   std::memset(&mf, 0, sizeof(mf));
   mf.n = n;
-  long long biggest = 0;
   for (int i = 0; i < n; ++i) {
     advx_plan* p = plans[i];
     const float* z = unit_noises ? unit_noises[i] : nullptr;
@@ -864,27 +863,17 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
     if (rc) return rc;
     mf.st[i] = p->dstage[0];
     mf.canvas[i] = wss[i] + p->dplan.canvas_off[0];
-    biggest = std::max(biggest, 3LL * p->dstage[0].can_h * p->dstage[0].can_w);
   }
   const DStage& D0 = plans[0]->dstage[0];
-  int need = 0, max_h = 0, max_w = 0;
+  int max_h = 0, max_w = 0;
   for (int i = 0; i < n; ++i) {
-    need = std::max(need, std::max(mf.st[i].th.stride, mf.st[i].tw.stride));
     max_h = std::max(max_h, mf.st[i].can_h);
     max_w = std::max(max_w, mf.st[i].can_w);
   }
-  const int T0 = 0 * pick_window(need);   // measured: the mixed geometries of a cross-model run lose with one window size (20.7 vs 19.1 us)
-  if (T0) {
-    dim3 grid((max_w + kRowBlock - 1) / kRowBlock, max_h, 3 * n);
-#define ADVX_SFM(T_)                                                                                                        \
-  hipLaunchKernelGGL((k_stage0_fwd_multi_t<T_>), grid, dim3(kRowBlock), 0, st, mf, argument, (long long)D0.src_h * D0.src_w, \
-                     D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats)
-    ADVX_WINDOW_SWITCH(T0, ADVX_SFM)
-#undef ADVX_SFM
-  } else {
-    hipLaunchKernelGGL(k_stage0_fwd_multi, dim3((max_w + kRowBlock - 1) / kRowBlock, max_h, n), dim3(kRowBlock), 0, st, mf, argument,
-                       (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats);
-  }
+  // one window size for plans of different geometry loses to the run-time loops (20.7 vs 19.1 us); what pays is three
+  // channels per thread on a (column chunk, row, plan) grid (11.5 us)
+  hipLaunchKernelGGL(k_stage0_fwd_multi, dim3((max_w + kRowBlock - 1) / kRowBlock, max_h, n), dim3(kRowBlock), 0, st, mf, argument,
+                     (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats);
   LAUNCH_CHECK();
   // the stages above stage 0 (Phi-3.5's global view), then the emits of all plans
   for (int i = 0; i < n; ++i) {
@@ -1243,7 +1232,7 @@ extern "C" int32_t advx_forward_multi(const float* p, const float* x0, int32_t H
 // generic kernels.
 static bool blur_bwd_fusable(int r, int H, int W) {
   if (g_generic_kernels || r < 1 || r > kBlurFastMaxR) return false;
-  return (long long)((W + kBlurTile - 1) / kBlurTile) * ((H + kBlurTile - 1) / kBlurTile) * 3 <= NormCount::kSlot;
+  return (long long)((W + kBlurTile - 1) / kBlurTile) * ((H + kBlurTile - 1) / kBlurTile) * 3 <= kNormCountSlot;
 }
 template <bool UPDATE>
 static void launch_blur_bwd_fused(int r, const float* gsrc, const float* s, int H, int W, float sigma, float eps, float c_fit,

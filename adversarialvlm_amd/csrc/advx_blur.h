@@ -138,10 +138,6 @@ __global__ void __launch_bounds__(kBlock) k_blur_fwd_r(const float* __restrict__
 // (32+3R)^2 from (32+5R)^2 where both borders fold into one tile; zeros outside the image.  No extended-domain
 // buffer in memory, no second pass over the image.  (A crop window's transposed resize stays a launch of its
 // own, k_crop_bwd_t: gathered while the tiles load it cost 36 us instead of 10.6 + 14.)
-struct NormCount {      // slot behind the 2048 norm partials: how many the last producer left (advx_update_flush)
-  static constexpr int kSlot = 2048;
-};
-
 template <int R, bool UPDATE>
 __global__ void __launch_bounds__(kBlock) k_blur_bwd_fused(const float* __restrict__ gsrc, const float* __restrict__ s,
                                                            int H, int W, float sigma,
@@ -283,7 +279,7 @@ __global__ void __launch_bounds__(kBlock) k_blur_bwd_fused(const float* __restri
   if (UPDATE) {
     const int blk = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     block_sum_store<1>(nacc, partials + blk);
-    if (blk == 0 && threadIdx.x == 0) partials[NormCount::kSlot] = (double)(gridDim.x * gridDim.y * gridDim.z);
+    if (blk == 0 && threadIdx.x == 0) partials[kNormCountSlot] = (double)(gridDim.x * gridDim.y * gridDim.z);
   }
 }
 

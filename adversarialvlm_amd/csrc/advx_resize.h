@@ -6,8 +6,9 @@
 // the host): every load of a thread is issued before the first use, taps beyond a row's count are read from a
 // clamped (valid) address and never enter the sum.  The in-range taps are accumulated by the same operations in
 // the same order as in stage_fwd_value / crop_bwd_value / stage_bwd_value, so the results are bit-identical
-// (tests/test_gpu_fastpaths.py).  Grids are (column chunks, rows, channels [x plans]): the row of a workgroup
-// is uniform, its tables are scalar loads and no thread divides to find its pixel.
+// (tests/test_gpu_fastpaths.py).  Grids are (column chunks, rows, channels): the row of a workgroup is uniform, its
+// tables are scalar loads and no thread divides to find its pixel.  Measured: windows up to 4 x 4 pay;
+// from 5 x 5 on, and for the mixed geometries of a multi-plan launch, the run-time loops of advx_kernels.h are faster.
 #pragma once
 #include "advx_kernels.h"
 
@@ -84,21 +85,6 @@ __global__ void __launch_bounds__(kRowBlock) k_stage_fwd_t(DStage st, const floa
   const int c = blockIdx.z, y = blockIdx.y;
   const int x = blockIdx.x * kRowBlock + threadIdx.x;
   if (x < st.can_w) canvas[((size_t)c * st.can_h + y) * st.can_w + x] = stage_fwd_value_t<T>(st, src, src_cstride, src_rstride, c, y, x);
-}
-
-// k_stage0_fwd_multi: blockIdx.z = 3 * plan + channel; grid rows / column chunks of the largest canvas
-template <int T>
-__global__ void __launch_bounds__(kRowBlock) k_stage0_fwd_multi_t(MultiFwd mf, const float* __restrict__ src,
-                                                                  long long src_cstride, int src_rstride,
-                                                                  const double* __restrict__ img_partials, int nblk,
-                                                                  long long n_img, float* __restrict__ stats) {
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && nblk > 0) finalize_image_block<true>(img_partials, nblk, n_img, stats);
-  const int k = blockIdx.z / 3, c = blockIdx.z - 3 * k;
-  const DStage& st = mf.st[k];
-  const int y = blockIdx.y;
-  const int x = blockIdx.x * kRowBlock + threadIdx.x;
-  if (y < st.can_h && x < st.can_w)
-    mf.canvas[k][((size_t)c * st.can_h + y) * st.can_w + x] = stage_fwd_value_t<T>(st, src, src_cstride, src_rstride, c, y, x);
 }
 
 // crop_bwd_value with a T x T window (T = the transposed tables' row length of this step's window)
