@@ -1,4 +1,8 @@
-set -o pipefail
-for sc in weak strong; do
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo --scaling $sc 2>gpurun_out/bench2.err | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$sc', d['n_gpus'], d['value'], d['ms_per_step'], d['scaling'], d['config']['prompts_per_gpu'], d['config']['exchange'][:60], d['config']['replicas_identical'], d['config']['exchange_timed_out'], d['roofline']['frac'], d.get('in_cache',{}).get('ms_per_step'))" || tail -20 gpurun_out/bench2.err
-done
+export TMPDIR=/tmp
+rm -rf gpurun_out/op.d; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/op.d -o p -- python3 tools/op_profile.py 512 > gpurun_out/op.log 2>&1
+python3 - $(find gpurun_out/op.d -name '*kernel_stats.csv' | head -1) <<'PY'
+import csv, re, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    name = re.sub(r'\(.*', '', r['Name']).replace('void ', '')[:70]
+    print(f"{name:70s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:7.2f} us min {float(r['MinNs'])/1e3:7.2f}")
+PY
