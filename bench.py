@@ -257,24 +257,27 @@ def main():
     # launch.  Single rank, pair chain only.
     graph_run = None
     if args.cache != "hot" and world == 1 and eng.mode == "pair" and not eng.exchange and ring % 2 == 0 and not args.no_graph:
-        outs_g = [torch.empty((B, 3 * H * W), dtype=io_dtype, device=dev) for _ in range(ring)]
-        replays = max(1, args.steps // ring)
-        sched = eng.make_schedule(ring * (replays + 1))
-        graph = torch.cuda.CUDAGraph()
-        torch.cuda.synchronize()
-        with torch.cuda.graph(graph):
-            for k in range(ring):
-                eng.forward_sched(B, sched, outs_g[k])
-                eng.backward_update_sched(gs_ring[k], sched)
-        graph.replay()                                   # warm-up replay (also the first real `ring` steps)
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(replays):
-            graph.replay()
-        fence()
-        gdt = time.perf_counter() - t0
-        eng.advance(ring * (replays + 1))
-        graph_run = (gdt, ring * replays)
+        try:
+            outs_g = [torch.empty((B, 3 * H * W), dtype=io_dtype, device=dev) for _ in range(ring)]
+            replays = max(1, args.steps // ring)
+            sched = eng.make_schedule(ring * (replays + 1))
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                for k in range(ring):
+                    eng.forward_sched(B, sched, outs_g[k])
+                    eng.backward_update_sched(gs_ring[k], sched)
+            graph.replay()                                   # warm-up replay (also the first real `ring` steps)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(replays):
+                graph.replay()
+            fence()
+            gdt = time.perf_counter() - t0
+            eng.advance(ring * (replays + 1))
+            graph_run = (gdt, ring * replays)
+        except Exception as e:      # supplementary: never cost the run its line
+            graph_run = f"{type(e).__name__}: {e}"
     main_key = "cold" if "cold" in runs else "hot"
     dt, prof = runs[main_key]
     # after the timed regions: the replicas of p must still hold the same bits on every rank, and no
@@ -371,7 +374,9 @@ def main():
             roofline["kernel_ms_in_cache"] = kernel_ms(hprof)
             roofline["kernel_frac_in_cache"] = kernel_fracs(hprof)
             roofline["step_frac_of_hbm_peak_in_cache"] = round(bytes_step * (args.steps / hdt) / 1e9 / HBM_PEAK_GBS, 4)
-        if graph_run is not None:
+        if isinstance(graph_run, str):
+            line["graph_replay"] = {"error": graph_run[:300]}
+        elif graph_run is not None:
             gdt, gsteps = graph_run
             line["graph_replay"] = {"value": round(gsteps / gdt * B, 1), "unit": "prompt-steps/s", "steps": gsteps,
                                     "ms_per_step": round(gdt / gsteps * 1e3, 5),
