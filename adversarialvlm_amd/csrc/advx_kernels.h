@@ -349,14 +349,17 @@ template <bool WRITE_S>
 __global__ void __launch_bounds__(kBlock) k_prep_taps(const float* __restrict__ p, const float* __restrict__ x0, float eps,
                                                       long long n, float* __restrict__ out, double* __restrict__ partials,
                                                       int nprep, TapBuild a0, TapBuild a1, int tap_blocks_per_axis) {
-  if ((int)blockIdx.x >= nprep) {
-    const int tb = (int)blockIdx.x - nprep;
+  // the builders come FIRST in the grid: dealt last by the dispatcher their microseconds of serial work trail the launch
+  const int ntap = 2 * tap_blocks_per_axis;
+  if ((int)blockIdx.x < ntap) {
+    const int tb = (int)blockIdx.x;
     const int axis = tb / tap_blocks_per_axis;
     build_taps_row(axis == 0 ? a0 : a1, (tb - axis * tap_blocks_per_axis) * blockDim.x + threadIdx.x);
     return;
   }
+  const int bid = (int)blockIdx.x - ntap;
   double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)nprep * blockDim.x) {
+  for (long long i = (long long)bid * blockDim.x + threadIdx.x; i < n; i += (long long)nprep * blockDim.x) {
     float x = eps * tanhf(p[i]);
     if (WRITE_S) {
       float s = x0[i] + x;
@@ -366,7 +369,7 @@ __global__ void __launch_bounds__(kBlock) k_prep_taps(const float* __restrict__ 
       out[i] = x;
     }
   }
-  if (WRITE_S) block_sum_store<kStatSlots>(acc, partials + (size_t)blockIdx.x * kStatSlots);
+  if (WRITE_S) block_sum_store<kStatSlots>(acc, partials + (size_t)bid * kStatSlots);
 }
 
 // ========================================================================== stage fwd
