@@ -29,9 +29,13 @@ def _free_port():
 
 
 def _gray(tmp, size=56):
+    """The test creates the image BEFORE it spawns the ranks (two ranks writing it at once raced: one read a
+    half-written PNG); inside a rank this only returns the path."""
     path = os.path.join(tmp, f"gray{size}.png")
     if not os.path.exists(path):
-        Image.fromarray(np.full((size, size, 3), 128, np.uint8)).save(path)
+        part = f"{path}.{os.getpid()}.tmp"
+        Image.fromarray(np.full((size, size, 3), 128, np.uint8)).save(part, format="PNG")
+        os.replace(part, path)
     return path
 
 
@@ -90,6 +94,7 @@ def test_trainer_ends_the_run_when_a_peer_is_late(tmp_path):
     each leaving its state behind - not train on with diverged replicas.  (Should a slow box skew the two processes
     by more than the limit already at an earlier iteration, the run has to end there - on both ranks just the same.)"""
     tmp = str(tmp_path)
+    _gray(tmp)
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
     mp.spawn(_late_rank, args=(2, _free_port(), tmp, out), nprocs=2, join=True)
@@ -129,6 +134,7 @@ def test_two_rank_resume_is_bit_for_bit(tmp_path, transport):
     """4 iterations + resume + 3 more = 7 iterations in one go, on both ranks, although only rank 0 wrote
     the state file: every rank keeps its own noise seed and re-derives its prompt stream."""
     tmp = str(tmp_path)
+    _gray(tmp)
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
     mp.spawn(_resume_rank, args=(2, _free_port(), tmp, transport, out), nprocs=2, join=True)
@@ -174,6 +180,7 @@ def test_cross_trainer_two_ranks_share_their_draws(tmp_path):
     """One model per rank, blur sigma and crop window redrawn every step from the global generators: the
     replica check after EVERY step passes only if both ranks drew the same values; state and probe files exist."""
     tmp = str(tmp_path)
+    _gray(tmp, 70)
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
     mp.spawn(_cross_rank, args=(2, _free_port(), tmp, out), nprocs=2, join=True)
