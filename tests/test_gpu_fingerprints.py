@@ -1,0 +1,29 @@
+"""GPU tier: bit-level fingerprints of the kernel chains (tools/regress_bits.py).
+
+tests/golden/chain_bits.json holds sha256 digests of everything sixteen chain configurations leave behind after three steps
+on seeded inputs (pixel_values, p, m, v, masked gradient, image), recorded in round 2 BEFORE the data-layout and
+launch-structure changes of that round (canvas-order gradient sums, merged image backward, multi-plan launches, windowed
+resizes).  Restructured kernels keep every element's operations and their order, so the digests must not move; a change that
+means to alter the arithmetic re-records them (`python tools/regress_bits.py write tests/golden/chain_bits.json`) and says so."""
+import json
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_chain_fingerprints_unchanged():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import regress_bits
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "chain_bits.json")))
+    cfgs = regress_bits.configs()
+    assert set(want) == set(cfgs)
+    moved = []
+    for name, cfg in cfgs.items():
+        chain, digest, _ = regress_bits.run(cfg)
+        if chain != want[name]["chain"] or digest != want[name]["sha256"]:
+            moved.append((name, want[name]["chain"], chain))
+    assert not moved, moved
