@@ -34,6 +34,28 @@ __device__ inline void blur_weights(float sigma, float (&w)[2 * R + 1]) {
   for (int i = 0; i < K; ++i) w[i] = w[i] / sum;
 }
 
+// The same weights formed ONCE per workgroup: thread t < K computes the k raw weights and their sum in registers and
+// publishes its own normalised one; everybody reads them back after the workgroup's next barrier.  (Per thread the k
+// exponentials, the sum and the k divisions are ~250 instructions, a tenth of what a tile costs a thread.)
+template <int R>
+__device__ inline void blur_weights_publish(float sigma, float* __restrict__ wn) {
+  constexpr int K = 2 * R + 1;
+  if (threadIdx.x < K) {
+    float w[K];
+    blur_weights<R>(sigma, w);
+    float mine = 0.0f;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+      if (i == (int)threadIdx.x) mine = w[i];
+    wn[threadIdx.x] = mine;
+  }
+}
+template <int R>
+__device__ inline void blur_weights_fetch(const float* __restrict__ wn, float (&w)[2 * R + 1]) {
+#pragma unroll
+  for (int i = 0; i < 2 * R + 1; ++i) w[i] = wn[i];
+}
+
 // ------------------------------------------------------------------------------ forward
 // k_blur<0, IN> with x0 epilogue: s = x0 + blur(IN == 1 ? eps*tanh(in) : in), statistics partials per tile.
 // blockIdx.z == 3: tap-table builder blocks riding in the launch (as in k_blur<0, 1>).
@@ -54,8 +76,8 @@ __global__ void __launch_bounds__(kBlock) k_blur_fwd_r(const float* __restrict__
   constexpr int NR = (TS * kBlurTile + kBlock - 1) / kBlock, NO = kBlurTile * kBlurTile / kBlock;
   __shared__ float tile[TS][TS + 1];
   __shared__ float tmp[TS][kBlurTile + 1];
-  float w[K];
-  blur_weights<R>(sigma, w);
+  __shared__ float wn[K];
+  blur_weights_publish<R>(sigma, wn);
   const int c = blockIdx.z;
   const int oy0 = blockIdx.y * kBlurTile, ox0 = blockIdx.x * kBlurTile;
   const float* src = in + (size_t)c * H * W;
@@ -88,6 +110,8 @@ __global__ void __launch_bounds__(kBlock) k_blur_fwd_r(const float* __restrict__
     }
   }
   __syncthreads();
+  float w[K];
+  blur_weights_fetch<R>(wn, w);
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
     const int e = (int)threadIdx.x + j * kBlock;
@@ -138,31 +162,33 @@ __global__ void __launch_bounds__(kBlock) k_blur_fwd_r(const float* __restrict__
 // (32+3R)^2 from (32+5R)^2 where both borders fold into one tile; zeros outside the image.  No extended-domain
 // buffer in memory, no second pass over the image.  (A crop window's transposed resize stays a launch of its
 // own, k_crop_bwd_t: gathered while the tiles load it cost 36 us instead of 10.6 + 14.)
-template <int R, bool UPDATE>
-__global__ void __launch_bounds__(kBlock) k_blur_bwd_fused(const float* __restrict__ gsrc, const float* __restrict__ s,
-                                                           int H, int W, float sigma,
-                                                           float eps, float c_fit, int accumulate, float* __restrict__ p,
-                                                           float* __restrict__ m, float* __restrict__ v,
-                                                           float* __restrict__ grad, const float* __restrict__ mask,
-                                                           OptScalars o, double* __restrict__ partials) {
-  // worst case: tile 0 of an image of 32 < H <= 32 + R rows folds from both borders: H + 2R <= 32 + 3R output rows
-  constexpr int K = 2 * R + 1, TI = kBlurTile + 5 * R, TO = kBlurTile + 3 * R;
-  constexpr int NL = (TI * TI + kBlock - 1) / kBlock, NO = kBlurTile * kBlurTile / kBlock;
-  __shared__ float tile[TI][TI + 1];
-  __shared__ float tmp[TI][TO + 1];
-  __shared__ float c2t[TO][TO + 1];
-  float w[K];
-  blur_weights<R>(sigma, w);
+// Body of k_blur_bwd_fused.  INTERIOR: the tile and its 2R halo lie strictly inside the image and none of its pixels
+// folds (77 % of the tiles at 512^2, k = 9): the window is the tile itself, 32 + 2R inputs per side with a compile-time
+// row length, no bounds tests, seven loads per thread instead of eleven slots, one c2 term per pixel.  Same operations
+// per element as the general form.
+template <int R, bool UPDATE, bool INTERIOR>
+__device__ inline void blur_bwd_body(const float* __restrict__ gsrc, const float* __restrict__ s, int H, int W, float eps,
+                                     float c_fit, int accumulate, float* __restrict__ p, float* __restrict__ m,
+                                     float* __restrict__ v, float* __restrict__ grad, const float* __restrict__ mask,
+                                     const OptScalars& o, double* __restrict__ partials, const float* __restrict__ wn,
+                                     float (*tile)[kBlurTile + 5 * R + 1], float (*tmp)[kBlurTile + 3 * R + 1],
+                                     float (*c2t)[kBlurTile + 3 * R + 1]) {
+  constexpr int K = 2 * R + 1, TI = kBlurTile + 5 * R;
+  constexpr int TC = kBlurTile + 2 * R;                       // interior: inputs per side
+  constexpr int NL = INTERIOR ? (TC * TC + kBlock - 1) / kBlock : (TI * TI + kBlock - 1) / kBlock;
+  constexpr int NO = kBlurTile * kBlurTile / kBlock;
   const int c = blockIdx.z;
   const int oy0 = blockIdx.y * kBlurTile, ox0 = blockIdx.x * kBlurTile;
   const int ty_hi = min(oy0 + kBlurTile, H) - 1, tx_hi = min(ox0 + kBlurTile, W) - 1;
   // output window of the extended domain (inclusive bounds)
-  const int wy0 = (oy0 == 0) ? -R : oy0;
-  const int wx0 = (ox0 == 0) ? -R : ox0;
-  const int wy1 = (ty_hi >= H - 1 - R && oy0 <= H - 2) ? 2 * (H - 1) - max(oy0, H - 1 - R) : ty_hi;
-  const int wx1 = (tx_hi >= W - 1 - R && ox0 <= W - 2) ? 2 * (W - 1) - max(ox0, W - 1 - R) : tx_hi;
-  const int wh = wy1 - wy0 + 1, ww = wx1 - wx0 + 1;          // <= TO
-  const int ih = wh + 2 * R, iw = ww + 2 * R;                // <= TI
+  const int wy0 = INTERIOR ? oy0 : ((oy0 == 0) ? -R : oy0);
+  const int wx0 = INTERIOR ? ox0 : ((ox0 == 0) ? -R : ox0);
+  const int wy1 = INTERIOR ? oy0 + kBlurTile - 1
+                           : ((ty_hi >= H - 1 - R && oy0 <= H - 2) ? 2 * (H - 1) - max(oy0, H - 1 - R) : ty_hi);
+  const int wx1 = INTERIOR ? ox0 + kBlurTile - 1
+                           : ((tx_hi >= W - 1 - R && ox0 <= W - 2) ? 2 * (W - 1) - max(ox0, W - 1 - R) : tx_hi);
+  const int wh = INTERIOR ? kBlurTile : wy1 - wy0 + 1, ww = INTERIOR ? kBlurTile : wx1 - wx0 + 1;
+  const int ih = INTERIOR ? TC : wh + 2 * R, iw = INTERIOR ? TC : ww + 2 * R;
   const size_t plane = (size_t)H * W;
   // this thread's pixels: state fetched first, used last
   float pp[NO], mk[NO], mm[NO], vv[NO], g0[NO];
@@ -171,7 +197,7 @@ __global__ void __launch_bounds__(kBlock) k_blur_bwd_fused(const float* __restri
     const int e = (int)threadIdx.x + j * kBlock;
     const int y = oy0 + e / kBlurTile, x = ox0 + (e & (kBlurTile - 1));
     pp[j] = mk[j] = mm[j] = vv[j] = g0[j] = 0.0f;
-    if (y < H && x < W) {
+    if (INTERIOR || (y < H && x < W)) {
       const size_t i = (size_t)c * plane + (size_t)y * W + x;
       pp[j] = p[i];
       if (accumulate) g0[j] = grad[i];
@@ -185,7 +211,7 @@ __global__ void __launch_bounds__(kBlock) k_blur_bwd_fused(const float* __restri
     }
   }
   // input tile: (gradient w.r.t. s) + imgfit'(s) inside the image, zero outside
-  const unsigned magic = (unsigned)((0x100000000ULL + (unsigned)iw - 1) / (unsigned)iw);   // e / iw for e < 2^16
+  const unsigned magic = INTERIOR ? 0u : (unsigned)((0x100000000ULL + (unsigned)iw - 1) / (unsigned)iw);   // e / iw, e < 2^16
   const int ne = ih * iw;
   float gv[NL], sv[NL];
 #pragma unroll
@@ -194,9 +220,9 @@ __global__ void __launch_bounds__(kBlock) k_blur_bwd_fused(const float* __restri
     gv[j] = 0.0f;
     sv[j] = 0.0f;
     if (e < ne) {
-      const int iy = (int)__umulhi((unsigned)e, magic), ix = e - iy * iw;
+      const int iy = INTERIOR ? e / TC : (int)__umulhi((unsigned)e, magic), ix = e - iy * iw;
       const int gy = wy0 - R + iy, gx = wx0 - R + ix;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      if (INTERIOR || (gy >= 0 && gy < H && gx >= 0 && gx < W)) {
         const size_t oidx = (size_t)c * plane + (size_t)gy * W + gx;
         gv[j] = gsrc[oidx];
         sv[j] = s[oidx];
@@ -207,19 +233,21 @@ __global__ void __launch_bounds__(kBlock) k_blur_bwd_fused(const float* __restri
   for (int j = 0; j < NL; ++j) {
     const int e = (int)threadIdx.x + j * kBlock;
     if (e < ne) {
-      const int iy = (int)__umulhi((unsigned)e, magic), ix = e - iy * iw;
+      const int iy = INTERIOR ? e / TC : (int)__umulhi((unsigned)e, magic), ix = e - iy * iw;
       const int gy = wy0 - R + iy, gx = wx0 - R + ix;
       float t = 0.0f;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) t = gv[j] + imgfit_grad(sv[j], c_fit);
+      if (INTERIOR || (gy >= 0 && gy < H && gx >= 0 && gx < W)) t = gv[j] + imgfit_grad(sv[j], c_fit);
       tile[iy][ix] = t;
     }
   }
   __syncthreads();
+  float w[K];
+  blur_weights_fetch<R>(wn, w);
   {
     // e / ww by multiplication (exact for e < 2^16); a one-column window divides by one
-    const unsigned mw = (ww > 1) ? (unsigned)((0x100000000ULL + (unsigned)ww - 1) / (unsigned)ww) : 0u;
+    const unsigned mw = (!INTERIOR && ww > 1) ? (unsigned)((0x100000000ULL + (unsigned)ww - 1) / (unsigned)ww) : 0u;
     for (int e = threadIdx.x; e < ih * ww; e += kBlock) {
-      const int iy = (ww > 1) ? (int)__umulhi((unsigned)e, mw) : e, x = e - iy * ww;
+      const int iy = INTERIOR ? e / kBlurTile : ((ww > 1) ? (int)__umulhi((unsigned)e, mw) : e), x = e - iy * ww;
       float a = 0.0f;
 #pragma unroll
       for (int t = 0; t < K; ++t) a += w[t] * tile[iy][x + t];
@@ -227,7 +255,7 @@ __global__ void __launch_bounds__(kBlock) k_blur_bwd_fused(const float* __restri
     }
     __syncthreads();
     for (int e = threadIdx.x; e < wh * ww; e += kBlock) {
-      const int y = (ww > 1) ? (int)__umulhi((unsigned)e, mw) : e, x = e - y * ww;
+      const int y = INTERIOR ? e / kBlurTile : ((ww > 1) ? (int)__umulhi((unsigned)e, mw) : e), x = e - y * ww;
       float a = 0.0f;
 #pragma unroll
       for (int t = 0; t < K; ++t) a += w[t] * tmp[y + t][x];
@@ -240,18 +268,22 @@ __global__ void __launch_bounds__(kBlock) k_blur_bwd_fused(const float* __restri
   for (int j = 0; j < NO; ++j) {
     const int e = (int)threadIdx.x + j * kBlock;
     const int y = oy0 + e / kBlurTile, x = ox0 + (e & (kBlurTile - 1));
-    if (y < H && x < W) {
-      // blur_fold: own position, the reflection about the first row / column, about the last
-      int yy[3], xx[3], ny = 0, nx = 0;
-      yy[ny++] = y;
-      if (y >= 1 && y <= R) yy[ny++] = -y;
-      if (y <= H - 2 && y >= H - 1 - R) yy[ny++] = 2 * (H - 1) - y;
-      xx[nx++] = x;
-      if (x >= 1 && x <= R) xx[nx++] = -x;
-      if (x <= W - 2 && x >= W - 1 - R) xx[nx++] = 2 * (W - 1) - x;
+    if (INTERIOR || (y < H && x < W)) {
       float gx = 0.0f;
-      for (int a = 0; a < ny; ++a)
-        for (int b = 0; b < nx; ++b) gx += c2t[yy[a] - wy0][xx[b] - wx0];
+      if (INTERIOR) {
+        gx += c2t[y - wy0][x - wx0];              // 0 + c2: what the one-term fold loop forms
+      } else {
+        // blur_fold: own position, the reflection about the first row / column, about the last
+        int yy[3], xx[3], ny = 0, nx = 0;
+        yy[ny++] = y;
+        if (y >= 1 && y <= R) yy[ny++] = -y;
+        if (y <= H - 2 && y >= H - 1 - R) yy[ny++] = 2 * (H - 1) - y;
+        xx[nx++] = x;
+        if (x >= 1 && x <= R) xx[nx++] = -x;
+        if (x <= W - 2 && x >= W - 1 - R) xx[nx++] = 2 * (W - 1) - x;
+        for (int a = 0; a < ny; ++a)
+          for (int b = 0; b < nx; ++b) gx += c2t[yy[a] - wy0][xx[b] - wx0];
+      }
       const size_t i = (size_t)c * plane + (size_t)y * W + x;
       float pv = pp[j];
       const float t = tanhf(pv);
@@ -281,6 +313,30 @@ __global__ void __launch_bounds__(kBlock) k_blur_bwd_fused(const float* __restri
     block_sum_store<1>(nacc, partials + blk);
     if (blk == 0 && threadIdx.x == 0) partials[kNormCountSlot] = (double)(gridDim.x * gridDim.y * gridDim.z);
   }
+}
+
+template <int R, bool UPDATE>
+__global__ void __launch_bounds__(kBlock) k_blur_bwd_fused(const float* __restrict__ gsrc, const float* __restrict__ s,
+                                                           int H, int W, float sigma,
+                                                           float eps, float c_fit, int accumulate, float* __restrict__ p,
+                                                           float* __restrict__ m, float* __restrict__ v,
+                                                           float* __restrict__ grad, const float* __restrict__ mask,
+                                                           OptScalars o, double* __restrict__ partials) {
+  // worst case: tile 0 of an image of 32 < H <= 32 + R rows folds from both borders: H + 2R <= 32 + 3R output rows
+  constexpr int K = 2 * R + 1, TI = kBlurTile + 5 * R, TO = kBlurTile + 3 * R;
+  __shared__ float tile[TI][TI + 1];
+  __shared__ float tmp[TI][TO + 1];
+  __shared__ float c2t[TO][TO + 1];
+  __shared__ float wn[K];
+  blur_weights_publish<R>(sigma, wn);
+  const int oy0 = blockIdx.y * kBlurTile, ox0 = blockIdx.x * kBlurTile;
+  // interior: the tile plus its 2R halo strictly inside the image, no pixel of it within R of the last row / column
+  const bool interior = oy0 >= kBlurTile && ox0 >= kBlurTile && oy0 + kBlurTile - 1 + 2 * R < H - 1 &&
+                        ox0 + kBlurTile - 1 + 2 * R < W - 1;
+  if (interior)
+    blur_bwd_body<R, UPDATE, true>(gsrc, s, H, W, eps, c_fit, accumulate, p, m, v, grad, mask, o, partials, wn, tile, tmp, c2t);
+  else
+    blur_bwd_body<R, UPDATE, false>(gsrc, s, H, W, eps, c_fit, accumulate, p, m, v, grad, mask, o, partials, wn, tile, tmp, c2t);
 }
 
 }  // namespace advx
