@@ -585,6 +585,12 @@ extern "C" int32_t advx_plan_upload(advx_plan* p, void* stream) {
   return ADVX_OK;
 }
 
+static inline TapRider no_rider() {
+  TapRider r;
+  std::memset(&r, 0, sizeof(r));
+  return r;
+}
+
 // ---------------------------------------------------------- windowed resizes (advx_resize.h)
 // T = compiled window size that holds `need` taps per axis (0: none - the run-time-loop kernels take over)
 static inline int pick_window(int need) {
@@ -637,6 +643,10 @@ static void launch_crop_bwd(const DStage& D, const float* gcan, float* gimg, int
 #define ADVX_CB(T_) hipLaunchKernelGGL((k_crop_bwd_t<T_>), grid, dim3(kRowBlock), 0, st, D, gcan, gimg, H, W, ci, cj)
     ADVX_WINDOW_SWITCH(T, ADVX_CB)
 #undef ADVX_CB
+    return;
+  }
+  if (!g_generic_kernels) {
+    hipLaunchKernelGGL(k_crop_bwd_rows, dim3((W + kRowBlock - 1) / kRowBlock, H, 3), dim3(kRowBlock), 0, st, D, gcan, gimg, H, W, ci, cj);
     return;
   }
   hipLaunchKernelGGL(k_crop_bwd, dim3(grid_for(3LL * H * W)), dim3(kBlock), 0, st, D, gcan, gimg, H, W, ci, cj);
@@ -721,7 +731,7 @@ extern "C" int32_t advx_emit_ex(advx_plan* p, const float* argument, int32_t bat
   dim3 grid(gx, slices);
 #define ADVX_EMIT_T(N, T)                                                                                           \
   hipLaunchKernelGGL((k_emit<N, T>), grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, \
-                     offset, (void*)out, q_lo, q_hi, live_lo, live_hi)
+                     offset, (void*)out, q_lo, q_hi, live_lo, live_hi, no_rider())
 #define ADVX_EMIT(N) \
   do { if (p->io == 0) ADVX_EMIT_T(N, 0); else if (p->io == 1) ADVX_EMIT_T(N, 1); else ADVX_EMIT_T(N, 2); } while (0)
   if (noise == 0) ADVX_EMIT(0); else if (noise == 1) ADVX_EMIT(1); else ADVX_EMIT(2);
@@ -832,11 +842,13 @@ static int32_t check_multi(int32_t n, advx_plan* const* plans, const int32_t* ba
 }
 
 namespace {
-struct PendingImageStats {   // statistics partials an advx_image_fwd left for the next launch to reduce
-  const double* partials = nullptr;
+struct PendingImageStats {   // what an advx_image_fwd left for the launches after it
+  const double* partials = nullptr;   // statistics partials for the next launch to reduce
   int nblk = 0;
   long long n_img = 0;
   float* stats = nullptr;
+  TapRider later;                     // the crop window's transposed tap tables, to ride in the emit (blocks > 0)
+  PendingImageStats() { std::memset(&later, 0, sizeof(later)); }
 };
 }  // namespace
 
@@ -918,12 +930,21 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
     max_gx = std::max(max_gx, a.gx);
     max_slices = std::max(max_slices, a.slices);
   }
+  // the crop window's transposed tables ride in the (first) emit launch when its grid has the blocks, else they get
+  // a launch of their own
+  TapRider rider = pend.later;
+  if (rider.blocks > 0 && 2 * rider.blocks > ((n > 1 && same_noise && !g_generic_kernels) ? max_gx : me.a[0].gx)) {
+    const int rows = std::max(rider.t[0].row_hi, rider.t[1].row_hi);
+    hipLaunchKernelGGL(k_build_taps, dim3((rows + kBlock - 1) / kBlock, 2), dim3(kBlock), 0, st, rider.t[0], rider.t[1]);
+    LAUNCH_CHECK();
+    rider = no_rider();
+  }
   if (n > 1 && same_noise && !g_generic_kernels) {
     // one launch for all plans: the plans fill each other's tails (same values: same counters, same offsets)
     dim3 grid(max_gx, max_slices, n);
-    if (noise_all == 0) hipLaunchKernelGGL(k_emit_multi<0>, grid, dim3(kBlock), 0, st, me, sigma_dev, seed);
-    else if (noise_all == 1) hipLaunchKernelGGL(k_emit_multi<1>, grid, dim3(kBlock), 0, st, me, sigma_dev, seed);
-    else hipLaunchKernelGGL(k_emit_multi<2>, grid, dim3(kBlock), 0, st, me, sigma_dev, seed);
+    if (noise_all == 0) hipLaunchKernelGGL(k_emit_multi<0>, grid, dim3(kBlock), 0, st, me, sigma_dev, seed, rider);
+    else if (noise_all == 1) hipLaunchKernelGGL(k_emit_multi<1>, grid, dim3(kBlock), 0, st, me, sigma_dev, seed, rider);
+    else hipLaunchKernelGGL(k_emit_multi<2>, grid, dim3(kBlock), 0, st, me, sigma_dev, seed, rider);
     LAUNCH_CHECK();
     return ADVX_OK;
   }
@@ -932,9 +953,10 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
     const EmitArgs& a = me.a[i];
     const int noise = a.unit_noise ? 1 : (use_philox ? 2 : 0);
     dim3 grid(a.gx, a.slices);
+    const TapRider ride_i = (i == 0) ? rider : no_rider();
 #define ADVX_EMIT_T(N, T)                                                                                                 \
   hipLaunchKernelGGL((k_emit<N, T>), grid, dim3(kBlock), 0, st, p->dplan, a.ws, a.batch, a.b_per_slice, sigma_dev, a.unit_noise, \
-                     seed, a.offset, a.out, a.q_lo, a.q_hi, a.live_lo, a.live_hi)
+                     seed, a.offset, a.out, a.q_lo, a.q_hi, a.live_lo, a.live_hi, ride_i)
 #define ADVX_EMIT(N) \
   do { if (p->io == 0) ADVX_EMIT_T(N, 0); else if (p->io == 1) ADVX_EMIT_T(N, 1); else ADVX_EMIT_T(N, 2); } while (0)
     if (noise == 0) ADVX_EMIT(0); else if (noise == 1) ADVX_EMIT(1); else ADVX_EMIT(2);
@@ -1055,6 +1077,7 @@ int32_t build_crop_stage(int H, int W, const int32_t* crop, Bump& b, hipStream_t
   for (int ax = 0; ax < 2; ++ax) {
     a[ax].mode = ADVX_MODE_AA_BILINEAR; a[ax].in_size = ins[ax]; a[ax].out_size = outs[ax];
     a[ax].stride = strides[ax]; a[ax].tstride = tstrides[ax];
+    a[ax].row_lo = 0; a[ax].row_hi = outs[ax] + ins[ax];
     a[ax].start = reinterpret_cast<int*>(b.take(outs[ax]));
     a[ax].count = reinterpret_cast<int*>(b.take(outs[ax]));
     a[ax].w = b.take((long long)outs[ax] * strides[ax]);
@@ -1127,6 +1150,17 @@ static int32_t image_fwd_impl(const float* p, const float* x0, int32_t H, int32_
     int32_t rc = build_crop_stage(H, W, crop, b, st, &crop_stage, false, taps);
     if (rc) return rc;
     tap_blocks = (std::max(H + crop[2], W + crop[3]) + kBlock - 1) / kBlock;
+    if (defer && !g_generic_kernels) {
+      // the forward needs only the forward tables; a transposed row costs two binary searches and several rows of
+      // weights and made the launch it rode in 3 us longer.  Those rows go to the caller's emit (17 us: hidden there).
+      for (int ax = 0; ax < 2; ++ax) {
+        defer->later.t[ax] = taps[ax];
+        defer->later.t[ax].row_lo = taps[ax].out_size;
+        taps[ax].row_hi = taps[ax].out_size;
+      }
+      defer->later.blocks = (std::max(crop[2], crop[3]) + kBlock - 1) / kBlock;
+      tap_blocks = (std::max(H, W) + kBlock - 1) / kBlock;
+    }
   }
   int nblk;
   if (blur_k > 0) {
@@ -1213,8 +1247,7 @@ extern "C" int32_t advx_forward_multi(const float* p, const float* x0, int32_t H
                                       const uint64_t* offsets, void* const* outs, float* const* wss,
                                       const int64_t* ws_floats, int32_t pad_mode, void* stream) {
   PendingImageStats pend;
-  int32_t rc = image_fwd_impl(p, x0, H, W, eps, blur_k, blur_sigma, crop, s, argument, stats, image_scratch,
-                              crop ? nullptr : &pend, stream);
+  int32_t rc = image_fwd_impl(p, x0, H, W, eps, blur_k, blur_sigma, crop, s, argument, stats, image_scratch, &pend, stream);
   if (rc) return rc;
   const float* arg = (crop || (argument && argument != s)) ? argument : s;
   rc = emit_multi_impl(n, plans, arg, batches, stats + ADVX_STAT_SIGMA, unit_noises, use_philox, seed, offsets, outs, wss,
@@ -1223,6 +1256,12 @@ extern "C" int32_t advx_forward_multi(const float* p, const float* x0, int32_t H
     // the emit was refused after the image kernels ran: do not leave the statistics unreduced
     hipLaunchKernelGGL(k_finalize_image, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, pend.partials, pend.nblk, pend.n_img,
                        pend.stats);
+  }
+  if (rc && pend.later.blocks > 0) {
+    // ... nor the transposed tables the backward will look for unbuilt
+    const int rows = std::max(pend.later.t[0].row_hi, pend.later.t[1].row_hi);
+    hipLaunchKernelGGL(k_build_taps, dim3((rows + kBlock - 1) / kBlock, 2), dim3(kBlock), 0, (hipStream_t)stream, pend.later.t[0],
+                       pend.later.t[1]);
   }
   return rc;
 }
@@ -2166,7 +2205,7 @@ extern "C" int32_t advx_prepared_fwd(advx_plan* p, const float* pp, const float*
   const float* sigma_dev = stats + ADVX_STAT_QERR_STD;   // quantise error of the PREVIOUS image (not yet rotated)
 #define ADVX_EMIT_T(N, T)                                                                                           \
   hipLaunchKernelGGL((k_emit<N, T>), grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, \
-                     offset, (void*)out, q_lo, q_hi, live_lo, live_hi)
+                     offset, (void*)out, q_lo, q_hi, live_lo, live_hi, no_rider())
 #define ADVX_EMIT(N) \
   do { if (p->io == 0) ADVX_EMIT_T(N, 0); else if (p->io == 1) ADVX_EMIT_T(N, 1); else ADVX_EMIT_T(N, 2); } while (0)
   if (noise == 0) ADVX_EMIT(0); else if (noise == 1) ADVX_EMIT(1); else ADVX_EMIT(2);

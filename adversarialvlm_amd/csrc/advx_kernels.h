@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_flush(FusedHeader* __restrict_
 // window changes every step).  blockIdx.y = axis; rows [0,out) forward, [out,out+in) transposed.
 struct TapBuild {
   int mode, in_size, out_size, stride, tstride;
+  int row_lo, row_hi;   // the rows of [0, out_size + in_size) this launch builds (the transposed rows may ride in a later one)
   int* start;
   int* count;
   float* w;
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(kBlock) k_build_taps(TapBuild a0, TapBuild a1)
   build_taps_row((blockIdx.y == 0) ? a0 : a1, blockIdx.x * blockDim.x + threadIdx.x);
 }
 __device__ inline void build_taps_row(const TapBuild& a, int i) {
-  float row[64];
+  if (i < a.row_lo || i >= a.row_hi) return;
   if (i < a.out_size) {
     float* w = a.w + (size_t)i * a.stride;
     TapRow r = tap_row(a.mode, a.in_size, a.out_size, i, a.stride, w);
@@ -139,13 +140,22 @@ __device__ inline void build_taps_row(const TapBuild& a, int i) {
     a.tstart[j] = t.start;
     a.tcount[j] = t.count;
     float* tw = a.tw + (size_t)j * a.tstride;
-    for (int q = 0; q < a.tstride; ++q) tw[q] = 0.0f;
     int st = a.stride < 64 ? a.stride : 64;
-    for (int q = 0; q < t.count; ++q) {
-      TapRow r = tap_row(a.mode, a.in_size, a.out_size, t.start + q, st, row);
-      int slot = j - r.start;
-      tw[q] = (slot >= 0 && slot < st) ? row[slot] : 0.0f;
-    }
+    // no row buffer indexed at run time: a kernel that carries these rows needs no scratch memory
+    for (int q = 0; q < a.tstride; ++q) tw[q] = (q < t.count) ? tap_weight(a.mode, a.in_size, a.out_size, t.start + q, j, st) : 0.0f;
+  }
+}
+// the rows of a TapRider are built by the first workgroups of the launch that carries it (row r of axis k by thread
+// r - row_lo of its axis' blocks)
+struct TapRider {
+  TapBuild t[2];
+  int blocks;          // per axis; 0: nothing rides
+};
+__device__ inline void ride_taps(const TapRider& tr, unsigned block) {
+  if (block < 2u * (unsigned)tr.blocks) {
+    const int axis = block >= (unsigned)tr.blocks;
+    const TapBuild& a = axis ? tr.t[1] : tr.t[0];
+    build_taps_row(a, a.row_lo + (int)(block - (unsigned)axis * tr.blocks) * (int)blockDim.x + (int)threadIdx.x);
   }
 }
 
@@ -768,7 +778,11 @@ __global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restri
                                                  const float* __restrict__ sigma_dev, const float* __restrict__ unit_noise,
                                                  unsigned long long seed, unsigned long long offset,
                                                  void* __restrict__ out, long long q_lo, long long q_hi,
-                                                 long long live_lo, long long live_hi) {
+                                                 long long live_lo, long long live_hi, TapRider rider) {
+  // the crop window's transposed tap tables (read by the backward) built by the first workgroups of this launch, which
+  // then go on with their own columns: hidden in a launch this long, where the image kernels they used to ride in
+  // were extended by them (advx_forward_multi)
+  if (blockIdx.y == 0) ride_taps(rider, blockIdx.x);
   emit_body<NOISE, IO>(pl, ws, batch, b_per_slice, sigma_dev, unit_noise, seed, offset, out, q_lo, q_hi, live_lo, live_hi,
                        blockIdx.x, blockIdx.y);
 }
@@ -790,7 +804,9 @@ struct MultiEmit {
   EmitArgs a[kMaxMulti];
 };
 template <int NOISE>
-__global__ void __launch_bounds__(kBlock) k_emit_multi(MultiEmit me, const float* __restrict__ sigma_dev, unsigned long long seed) {
+__global__ void __launch_bounds__(kBlock) k_emit_multi(MultiEmit me, const float* __restrict__ sigma_dev, unsigned long long seed,
+                                                       TapRider rider) {
+  if (blockIdx.z == 0 && blockIdx.y == 0) ride_taps(rider, blockIdx.x);   // as in k_emit
 #pragma unroll
   for (int k = 0; k < kMaxMulti; ++k) {
     if (k != (int)blockIdx.z) continue;          // static indices into the kernel arguments

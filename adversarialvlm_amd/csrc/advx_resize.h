@@ -108,4 +108,15 @@ __global__ void __launch_bounds__(kRowBlock) k_crop_bwd_t(DStage st, const float
   if (x < W) gimg[((size_t)c * H + y) * W + x] = crop_bwd_value_t<T>(st, gcan, ci, cj, c, y, x);
 }
 
+// k_crop_bwd on the (column chunk, row, channel) grid with crop_bwd_value's run-time loops: no thread divides to find its
+// pixel (the 1-D grid-stride form spends ~35 instructions per element on two run-time divisions), the window row's
+// vertical taps are uniform, and only taps that exist are loaded.  These kernels are bound by the instructions a SIMD has
+// to issue for its few waves, so fewer instructions per element is what pays: 10.4 -> see DESIGN.md 5.
+__global__ void __launch_bounds__(kRowBlock) k_crop_bwd_rows(DStage st, const float* __restrict__ gcan, float* __restrict__ gimg,
+                                                             int H, int W, int ci, int cj) {
+  const int c = blockIdx.z, y = blockIdx.y;
+  const int x = blockIdx.x * kRowBlock + threadIdx.x;
+  if (x < W) gimg[((size_t)c * H + y) * W + x] = crop_bwd_value(st, gcan, ci, cj, c, y, x);
+}
+
 }  // namespace advx

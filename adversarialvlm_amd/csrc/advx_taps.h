@@ -153,6 +153,34 @@ ADVX_HD TapRow tap_row(int mode, int in_size, int out_size, int i, int stride, f
   return r;
 }
 
+// weight of source index j in output row i (tap_row(...)[j - start], 0 outside the row): the same operations in the
+// same order as tap_row, without a row buffer the caller would index at run time
+ADVX_HD float tap_weight(int mode, int in_size, int out_size, int i, int j, int stride) {
+  if (mode == ADVX_MODE_AA_BILINEAR) {
+    TapRow r = tap_bounds(mode, in_size, out_size, i);
+    float scale = tap_scale(in_size, out_size);
+    float invscale = (scale >= 1.0f) ? (float)(1.0 / (double)scale) : 1.0f;
+    float center = (float)((double)scale * ((double)i + 0.5));
+    float total = 0.0f, wj = 0.0f;
+    for (int q = 0; q < r.count && q < stride; ++q) {
+      float d = (float)(q + r.start) - center;
+      float arg = (float)(((double)d + 0.5) * (double)invscale);
+      float a = fabsf(arg);
+      float wt = (a < 1.0f) ? (1.0f - a) : 0.0f;
+      total += wt;
+      if (q + r.start == j) wj = wt;
+    }
+    if (total != 0.0f) wj *= (float)(1.0 / (double)total);
+    return wj;
+  }
+  float w[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  TapRow r = tap_row(mode, in_size, out_size, i, stride < 4 ? stride : 4, w);
+  int slot = j - r.start;
+  int lim = stride < 4 ? stride : 4;
+  if (slot < 0 || slot >= lim) return 0.0f;
+  return slot == 0 ? w[0] : slot == 1 ? w[1] : slot == 2 ? w[2] : w[3];
+}
+
 // Outputs that read source index j form a contiguous range because start(i) and
 // start(i)+count(i) are both non-decreasing in i: [first i with end(i) > j, last i with
 // start(i) <= j].  Returned as (start, count) over OUTPUT indices (count may be 0).

@@ -105,6 +105,10 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
+def main_step_is_cold(args):
+    return args.cache in ("both", "cold")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,18 +228,19 @@ def main():
 
     from adversarialvlm_amd import ops
 
-    def timed(step):
+    def timed(step, steps=None, warmup=None):
         """W warm-up steps, then exactly K steps between two fences; MAX over ranks.  Every stride-th launch of the
         B*P_out movers carries its own start/stop HIP event pair on the launch stream (advx_profile_*,
         hipExtLaunchKernelGGL); the stride is chosen so that at least 10 launches per kernel are timed whatever
         K >= 10 is (64 from K = 640 up).  A timed launch is fenced off from its neighbours by the event
         packets (measured: +2.5 us per step at stride 1), which is why not every launch is timed."""
-        for _ in range(args.warmup):
+        steps = args.steps if steps is None else steps
+        for _ in range(args.warmup if warmup is None else warmup):
             step()
         fence()
-        ops.profile_begin(max(args.steps, 1), stride=max(1, args.steps // (64 if args.steps >= 640 else 10)))
+        ops.profile_begin(max(steps, 1), stride=max(1, steps // (64 if steps >= 640 else 10)))
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
         fence()
         dt = time.perf_counter() - t0
@@ -252,6 +257,13 @@ def main():
     held.clear()
     if args.cache in ("both", "hot"):
         runs["hot"] = timed(step_hot)
+    # A short timed region (the driver's K = 20 is 0.8 ms of device work) carries fixed costs - first launch after the
+    # fence, the fence itself, one timed launch in two - of about 130 us: the same loop over 1000 steps is reported
+    # beside it as `long_run` (supplementary; `value` stays the K steps asked for).
+    long_run = None
+    if args.steps < 500 and main_step_is_cold(args):
+        long_run = timed(step_cold, steps=1000, warmup=0)
+        held.clear()
     # The same cold steps as a captured hipGraph (supplementary figure): `ring` steps of the pair - forward and backward
     # with their per-step scalars in device memory (advx_fused_*_sched) - captured once and replayed; no host work per
     # launch.  Single rank, pair chain only.
@@ -374,6 +386,12 @@ def main():
             roofline["kernel_ms_in_cache"] = kernel_ms(hprof)
             roofline["kernel_frac_in_cache"] = kernel_fracs(hprof)
             roofline["step_frac_of_hbm_peak_in_cache"] = round(bytes_step * (args.steps / hdt) / 1e9 / HBM_PEAK_GBS, 4)
+        if long_run is not None:
+            ldt, lprof = long_run
+            line["long_run"] = {"value": round(1000 / ldt * B * world, 1), "unit": "prompt-steps/s", "steps": 1000,
+                                "ms_per_step": round(ldt / 1000 * 1e3, 5), "kernel_ms": kernel_ms(lprof),
+                                "note": f"the same cold loop over 1000 steps, timed after the K = {args.steps} above: fixed costs "
+                                        "of a short region (first launch, fence, timed launches) amortised; supplementary"}
         if isinstance(graph_run, str):
             line["graph_replay"] = {"error": graph_run[:300]}
         elif graph_run is not None:
