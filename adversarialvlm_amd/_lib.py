@@ -18,6 +18,7 @@ STAT_SIGMA, STAT_QERR_STD, STAT_QERR_MEAN, STAT_QERR_L1, STAT_IMGFIT, STAT_X_MEA
 STATS_N = 16
 MAX_STAGES = 2
 TUNE_GENERIC_KERNELS = 1
+TUNE_FULL_TAP_ROWS = 3
 
 
 class AdvxError(RuntimeError):

@@ -45,6 +45,7 @@ static int32_t fail(int32_t code, const std::string& msg) {
 // compare the specialised kernels with them bit for bit)
 static int g_generic_kernels = 0;
 static int g_pair_nt_loads = 0;
+static int g_full_tap_rows = 0;
 extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
   if (what == ADVX_TUNE_GENERIC_KERNELS) {
     g_generic_kernels = value ? 1 : 0;
@@ -52,6 +53,10 @@ extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
   }
   if (what == ADVX_TUNE_PAIR_NT_LOADS) {
     g_pair_nt_loads = value ? 1 : 0;
+    return ADVX_OK;
+  }
+  if (what == ADVX_TUNE_FULL_TAP_ROWS) {
+    g_full_tap_rows = value ? 1 : 0;
     return ADVX_OK;
   }
   return fail(ADVX_E_BADARG, "advx_set_tuning: unknown switch");
@@ -529,6 +534,35 @@ extern "C" int32_t advx_plan_out_index(const advx_plan* p, int32_t stage, int32_
 }
 
 // ---- upload of the tap tables
+// The device copies drop the taps of weight exactly zero at either end of a row.  A resize between equal sizes (Qwen2-VL
+// and Phi-3.5 at 336 x 336: the reference's cross-model preset) has bicubic rows (0, 1, 0, 0): sixteen loads per gathered
+// value of which one counts.  The sums are unchanged bit for bit: an accumulator that starts at +0 stays what it was
+// after adding 0 * x for finite x.  The tables the C ABI hands out (advx_plan_taps) keep ATen's index ranges.
+static HostTaps trim_zero_taps(const HostTaps& t) {
+  HostTaps r;
+  r.n = t.n;
+  r.start = t.start;
+  r.count = t.count;
+  std::vector<int> lead(t.n, 0);
+  int mx = 1;
+  for (int i = 0; i < t.n; ++i) {
+    const float* w = &t.w[(size_t)i * t.stride];
+    int lo = 0, hi = std::min(t.count[i], t.stride);
+    while (lo < hi && w[lo] == 0.0f) ++lo;
+    while (hi > lo && w[hi - 1] == 0.0f) --hi;
+    if (t.count[i] > t.stride) { lo = 0; hi = t.count[i]; }   // never the case for tables built here
+    lead[i] = lo;
+    r.start[i] = (hi > lo) ? t.start[i] + lo : t.start[i];
+    r.count[i] = hi - lo;
+    mx = std::max(mx, r.count[i]);
+  }
+  r.stride = mx;
+  r.w.assign((size_t)t.n * mx, 0.0f);
+  for (int i = 0; i < t.n; ++i)
+    for (int q = 0; q < r.count[i]; ++q) r.w[(size_t)i * mx + q] = t.w[(size_t)i * t.stride + lead[i] + q];
+  return r;
+}
+
 static size_t taps_bytes(const HostTaps& t) { return (((size_t)t.n * 2 * sizeof(int) + (size_t)t.n * t.stride * sizeof(float)) + 255) / 256 * 256; }
 
 static void place_taps(const HostTaps& t, char* host, char* dev, size_t& off, DevTaps* d) {
@@ -555,8 +589,14 @@ extern "C" int32_t advx_plan_upload(advx_plan* p, void* stream) {
     p->uploaded = false;
   }
   size_t total = 0;
-  for (int k = 0; k < p->info.n_stage; ++k)
-    total += taps_bytes(p->st[k].th) + taps_bytes(p->st[k].tw) + taps_bytes(p->st[k].tth) + taps_bytes(p->st[k].ttw);
+  HostTaps dev_taps[ADVX_MAX_STAGES][4];
+  for (int k = 0; k < p->info.n_stage; ++k) {
+    const HostTaps* src[4] = {&p->st[k].th, &p->st[k].tw, &p->st[k].tth, &p->st[k].ttw};
+    for (int a = 0; a < 4; ++a) {
+      dev_taps[k][a] = g_full_tap_rows ? *src[a] : trim_zero_taps(*src[a]);
+      total += taps_bytes(dev_taps[k][a]);
+    }
+  }
   std::vector<char> host(total, 0);
   void* block = nullptr;
   HIP_TRY(hipMalloc(&block, total));
@@ -568,10 +608,10 @@ extern "C" int32_t advx_plan_upload(advx_plan* p, void* stream) {
     D.can_h = s.can_h; D.can_w = s.can_w; D.off_y = s.off_y; D.off_x = s.off_x; D.pad_value = s.pad_value;
     D.normalise = s.normalise; D.inner_axis_h = s.inner_axis_h;
     for (int c = 0; c < 3; ++c) { D.mean[c] = p->desc.mean[c]; D.stdv[c] = p->desc.std[c]; }
-    place_taps(p->st[k].th, host.data(), (char*)block, off, &D.th);
-    place_taps(p->st[k].tw, host.data(), (char*)block, off, &D.tw);
-    place_taps(p->st[k].tth, host.data(), (char*)block, off, &D.tth);
-    place_taps(p->st[k].ttw, host.data(), (char*)block, off, &D.ttw);
+    place_taps(dev_taps[k][0], host.data(), (char*)block, off, &D.th);
+    place_taps(dev_taps[k][1], host.data(), (char*)block, off, &D.tw);
+    place_taps(dev_taps[k][2], host.data(), (char*)block, off, &D.tth);
+    place_taps(dev_taps[k][3], host.data(), (char*)block, off, &D.ttw);
   }
   hipError_t e = hipMemcpy(block, host.data(), total, hipMemcpyHostToDevice);
   if (e != hipSuccess) {

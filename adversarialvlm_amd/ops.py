@@ -21,6 +21,17 @@ class generic_kernels:
         L.check(L.load().advx_set_tuning(L.TUNE_GENERIC_KERNELS, 0), "advx_set_tuning")
 
 
+class full_tap_rows:
+    """Context manager (tests): plans UPLOADED inside keep ATen's full tap rows on the device instead of the rows with the
+    zero-weight end taps dropped.  Results must be bit-identical."""
+
+    def __enter__(self):
+        L.check(L.load().advx_set_tuning(L.TUNE_FULL_TAP_ROWS, 1), "advx_set_tuning")
+
+    def __exit__(self, *exc):
+        L.check(L.load().advx_set_tuning(L.TUNE_FULL_TAP_ROWS, 0), "advx_set_tuning")
+
+
 def _require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:

@@ -120,6 +120,8 @@ const char* advx_last_error(void);
  * is what the tests use it for.  Process-wide, not thread-safe. */
 #define ADVX_TUNE_GENERIC_KERNELS 1
 #define ADVX_TUNE_PAIR_NT_LOADS 2   /* advx_fused_bwd reads grad_out with non-temporal loads (same results) */
+#define ADVX_TUNE_FULL_TAP_ROWS 3   /* plans uploaded from now on keep ATen's full tap rows on the device; by default the
+                                     * device copies drop the zero-weight taps at the ends of a row (same results) */
 int32_t advx_set_tuning(int32_t what, int32_t value);
 
 /* ------------------------------------------------------------------ plans

@@ -213,6 +213,58 @@ def test_cross_chain_windowed_equals_general():
             assert torch.equal(u, v), float((u - v).abs().max())
 
 
+def _trim_plans():
+    from adversarialvlm_amd.plan import Plan
+    return {
+        # equal sizes: bicubic rows (0, 1, 0, 0) - the reference's cross preset runs Phi-3.5 and Qwen2-VL at 336 x 336
+        "qwen336": lambda: Plan.qwen2vl(336, 336),
+        "phi3_336": lambda: Plan.phi3(336, 336),
+        "qwen_equal_small": lambda: Plan.qwen2vl(56, 84, min_pixels=28 * 28, max_pixels=28 * 28 * 16),
+        "mllama336": lambda: Plan.mllama(336, 336),
+        "llava_up2": lambda: Plan.llava(32, 48, 64, 96),           # exact 2x: bilinear-family rows with zero ends
+        "llava512": lambda: Plan.llava(512, 512),
+        "phi3_tall": lambda: Plan.phi3(700, 300),
+    }
+
+
+@pytest.mark.parametrize("name", sorted(_trim_plans()))
+def test_trimmed_tap_rows_equal_full_rows(name):
+    """The device tables drop zero-weight taps at the ends of a row (advx_plan_upload); a plan uploaded under
+    ops.full_tap_rows() keeps ATen's rows.  Forward, gradient and three prepared steps: identical bits."""
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.pgd import PixelPGD
+    gen = torch.Generator().manual_seed(13)
+    mk = _trim_plans()[name]
+    plan0 = mk()
+    x0 = torch.rand(3, plan0.in_h, plan0.in_w, generator=gen)
+    img = x0.to(DEV)
+    B = 2
+    gs = [torch.randn(B, plan0.out_numel, generator=gen) * 0.05 for _ in range(3)]
+
+    def go():
+        plan = mk()
+        res = [ops.emit(plan, img, B)]
+        res.append(ops.collect(plan, gs[0].to(DEV).view_as(res[0]), B))
+        eng = PixelPGD(x0.to(DEV), [mk()], lr=1e-2, fused_mode="prepared")
+        for t in range(3):
+            pv = eng.forward(B)[0]
+            eng.backward_update([gs[t].to(DEV).view_as(pv)])
+            res += [pv.clone(), eng.p.clone()]
+        eng = PixelPGD(x0.to(DEV), [mk()], lr=1e-2, blur_kernel=3, allow_fused=False)
+        for t in range(2):
+            pv = eng.forward(B, blur_sigma=0.8)[0]
+            eng.backward_update([gs[t].to(DEV).view_as(pv)])
+            res += [pv.clone(), eng.p.clone(), eng.grad.clone()]
+        return res
+
+    fast = go()
+    with ops.full_tap_rows():
+        ref = go()
+    assert len(fast) == len(ref)
+    for u, v in zip(fast, ref):
+        assert torch.equal(u, v), (name, float((u - v).abs().max()))
+
+
 def test_large_image_takes_the_general_backward():
     """Beyond 2048 tiles (here 33 x 33 x 3) the merged backward has no room for its ||g|| partials and the host falls
     back to k_blur<1,2> + k_bwd_update<1>; the forward stays radius-templated.  Same bits either way."""
