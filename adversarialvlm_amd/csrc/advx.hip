@@ -834,8 +834,28 @@ static int32_t reduce_to_canvas(advx_plan* p, const void* grad_out, int batch, f
   plan_live_range(p, &lo, &hi);   // what lies outside is constant padding whose gradient goes nowhere
   return launch_batch_reduce(reinterpret_cast<const float*>(grad_out), batch, p->info.out_numel, ws, st, lo, hi, p->io, &p->dplan);
 }
+// The gradient a later stage propagates into canvas k (Phi-3.5's global view into the hd canvas) is ADDED to the
+// batch-reduced sums of that canvas where they stand instead of going to a buffer of its own: the transposed resize of
+// stage k then reads one value per tap, not two.  Allowed when the sums are one image that the reduction rewrites
+// completely every step (the emits cover the whole canvas); (0 + sum) + d and sum + d are the same float.
+static bool dgrad_into_gcan(const advx_plan* p, int k) {
+  if (g_generic_kernels || p->dplan.gcan_off[k] < 0 || p->dplan.gcan_copies[k] != 1) return false;
+  long long covered = 0;
+  for (int j = 0; j < p->dplan.n_emit; ++j)
+    if (p->dplan.e[j].stage == k) covered += p->dplan.e[j].out_count;
+  return covered == 3LL * p->st[k].info.can_h * p->st[k].info.can_w;
+}
+// where the backward of a stage that reads canvas `src_canvas` writes, and whether it accumulates there
+static float* dgrad_target(const advx_plan* p, int src_canvas, float* ws, int* accumulate) {
+  if (dgrad_into_gcan(p, src_canvas)) {
+    *accumulate = 1;
+    return ws + p->dplan.gcan_off[src_canvas];
+  }
+  *accumulate = 0;
+  return ws + p->dplan.dgrad_off[src_canvas];
+}
 static CanvasGrad stage_grad(const advx_plan* p, int k, const float* ws) {
-  const float* dgrad = (p->dplan.dgrad_off[k] >= 0) ? ws + p->dplan.dgrad_off[k] : nullptr;
+  const float* dgrad = (p->dplan.dgrad_off[k] >= 0 && !dgrad_into_gcan(p, k)) ? ws + p->dplan.dgrad_off[k] : nullptr;
   return canvas_grad_of(p->dplan, k, p->dstage[k].can_h, p->dstage[k].can_w, ws, dgrad);
 }
 
@@ -852,8 +872,8 @@ extern "C" int32_t advx_collect(advx_plan* p, const float* grad_out, int32_t bat
   for (int k = p->info.n_stage - 1; k >= 0; --k) {
     const DStage& D = p->dstage[k];
     const advx_stage_info& s = p->st[k].info;
-    float* gsrc = (s.src == 0) ? grad_argument : ws + p->dplan.dgrad_off[s.src - 1];
-    int acc = (s.src == 0) ? accumulate : 0;
+    int acc = accumulate;
+    float* gsrc = (s.src == 0) ? grad_argument : dgrad_target(p, s.src - 1, ws, &acc);
     const int rowblk = 128;   // two waves along x: little waste on the last chunk of a 336 / 512 / 672-wide row
     hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D, stage_grad(p, k, ws),
                        gsrc, (long long)D.src_h * D.src_w, D.src_w, acc);
@@ -980,7 +1000,8 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
     rider = no_rider();
   }
   if (n > 1 && same_noise && !g_generic_kernels) {
-    // one launch for all plans: the plans fill each other's tails (same values: same counters, same offsets)
+    // one launch for all plans: the plans fill each other's tails (same values: same counters, same offsets).
+    // (Largest plan first in the grid: no change for the emits, 3 us WORSE for the merged reductions - kept in caller order.)
     dim3 grid(max_gx, max_slices, n);
     if (noise_all == 0) hipLaunchKernelGGL(k_emit_multi<0>, grid, dim3(kBlock), 0, st, me, sigma_dev, seed, rider);
     else if (noise_all == 1) hipLaunchKernelGGL(k_emit_multi<1>, grid, dim3(kBlock), 0, st, me, sigma_dev, seed, rider);
@@ -1034,12 +1055,48 @@ extern "C" int32_t advx_collect_multi(int32_t n, advx_plan* const* plans, const 
     mb.st[i] = p->dstage[0];
     mb.cg[i] = stage_grad(p, 0, wss[i]);
   }
-  // one batch reduction per plan.  (All plans in ONE launch was tried: the merged kernel - six load variants behind a
-  // switch, the per-plan arguments selected from a kernel-argument array - went through scratch memory and took
-  // 850 us instead of 45.)
-  for (int i = 0; i < n; ++i) {
-    rc = reduce_to_canvas(plans[i], grad_outs[i], batches[i], wss[i], st);
-    if (rc) return rc;
+  // the batch reductions: one launch for all plans when they read the same way (same boundary dtype, all cached or
+  // all streamed), else one per plan
+  {
+    MultiReduce mr;
+    std::memset(&mr, 0, sizeof(mr));
+    mr.n = n;
+    int code_all = -1, max_blocks = 0;
+    bool merge = n > 1 && !g_generic_kernels;
+    for (int i = 0; i < n && merge; ++i) {
+      advx_plan* p = plans[i];
+      const long long nn = p->info.out_numel;
+      if ((nn & 3) != 0 || !aligned16(grad_outs[i]) || !aligned16(wss[i])) { merge = false; break; }
+      long long lo, hi;
+      plan_live_range(p, &lo, &hi);
+      ReduceArgs& a = mr.a[i];
+      a.pl = p->dplan; a.g = grad_outs[i]; a.out = wss[i]; a.n = nn; a.batch = batches[i];
+      a.q_lo = lo >> 2; a.q_hi = (std::min(hi, nn) + 3) >> 2;
+      if (a.q_hi <= a.q_lo) { merge = false; break; }
+      a.blocks = (int)((a.q_hi - a.q_lo + kWave - 1) / kWave);
+      const double read_bytes = (double)a.batch * (double)(a.q_hi - a.q_lo) * (p->io == 0 ? 16.0 : 8.0);
+      const int code = p->io + ((read_bytes > 256.0 * 1024 * 1024) ? 3 : 0);     // as launch_batch_reduce
+      if (code_all < 0) code_all = code;
+      if (code != code_all) merge = false;
+      max_blocks = std::max(max_blocks, a.blocks);
+    }
+    if (merge) {
+      dim3 grid(max_blocks, n);
+      switch (code_all) {
+        case 0: hipLaunchKernelGGL(k_batch_reduce_multi<0>, grid, dim3(kBlock), 0, st, mr); break;
+        case 1: hipLaunchKernelGGL(k_batch_reduce_multi<1>, grid, dim3(kBlock), 0, st, mr); break;
+        case 2: hipLaunchKernelGGL(k_batch_reduce_multi<2>, grid, dim3(kBlock), 0, st, mr); break;
+        case 3: hipLaunchKernelGGL(k_batch_reduce_multi<3>, grid, dim3(kBlock), 0, st, mr); break;
+        case 4: hipLaunchKernelGGL(k_batch_reduce_multi<4>, grid, dim3(kBlock), 0, st, mr); break;
+        default: hipLaunchKernelGGL(k_batch_reduce_multi<5>, grid, dim3(kBlock), 0, st, mr); break;
+      }
+      LAUNCH_CHECK();
+    } else {
+      for (int i = 0; i < n; ++i) {
+        rc = reduce_to_canvas(plans[i], grad_outs[i], batches[i], wss[i], st);
+        if (rc) return rc;
+      }
+    }
   }
   const int rowblk = 128;
   for (int i = 0; i < n; ++i) {
@@ -1048,9 +1105,10 @@ extern "C" int32_t advx_collect_multi(int32_t n, advx_plan* const* plans, const 
       const DStage& D = p->dstage[k];
       const advx_stage_info& s = p->st[k].info;
       REQUIRE(s.src >= 1, ADVX_E_UNSUPPORTED, "advx_collect_multi: only stage 0 may read the image");
-      float* gsrc = wss[i] + p->dplan.dgrad_off[s.src - 1];
+      int acc = 0;
+      float* gsrc = dgrad_target(p, s.src - 1, wss[i], &acc);
       hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D,
-                         stage_grad(p, k, wss[i]), gsrc, (long long)D.src_h * D.src_w, D.src_w, 0);
+                         stage_grad(p, k, wss[i]), gsrc, (long long)D.src_h * D.src_w, D.src_w, acc);
       LAUNCH_CHECK();
     }
   }
@@ -2184,10 +2242,11 @@ static void prepared_upper_bwd(advx_plan* p, float* ws, hipStream_t st) {
   for (int k = p->info.n_stage - 1; k >= 1; --k) {
     const DStage& D = p->dstage[k];
     const advx_stage_info& s = p->st[k].info;
-    float* gsrc = ws + p->dplan.dgrad_off[s.src - 1];
+    int acc = 0;
+    float* gsrc = dgrad_target(p, s.src - 1, ws, &acc);
     const int rowblk = 128;
     hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D, stage_grad(p, k, ws),
-                       gsrc, (long long)D.src_h * D.src_w, D.src_w, 0);
+                       gsrc, (long long)D.src_h * D.src_w, D.src_w, acc);
   }
 }
 

@@ -498,9 +498,10 @@ __global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, CanvasGrad cg, 
   const int c = blockIdx.z, ys = blockIdx.y;
   const int xs = blockIdx.x * blockDim.x + threadIdx.x;
   if (xs < st.src_w) {
-    float v = stage_bwd_value(st, cg, c, ys, xs);
-    size_t o = (size_t)c * gsrc_cstride + (size_t)ys * gsrc_rstride + xs;
-    gsrc[o] = accumulate ? (gsrc[o] + v) : v;
+    const size_t o = (size_t)c * gsrc_cstride + (size_t)ys * gsrc_rstride + xs;
+    const float before = accumulate ? gsrc[o] : 0.0f;     // in flight while the taps are gathered
+    const float v = stage_bwd_value(st, cg, c, ys, xs);
+    gsrc[o] = accumulate ? (before + v) : v;
   }
 }
 
@@ -713,6 +714,40 @@ __device__ inline float emit_value(const DPlan& pl, const float* __restrict__ ws
   return 0.0f;  // zero tiles (llama32processor.py:344-346, phi3processor.py:232-235)
 }
 
+// v[0..3] = emit_value(i0 .. i0+3).  Common case: the four indices lie in one emit and in one run of consecutive canvas
+// elements (a tile row whose width is a multiple of 4, the inside of a 14-pixel patch row) - ONE inverse layout map
+// (its divisions are a tenth of the generator's work per thread otherwise) and, when aligned, one 16-byte load.
+__device__ inline void emit_values4(const DPlan& pl, const float* __restrict__ ws, long long i0, long long n, float (&v)[4]) {
+  if (i0 + 3 < n) {
+    for (int k = 0; k < pl.n_emit; ++k) {
+      const DEmit& e = pl.e[k];
+      if (i0 >= e.out_begin && i0 + 3 < e.out_begin + e.out_count) {
+        long long off = -1;
+        if (e.kind == ADVX_EMIT_PLAIN) {
+          off = pl.canvas_off[e.stage] + (i0 - e.out_begin);
+        } else {
+          int c, y, x;
+          emit_inverse(e, i0, c, y, x);
+          const unsigned run = (e.kind == ADVX_EMIT_TILES) ? (unsigned)e.tile : (unsigned)e.patch;
+          if ((unsigned)x % run + 3u < run) off = pl.canvas_off[e.stage] + ((long long)c * e.can_h + y) * e.can_w + x;
+        }
+        if (off >= 0) {
+          if ((off & 3) == 0) {
+            const float4 c4 = *reinterpret_cast<const float4*>(ws + off);
+            v[0] = c4.x; v[1] = c4.y; v[2] = c4.z; v[3] = c4.w;
+          } else {
+            v[0] = ws[off]; v[1] = ws[off + 1]; v[2] = ws[off + 2]; v[3] = ws[off + 3];
+          }
+          return;
+        }
+        break;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? emit_value(pl, ws, i0 + k) : 0.0f;
+}
+
 // NOISE: 0 none, 1 unit-noise tensor supplied, 2 in-kernel Philox
 template <int NOISE, int IO>   // IO: boundary dtype of `out` (0 f32, 1 f16, 2 bf16; halves need n % 4 == 0)
 __device__ inline void emit_body(const DPlan& pl, const float* __restrict__ ws, int batch, int b_per_slice,
@@ -737,8 +772,7 @@ __device__ inline void emit_body(const DPlan& pl, const float* __restrict__ ws, 
     const float4 c4 = *reinterpret_cast<const float4*>(ws + pl.canvas_off[pl.e[0].stage] + i0);
     v[0] = c4.x; v[1] = c4.y; v[2] = c4.z; v[3] = c4.w;
   } else {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? emit_value(pl, ws, i0 + k) : 0.0f;
+    emit_values4(pl, ws, i0, n, v);
   }
   const bool edge = (i0 < live_lo) || (i0 + 4 > live_hi);
   const float sigma = (NOISE != 0) ? sigma_dev[0] : 0.0f;
@@ -932,6 +966,31 @@ template <int IO, bool CANVAS>
 __global__ void __launch_bounds__(kBlock) k_batch_reduce(const void* __restrict__ g, int batch, long long n,
                                                          float* __restrict__ out, long long q_lo, long long q_hi, DPlan pl) {
   reduce_body<IO, CANVAS>(g, batch, n, out, q_lo, q_hi, pl, blockIdx.x, gridDim.x);
+}
+
+// Cross-model runs: the batch reductions of all plans in ONE launch (blockIdx.y = plan), as k_emit_multi does for the
+// emits: each reduction alone ends in a tail on a mostly idle device.  The plan's arguments are picked with a STATIC
+// index (a kernel-argument array indexed at run time is copied to scratch memory: 850 us instead of 45).
+struct ReduceArgs {
+  DPlan pl;
+  const void* g;
+  float* out;
+  long long n, q_lo, q_hi;
+  int batch, blocks;
+};
+struct MultiReduce {
+  int n;
+  ReduceArgs a[kMaxMulti];
+};
+template <int IO>
+__global__ void __launch_bounds__(kBlock) k_batch_reduce_multi(MultiReduce mr) {
+#pragma unroll
+  for (int k = 0; k < kMaxMulti; ++k) {
+    if (k != (int)blockIdx.y) continue;
+    const ReduceArgs& a = mr.a[k];
+    if ((int)blockIdx.x >= a.blocks) return;
+    reduce_body<IO, true>(a.g, a.batch, a.n, a.out, a.q_lo, a.q_hi, a.pl, blockIdx.x, (unsigned)a.blocks);
+  }
 }
 
 // rows not 16-byte aligned (n % 4 != 0): one thread per column, test-sized inputs only
