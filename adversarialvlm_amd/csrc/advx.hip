@@ -46,6 +46,7 @@ static int32_t fail(int32_t code, const std::string& msg) {
 static int g_generic_kernels = 0;
 static int g_pair_nt_loads = 0;
 static int g_full_tap_rows = 0;
+static long long kRows3MinPositions = 250000;   // three channels per thread (k_stage_bwd3, k_crop_bwd_rows3) from here up (measured)
 extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
   if (what == ADVX_TUNE_GENERIC_KERNELS) {
     g_generic_kernels = value ? 1 : 0;
@@ -656,6 +657,8 @@ static void launch_stage_fwd(const DStage& D, const float* src, long long src_cs
                              float* stats, hipStream_t st) {
   const int T = pick_window(std::max(D.th.stride, D.tw.stride));
   if (T) {
+    // (three channels per thread, as k_stage_bwd3 / k_crop_bwd_rows3: SLOWER here - 6.4 -> 7.4 us on the crop's resize,
+    // 10.9 -> 11.7 on Qwen2-VL's - the windows of one channel already keep the loads in flight)
     dim3 grid((D.can_w + kRowBlock - 1) / kRowBlock, D.can_h, 3);
 #define ADVX_SF(T_)                                                                                                     \
   hipLaunchKernelGGL((k_stage_fwd_t<T_>), grid, dim3(kRowBlock), 0, st, D, src, src_cstride, src_rstride, canvas, img_partials, \
@@ -686,7 +689,10 @@ static void launch_crop_bwd(const DStage& D, const float* gcan, float* gimg, int
     return;
   }
   if (!g_generic_kernels) {
-    hipLaunchKernelGGL(k_crop_bwd_rows, dim3((W + kRowBlock - 1) / kRowBlock, H, 3), dim3(kRowBlock), 0, st, D, gcan, gimg, H, W, ci, cj);
+    if ((long long)H * W >= kRows3MinPositions)
+      hipLaunchKernelGGL(k_crop_bwd_rows3, dim3((W + kRowBlock - 1) / kRowBlock, H), dim3(kRowBlock), 0, st, D, gcan, gimg, H, W, ci, cj);
+    else
+      hipLaunchKernelGGL(k_crop_bwd_rows, dim3((W + kRowBlock - 1) / kRowBlock, H, 3), dim3(kRowBlock), 0, st, D, gcan, gimg, H, W, ci, cj);
     return;
   }
   hipLaunchKernelGGL(k_crop_bwd, dim3(grid_for(3LL * H * W)), dim3(kBlock), 0, st, D, gcan, gimg, H, W, ci, cj);
@@ -845,6 +851,14 @@ static bool dgrad_into_gcan(const advx_plan* p, int k) {
     if (p->dplan.e[j].stage == k) covered += p->dplan.e[j].out_count;
   return covered == 3LL * p->st[k].info.can_h * p->st[k].info.can_w;
 }
+static void launch_stage_bwd(const DStage& D, const CanvasGrad& cg, float* gsrc, long long cstride, int rstride, int acc,
+                             hipStream_t st) {
+  const int rowblk = 128;   // two waves along x: little waste on the last chunk of a 336 / 512 / 672-wide row
+  if (!g_generic_kernels && (long long)D.src_h * D.src_w >= kRows3MinPositions)
+    hipLaunchKernelGGL(k_stage_bwd3, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h), dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc);
+  else
+    hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc);
+}
 // where the backward of a stage that reads canvas `src_canvas` writes, and whether it accumulates there
 static float* dgrad_target(const advx_plan* p, int src_canvas, float* ws, int* accumulate) {
   if (dgrad_into_gcan(p, src_canvas)) {
@@ -874,9 +888,7 @@ extern "C" int32_t advx_collect(advx_plan* p, const float* grad_out, int32_t bat
     const advx_stage_info& s = p->st[k].info;
     int acc = accumulate;
     float* gsrc = (s.src == 0) ? grad_argument : dgrad_target(p, s.src - 1, ws, &acc);
-    const int rowblk = 128;   // two waves along x: little waste on the last chunk of a 336 / 512 / 672-wide row
-    hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D, stage_grad(p, k, ws),
-                       gsrc, (long long)D.src_h * D.src_w, D.src_w, acc);
+    launch_stage_bwd(D, stage_grad(p, k, ws), gsrc, (long long)D.src_h * D.src_w, D.src_w, acc, st);
     LAUNCH_CHECK();
   }
   return ADVX_OK;
@@ -1107,8 +1119,7 @@ extern "C" int32_t advx_collect_multi(int32_t n, advx_plan* const* plans, const 
       REQUIRE(s.src >= 1, ADVX_E_UNSUPPORTED, "advx_collect_multi: only stage 0 may read the image");
       int acc = 0;
       float* gsrc = dgrad_target(p, s.src - 1, wss[i], &acc);
-      hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D,
-                         stage_grad(p, k, wss[i]), gsrc, (long long)D.src_h * D.src_w, D.src_w, acc);
+      launch_stage_bwd(D, stage_grad(p, k, wss[i]), gsrc, (long long)D.src_h * D.src_w, D.src_w, acc, st);
       LAUNCH_CHECK();
     }
   }
@@ -2244,9 +2255,7 @@ static void prepared_upper_bwd(advx_plan* p, float* ws, hipStream_t st) {
     const advx_stage_info& s = p->st[k].info;
     int acc = 0;
     float* gsrc = dgrad_target(p, s.src - 1, ws, &acc);
-    const int rowblk = 128;
-    hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D, stage_grad(p, k, ws),
-                       gsrc, (long long)D.src_h * D.src_w, D.src_w, acc);
+    launch_stage_bwd(D, stage_grad(p, k, ws), gsrc, (long long)D.src_h * D.src_w, D.src_w, acc, st);
   }
 }
 

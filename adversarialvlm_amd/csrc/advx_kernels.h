@@ -505,6 +505,45 @@ __global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, CanvasGrad cg, 
   }
 }
 
+// k_stage_bwd with the three channels of a position in one thread: taps and weights looked up once, three gathers in
+// flight.  For sources large enough that a third of the threads still fills the device (Phi-3.5's 672 x 672 hd canvas:
+// 12.5 -> see DESIGN.md 5); at 113 k positions the same form was slower (two waves per SIMD, k_stage0_bwd_multi below).
+__global__ void __launch_bounds__(kBlock) k_stage_bwd3(DStage st, CanvasGrad cg, float* __restrict__ gsrc,
+                                                       long long gsrc_cstride, int gsrc_rstride, int accumulate) {
+  const int ys = blockIdx.y;
+  const int xs = blockIdx.x * blockDim.x + threadIdx.x;
+  if (xs >= st.src_w) return;
+  const size_t o = (size_t)ys * gsrc_rstride + xs;
+  float before[3] = {0.0f, 0.0f, 0.0f};
+  if (accumulate) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) before[c] = gsrc[(size_t)c * gsrc_cstride + o];     // in flight while the taps are gathered
+  }
+  const int oy = st.tth.start[ys], oyc = st.tth.count[ys];
+  const int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
+  const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
+  const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
+  const size_t plane = (size_t)st.can_h * st.can_w;
+  float v[3] = {0.0f, 0.0f, 0.0f};
+  for (int a = 0; a < oyc; ++a) {
+    const size_t row = (size_t)(st.off_y + oy + a) * st.can_w + st.off_x + ox;
+    const float wa = wy[a];
+    float h[3] = {0.0f, 0.0f, 0.0f};
+    for (int b = 0; b < oxc; ++b) {
+      const float wb = wx[b];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) h[c] += wb * canvas_grad_at(cg, (size_t)c * plane + row + b);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] += wa * h[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float r = st.normalise ? v[c] / st.stdv[c] : v[c];
+    gsrc[(size_t)c * gsrc_cstride + o] = accumulate ? (before[c] + r) : r;
+  }
+}
+
 // Several plans over ONE image (cross-model runs, crossattack_models.py:352-391).  Their
 // stage-0 kernels are each too small to fill the device and a dependent launch costs ~5 us, so
 // the stage-0 work of all plans goes into one launch:

@@ -119,4 +119,36 @@ __global__ void __launch_bounds__(kRowBlock) k_crop_bwd_rows(DStage st, const fl
   if (x < W) gimg[((size_t)c * H + y) * W + x] = crop_bwd_value(st, gcan, ci, cj, c, y, x);
 }
 
+// ... and with the three channels of a pixel in one thread (taps and weights looked up once, three gathers in flight), for
+// images of kRows3MinPositions pixels and more (fewer leave the SIMDs too few waves: measured at 113 k)
+__global__ void __launch_bounds__(kRowBlock) k_crop_bwd_rows3(DStage st, const float* __restrict__ gcan, float* __restrict__ gimg,
+                                                              int H, int W, int ci, int cj) {
+  const int y = blockIdx.y;
+  const int x = blockIdx.x * kRowBlock + threadIdx.x;
+  if (x >= W) return;
+  const int ys = y - ci, xs = x - cj;
+  float v[3] = {0.0f, 0.0f, 0.0f};
+  if (ys >= 0 && ys < st.src_h && xs >= 0 && xs < st.src_w) {
+    const int oy = st.tth.start[ys], oyc = st.tth.count[ys];
+    const int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
+    const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
+    const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
+    const size_t plane = (size_t)st.can_h * st.can_w;
+    for (int a = 0; a < oyc; ++a) {
+      const float* rowp = gcan + (size_t)(oy + a) * st.can_w + ox;
+      const float wa = wy[a];
+      float h[3] = {0.0f, 0.0f, 0.0f};
+      for (int b = 0; b < oxc; ++b) {
+        const float wb = wx[b];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) h[c] += wb * rowp[(size_t)c * plane + b];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] += wa * h[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) gimg[((size_t)c * H + y) * W + x] = v[c];
+}
+
 }  // namespace advx

@@ -154,6 +154,31 @@ def test_windowed_crop_equals_general(window):
     assert torch.equal(fast[0], ref[0]) and torch.equal(fast[1], ref[1])
 
 
+@pytest.mark.parametrize("H,W,window", [(512, 512, (40, 30, 400, 420)), (500, 530, (0, 0, 500, 530)), (600, 450, (100, 50, 160, 170))])
+def test_three_channel_gathers_equal_general(H, W, window):
+    """From 250 k positions up the crop adjoint and the transposed resize handle the three channels of a position in
+    one thread (k_crop_bwd_rows3, k_stage_bwd3): same bits as the general kernels."""
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan
+    gen = torch.Generator().manual_seed(H + W)
+    g = torch.randn(3, H, W, generator=gen).to(DEV)
+    plan = Plan.llava(H, W)
+    gout = (torch.randn(2, plan.out_numel, generator=gen) * 0.1).to(DEV)
+    acc0 = torch.randn(3, H, W, generator=gen).to(DEV)
+
+    def go():
+        pv = ops.emit(plan, g, 2)
+        a = ops.collect(plan, gout.view_as(pv), 2)
+        b = ops.collect(plan, gout.view_as(pv), 2, grad_argument=acc0.clone(), accumulate=True)
+        return ops.crop_resize_bwd(g, window), a, b
+
+    fast = go()
+    with ops.generic_kernels():
+        ref = go()
+    for u, v in zip(fast, ref):
+        assert torch.equal(u, v), float((u - v).abs().max())
+
+
 @pytest.mark.parametrize("name", ["llava512", "llava_odd", "mllama_wide", "phi3_tall", "qwen_small"])
 def test_prepared_chain_windowed_equals_general(name):
     """Three steps of the prepared chain (k_plan_head through the windowed kernel, ||g|| reduced by its block 0)."""
