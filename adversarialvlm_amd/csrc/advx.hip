@@ -72,6 +72,8 @@ static inline int grid_for(long long n, int cap = 2048) {
 }
 
 // --------------------------------------------------------------------------- profiling
+// no system-scope fence at a profiling event: the events time a launch, nobody on the host reads memory behind them
+constexpr unsigned kProfEventFlags = hipEventDisableSystemFence;
 // Optional per-kernel timing of the three B*P_out movers: when enabled, each of their
 // launches goes through hipExtLaunchKernelGGL with its own start/stop event pair, i.e. the
 // device timestamps of that dispatch alone (what rocprofv3 --kernel-trace reports).
@@ -92,7 +94,7 @@ static inline bool prof_take(hipEvent_t& e0, hipEvent_t& e1) {
     g_prof.pool.pop_back();
     return true;
   }
-  return hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+  return hipEventCreateWithFlags(&e0, kProfEventFlags) == hipSuccess && hipEventCreateWithFlags(&e1, kProfEventFlags) == hipSuccess;
 }
 }  // namespace
 
@@ -126,8 +128,8 @@ extern "C" int32_t advx_profile_begin(int32_t max_launches, int32_t stride) {
   long long want = std::min<long long>(2LL * ((max_launches + stride - 1) / stride + 1), 512);
   while ((long long)g_prof.pool.size() < want) {
     hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess) break;
-    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); break; }
+    if (hipEventCreateWithFlags(&e0, kProfEventFlags) != hipSuccess) break;
+    if (hipEventCreateWithFlags(&e1, kProfEventFlags) != hipSuccess) { (void)hipEventDestroy(e0); break; }
     g_prof.pool.push_back({e0, e1});
   }
   g_prof.on = true;

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(kRowBlock) k_crop_bwd_t(DStage st, const float
 // k_crop_bwd on the (column chunk, row, channel) grid with crop_bwd_value's run-time loops: no thread divides to find its
 // pixel (the 1-D grid-stride form spends ~35 instructions per element on two run-time divisions), the window row's
 // vertical taps are uniform, and only taps that exist are loaded.  These kernels are bound by the instructions a SIMD has
-// to issue for its few waves, so fewer instructions per element is what pays: 10.4 -> see DESIGN.md 5.
+// to issue for its few waves: 10.4 -> 10.1 us at 512 x 512 (the divisions were not the cost; see k_crop_bwd_rows3).
 __global__ void __launch_bounds__(kRowBlock) k_crop_bwd_rows(DStage st, const float* __restrict__ gcan, float* __restrict__ gimg,
                                                              int H, int W, int ci, int cj) {
   const int c = blockIdx.z, y = blockIdx.y;

@@ -105,10 +105,6 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
-def main_step_is_cold(args):
-    return args.cache in ("both", "cold")
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,7 +257,7 @@ def main():
     # fence, the fence itself, one timed launch in two - of about 130 us: the same loop over 1000 steps is reported
     # beside it as `long_run` (supplementary; `value` stays the K steps asked for).
     long_run = None
-    if args.steps < 500 and main_step_is_cold(args):
+    if args.steps < 500 and "cold" in runs:
         long_run = timed(step_cold, steps=1000, warmup=0)
         held.clear()
     # The same cold steps as a captured hipGraph (supplementary figure): `ring` steps of the pair - forward and backward
