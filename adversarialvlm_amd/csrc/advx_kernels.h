@@ -787,6 +787,40 @@ __device__ inline void emit_values4(const DPlan& pl, const float* __restrict__ w
   for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? emit_value(pl, ws, i0 + k) : 0.0f;
 }
 
+// the batch loop of one float4 column: out[b, i0..i0+3] = v + sigma * noise, b0 <= b < b1
+template <int NOISE, int IO, bool EDGE>
+__device__ inline void emit_batch_loop(const float (&v)[4], bool vec, long long n, long long i0, long long q, int b0, int b1,
+                                       float sigma, const float* __restrict__ unit_noise, unsigned long long seed,
+                                       unsigned long long offset, void* __restrict__ out, long long live_lo, long long live_hi) {
+  for (int b = b0; b < b1; ++b) {
+    float o[4] = {v[0], v[1], v[2], v[3]};
+    if (NOISE == 1) {
+      if (vec) {
+        float4 z = *reinterpret_cast<const float4*>(unit_noise + (size_t)b * n + i0);
+        o[0] = v[0] + z.x * sigma; o[1] = v[1] + z.y * sigma; o[2] = v[2] + z.z * sigma; o[3] = v[3] + z.w * sigma;
+      } else {
+        for (int k = 0; k < 4; ++k)
+          if (i0 + k < n) o[k] = v[k] + unit_noise[(size_t)b * n + i0 + k] * sigma;
+      }
+    } else if (NOISE == 2) {
+      float4 z = philox_normal4_qb((uint32_t)q, (uint32_t)b, offset, seed);
+      o[0] = v[0] + z.x * sigma; o[1] = v[1] + z.y * sigma; o[2] = v[2] + z.z * sigma; o[3] = v[3] + z.w * sigma;
+    }
+    if (EDGE) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i0 + k < live_lo || i0 + k >= live_hi) o[k] = 0.0f;
+    }
+    if (vec) {
+      // write-once stream: non-temporal, like the fused forward; rounded once to the boundary dtype
+      io_store4<IO>(out, (size_t)b * n + i0, make_float4(o[0], o[1], o[2], o[3]));
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (i0 + k < n) reinterpret_cast<float*>(out)[(size_t)b * n + i0 + k] = o[k];
+    }
+  }
+}
+
 // NOISE: 0 none, 1 unit-noise tensor supplied, 2 in-kernel Philox
 template <int NOISE, int IO>   // IO: boundary dtype of `out` (0 f32, 1 f16, 2 bf16; halves need n % 4 == 0)
 __device__ inline void emit_body(const DPlan& pl, const float* __restrict__ ws, int batch, int b_per_slice,
@@ -813,37 +847,16 @@ __device__ inline void emit_body(const DPlan& pl, const float* __restrict__ ws, 
   } else {
     emit_values4(pl, ws, i0, n, v);
   }
-  const bool edge = (i0 < live_lo) || (i0 + 4 > live_hi);
   const float sigma = (NOISE != 0) ? sigma_dev[0] : 0.0f;
   const int b0 = (int)block_y * b_per_slice;
   const int b1 = min(batch, b0 + b_per_slice);
-  for (int b = b0; b < b1; ++b) {
-    float o[4] = {v[0], v[1], v[2], v[3]};
-    if (NOISE == 1) {
-      if (vec) {
-        float4 z = *reinterpret_cast<const float4*>(unit_noise + (size_t)b * n + i0);
-        o[0] = v[0] + z.x * sigma; o[1] = v[1] + z.y * sigma; o[2] = v[2] + z.z * sigma; o[3] = v[3] + z.w * sigma;
-      } else {
-        for (int k = 0; k < 4; ++k)
-          if (i0 + k < n) o[k] = v[k] + unit_noise[(size_t)b * n + i0 + k] * sigma;
-      }
-    } else if (NOISE == 2) {
-      float4 z = philox_normal4_qb((uint32_t)q, (uint32_t)b, offset, seed);
-      o[0] = v[0] + z.x * sigma; o[1] = v[1] + z.y * sigma; o[2] = v[2] + z.z * sigma; o[3] = v[3] + z.w * sigma;
-    }
-    if (edge) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (i0 + k < live_lo || i0 + k >= live_hi) o[k] = 0.0f;
-    }
-    if (vec) {
-      // write-once stream: non-temporal, like the fused forward; rounded once to the boundary dtype
-      io_store4<IO>(out, (size_t)b * n + i0, make_float4(o[0], o[1], o[2], o[3]));
-    } else {
-      for (int k = 0; k < 4; ++k)
-        if (i0 + k < n) reinterpret_cast<float*>(out)[(size_t)b * n + i0 + k] = o[k];
-    }
-  }
+  // A column that straddles the live range zeroes its dead elements.  Two instances of the loop, not one with the test
+  // inside: there the compiler turned the test into eleven selects per iteration in EVERY thread, a tenth of the
+  // generator-bound loop's instructions.
+  if ((i0 < live_lo) || (i0 + 4 > live_hi))
+    emit_batch_loop<NOISE, IO, true>(v, vec, n, i0, q, b0, b1, sigma, unit_noise, seed, offset, out, live_lo, live_hi);
+  else
+    emit_batch_loop<NOISE, IO, false>(v, vec, n, i0, q, b0, b1, sigma, unit_noise, seed, offset, out, live_lo, live_hi);
 }
 
 template <int NOISE, int IO>
