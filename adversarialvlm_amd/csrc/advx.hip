@@ -507,14 +507,39 @@ extern "C" int32_t advx_plan_taps(const advx_plan* p, int32_t stage, int32_t axi
   return copy_taps(t, n, stride, start, count, weight);
 }
 
-extern "C" int32_t advx_taps_compute(int32_t mode, int32_t in_size, int32_t out_size, int32_t transposed, int32_t* n,
+static HostTaps trim_zero_taps(const HostTaps& t);
+// the transposed table as the device-side builder of the crop window forms it (build_taps_row: bounds by binary search,
+// every weight by tap_weight), on the host
+static HostTaps host_taps_transposed_builder(int mode, int in_size, int out_size, int stride) {
+  HostTaps t;
+  t.n = in_size;
+  t.start.resize(in_size);
+  t.count.resize(in_size);
+  int mx = 1;
+  for (int j = 0; j < in_size; ++j) {
+    TapRow r = tap_bounds_transposed(mode, in_size, out_size, j);
+    t.start[j] = r.start;
+    t.count[j] = r.count;
+    mx = std::max(mx, r.count);
+  }
+  t.stride = mx;
+  t.w.assign((size_t)in_size * mx, 0.0f);
+  for (int j = 0; j < in_size; ++j)
+    for (int q = 0; q < t.count[j]; ++q) t.w[(size_t)j * mx + q] = tap_weight(mode, in_size, out_size, t.start[j] + q, j, stride);
+  return t;
+}
+
+extern "C" int32_t advx_taps_compute(int32_t mode, int32_t in_size, int32_t out_size, int32_t flags, int32_t* n,
                                      int32_t* stride, int32_t* start, int32_t* count, float* weight) {
-  REQUIRE(mode >= 0 && mode <= 2 && in_size > 0 && out_size > 0 && in_size <= 65536 && out_size <= 65536, ADVX_E_BADARG,
-          "advx_taps_compute: bad arguments");
+  REQUIRE(mode >= 0 && mode <= 2 && in_size > 0 && out_size > 0 && in_size <= 65536 && out_size <= 65536 && flags >= 0 &&
+              flags < 8, ADVX_E_BADARG, "advx_taps_compute: bad arguments");
   HostTaps f = host_taps(mode, in_size, out_size);
-  if (!transposed) return copy_taps(f, n, stride, start, count, weight);
-  HostTaps t = host_taps_transposed(mode, in_size, out_size, f);
-  return copy_taps(t, n, stride, start, count, weight);
+  HostTaps r = f;
+  if (flags & ADVX_TAPS_TRANSPOSED)
+    r = (flags & ADVX_TAPS_BUILDER) ? host_taps_transposed_builder(mode, in_size, out_size, f.stride)
+                                    : host_taps_transposed(mode, in_size, out_size, f);
+  if (flags & ADVX_TAPS_DEVICE_ROWS) r = trim_zero_taps(r);
+  return copy_taps(r, n, stride, start, count, weight);
 }
 
 extern "C" int32_t advx_plan_out_index(const advx_plan* p, int32_t stage, int32_t c, int32_t y, int32_t x, int32_t* n_idx,

@@ -111,16 +111,18 @@ class Plan:
             pass
 
 
-def taps_compute(mode, in_size, out_size, transposed=False):
-    """Host tap table of an arbitrary 1-D resize (tests, crop windows)."""
+def taps_compute(mode, in_size, out_size, transposed=False, device_rows=False, builder=False):
+    """Host tap table of an arbitrary 1-D resize (tests, crop windows).  device_rows: as advx_plan_upload stores them
+    (zero-weight end taps dropped); builder: the transposed table the way the device-side builder forms it."""
     lib = L.load()
     n, stride = C.c_int32(), C.c_int32()
-    L.check(lib.advx_taps_compute(mode, in_size, out_size, int(transposed), C.byref(n), C.byref(stride), None, None, None),
+    flags = (1 if transposed else 0) | (2 if device_rows else 0) | (4 if builder else 0)
+    L.check(lib.advx_taps_compute(mode, in_size, out_size, flags, C.byref(n), C.byref(stride), None, None, None),
             "advx_taps_compute")
     start = np.zeros(n.value, np.int32)
     count = np.zeros(n.value, np.int32)
     w = np.zeros((n.value, stride.value), np.float32)
-    L.check(lib.advx_taps_compute(mode, in_size, out_size, int(transposed), C.byref(n), C.byref(stride),
+    L.check(lib.advx_taps_compute(mode, in_size, out_size, flags, C.byref(n), C.byref(stride),
                                   start.ctypes.data_as(C.c_void_p), count.ctypes.data_as(C.c_void_p),
                                   w.ctypes.data_as(C.c_void_p)), "advx_taps_compute")
     return start, count, w

@@ -153,8 +153,14 @@ int32_t advx_plan_live_range(const advx_plan* plan, int64_t* lo, int64_t* hi);
  * half data; `unit_noise` stays float32.  Needs out_numel % 4 == 0. */
 int32_t advx_plan_set_io(advx_plan* plan, int32_t io_dtype);
 int32_t advx_plan_get_io(const advx_plan* plan);
-/* Host tap computation for an arbitrary 1-D resize (tests; also the crop window's tables). */
-int32_t advx_taps_compute(int32_t mode, int32_t in_size, int32_t out_size, int32_t transposed,
+/* Host tap computation for an arbitrary 1-D resize (tests; also the crop window's tables).  flags: a sum of
+ *   ADVX_TAPS_TRANSPOSED   the table of the adjoint (rows = source indices);
+ *   ADVX_TAPS_DEVICE_ROWS  the rows as advx_plan_upload stores them: zero-weight taps at either end of a row dropped;
+ *   ADVX_TAPS_BUILDER      (with TRANSPOSED) formed the way the device-side builder of the crop window forms them. */
+#define ADVX_TAPS_TRANSPOSED 1
+#define ADVX_TAPS_DEVICE_ROWS 2
+#define ADVX_TAPS_BUILDER 4
+int32_t advx_taps_compute(int32_t mode, int32_t in_size, int32_t out_size, int32_t flags,
                           int32_t* n, int32_t* stride, int32_t* start, int32_t* count, float* weight);
 
 /* ------------------------------------------------ processor level (plugin API)
@@ -197,7 +203,7 @@ int32_t advx_collect(advx_plan* plan, const float* grad_out, int32_t batch, floa
  * is, bit for bit, what n calls of advx_emit_ex / advx_collect (the first with `accumulate`, the
  * others adding) give; the resize kernels of all plans that read the image run in one launch each
  * way and the plans' image gradients are summed left to right inside it, without read-modify-write
- * passes.  Arrays have n entries, host memory; every plan needs its own workspace; plan i's noise
+ * passes; so do the emits, and the batch reductions when the plans read their gradients the same way.  Arrays have n entries, host memory; every plan needs its own workspace; plan i's noise
  * stream is (seed, offsets[i]); unit_noises may be NULL or hold NULL entries; `outs` / `grad_outs`
  * carry each plan's boundary dtype (advx_plan_set_io). */
 int32_t advx_emit_multi(int32_t n, advx_plan* const* plans, const float* argument, const int32_t* batches,
@@ -212,7 +218,9 @@ int32_t advx_collect_multi(int32_t n, advx_plan* const* plans, const void* const
 /* advx_image_fwd followed by advx_emit_multi in one call (the forward half of a step of either trainer
  * whenever the fused / prepared chains do not apply): same tensors; without a crop window the
  * statistics of the image are reduced by one block of the plans' resize launch instead of a launch of
- * their own.  The emits read their sigma from stats[ADVX_STAT_SIGMA].  Arguments as for the two calls. */
+ * their own; with one, the window's transposed tap tables (read only by advx_image_bwd*) are built by the first
+ * workgroups of the emit launch instead of the step's first image kernel.  The emits read their sigma from
+ * stats[ADVX_STAT_SIGMA].  Arguments as for the two calls. */
 int32_t advx_forward_multi(const float* p, const float* x0, int32_t H, int32_t W, float epsilon,
                            int32_t blur_kernel, float blur_sigma, const int32_t* crop_ijhw, float* s,
                            float* argument, float* stats, float* image_scratch, int32_t n,

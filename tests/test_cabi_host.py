@@ -135,6 +135,47 @@ def test_tap_tables_bit_exact_vs_oracle(lib, mode, n, m):
     assert np.array_equal(R.taps_to_matrix((ts, tc, tw), m), R.taps_to_matrix((s, c, w), n).T)
 
 
+@settings(max_examples=150, deadline=None)
+@given(mode=st.integers(0, 2), n=st.integers(2, 700), m=st.integers(2, 700), same=st.booleans())
+def test_device_tap_rows_are_the_full_rows_without_their_zero_ends(lib, mode, n, m, same):
+    """advx_plan_upload stores rows without the zero-weight taps at their ends (a resize between equal sizes has
+    bicubic rows (0, 1, 0, 0)); every dropped tap had weight exactly zero, every kept one is unchanged, in place."""
+    from adversarialvlm_amd.plan import taps_compute
+    if same:
+        m = n
+    for transposed in (False, True):
+        s, c, w = taps_compute(mode, n, m, transposed=transposed)
+        ds, dc, dw = taps_compute(mode, n, m, transposed=transposed, device_rows=True)
+        cols = n if not transposed else m
+        assert np.array_equal(R.taps_to_matrix((ds, dc, dw), cols), R.taps_to_matrix((s, c, w), cols))
+        assert dw.shape[1] == max(1, int(dc.max()))
+        for i in range(len(s)):
+            row, drow = w[i, :c[i]], dw[i, :dc[i]]
+            lead = ds[i] - s[i]
+            assert lead >= 0 and lead + dc[i] <= max(c[i], 0) or dc[i] == 0
+            if dc[i]:
+                assert drow[0] != 0 and drow[-1] != 0
+                assert np.array_equal(row[lead:lead + dc[i]], drow)
+                assert not row[:lead].any() and not row[lead + dc[i]:].any()
+            else:
+                assert not row.any()
+    if same and mode == 2:
+        ds, dc, dw = taps_compute(mode, n, n, device_rows=True)
+        assert dw.shape[1] == 1 and np.all(dc == 1) and np.array_equal(ds, np.arange(n)) and np.all(dw == 1.0)
+
+
+@settings(max_examples=150, deadline=None)
+@given(mode=st.integers(0, 2), n=st.integers(2, 700), m=st.integers(2, 700))
+def test_device_side_builder_forms_the_same_transposed_table(lib, mode, n, m):
+    """The crop window's transposed table is built on the device from tap_bounds_transposed + tap_weight (no row buffer);
+    the same routine run on the host gives the table the host derives from the forward rows, bit for bit."""
+    from adversarialvlm_amd.plan import taps_compute
+    # (mode 0, antialiased bilinear, is the crop window's resize; tap_weight covers the other two as well)
+    ts, tc, tw = taps_compute(mode, n, m, transposed=True)
+    bs, bc, bw = taps_compute(mode, n, m, transposed=True, builder=True)
+    assert np.array_equal(ts, bs) and np.array_equal(tc, bc) and np.array_equal(tw, bw)
+
+
 def test_layout_index_maps_vs_reference_permutes(lib):
     """Tile / patch index maps are integer-exact against the reshape-permute-reshape of the
     reference (llama32processor.py:326-332, phi3processor.py:227, qwen2VLprocessor.py:249-267)."""
