@@ -726,11 +726,21 @@ static void launch_crop_bwd(const DStage& D, const float* gcan, float* gimg, int
 }
 
 // ------------------------------------------------------------------ emit / collect
-static void emit_slices(long long n4, int batch, int* gx, int* slices, int* b_per_slice) {
+// How a B x n4 emit is cut into workgroups: gx column blocks x `slices` batch slices of b_per_slice rows each.
+// Two pulls (measured on the final kernels).  The write stream likes short per-thread batch loops with many
+// workgroups in flight: Mllama's 963 MB take 240 us at 64 rows per thread and 219 at 8 (half-precision boundary, where the
+// generator bounds the loop instead: 16 rows).  But every slice repeats the column's prologue, and for a patch layout
+// (Qwen2-VL: a chain of divisions per inverse map) that costs as much as five rows of the loop: there, as few slices as
+// give a thousand workgroups (Qwen2-VL 512, bf16: 119 us at one slice, 125 at two, 138 at four).
+static void emit_slices(long long n4, int batch, bool patch_layout, bool half_io, int* gx, int* slices, int* b_per_slice) {
   long long bx = (n4 + kBlock - 1) / kBlock;
   if (bx < 1) bx = 1;
-  const int target = 2048;   // ~8 workgroups per CU: measured best on MI355X (profiles/r01)
+  const int target = patch_layout ? 1024 : 2048;   // workgroups, when the batch allows it (~8 per CU: profiles/r01)
   int want = (int)std::max<long long>(1, (target + bx - 1) / bx);
+  if (!patch_layout) {
+    const int rows = half_io ? 16 : 8;
+    want = std::max(want, (batch + rows - 1) / rows);
+  }
   int sl = std::min(batch, want);
   while (sl < batch && batch % sl != 0) ++sl;  // equal slices: no straggler slice
   int bps = (batch + sl - 1) / sl;
@@ -739,7 +749,13 @@ static void emit_slices(long long n4, int batch, int* gx, int* slices, int* b_pe
   *slices = sl;
   *b_per_slice = bps;
 }
+static bool plan_has_patch_layout(const advx_plan* p);
 
+static bool plan_has_patch_layout(const advx_plan* p) {
+  for (int k = 0; k < p->dplan.n_emit; ++k)
+    if (p->dplan.e[k].kind != ADVX_EMIT_PLAIN && p->dplan.e[k].kind != ADVX_EMIT_TILES) return true;
+  return false;
+}
 // span of flat indices the emits of a plan cover; what lies outside is constant padding
 static void plan_live_range(const advx_plan* p, long long* lo, long long* hi) {
   *lo = p->info.out_numel;
@@ -800,7 +816,7 @@ extern "C" int32_t advx_emit_ex(advx_plan* p, const float* argument, int32_t bat
     q_hi = (live_hi + 3) >> 2;
   }
   int gx, slices, bps;
-  emit_slices(q_hi - q_lo, batch, &gx, &slices, &bps);
+  emit_slices(q_hi - q_lo, batch, plan_has_patch_layout(p), p->io != 0, &gx, &slices, &bps);
   dim3 grid(gx, slices);
 #define ADVX_EMIT_T(N, T)                                                                                           \
   hipLaunchKernelGGL((k_emit<N, T>), grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, \
@@ -1025,7 +1041,7 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
       a.q_lo = a.live_lo >> 2;
       a.q_hi = (a.live_hi + 3) >> 2;
     }
-    emit_slices(a.q_hi - a.q_lo, batches[i], &a.gx, &a.slices, &a.b_per_slice);
+    emit_slices(a.q_hi - a.q_lo, batches[i], plan_has_patch_layout(p), p->io != 0, &a.gx, &a.slices, &a.b_per_slice);
     max_gx = std::max(max_gx, a.gx);
     max_slices = std::max(max_slices, a.slices);
   }
@@ -1693,7 +1709,7 @@ static int32_t fused_fwd_impl(advx_plan* p, const float* pp, const float* x0, fl
     LAUNCH_CHECK();
   }
   int gx, slices, bps;
-  emit_slices(n4, batch, &gx, &slices, &bps);
+  emit_slices(n4, batch, false, false, &gx, &slices, &bps);   // the pair: 8 rows per thread, as measured in round 1
   dim3 grid(gx, slices + 1);  // y == 0: statistics blocks, y >= 1: batch slices
   int noise = unit_noise ? 1 : (use_philox ? 2 : 0);
 #define ADVX_FF_S(N, T, S)                                                                                       \
@@ -2335,7 +2351,7 @@ extern "C" int32_t advx_prepared_fwd(advx_plan* p, const float* pp, const float*
     q_hi = (live_hi + 3) >> 2;
   }
   int gx, slices, bps;
-  emit_slices(q_hi - q_lo, batch, &gx, &slices, &bps);
+  emit_slices(q_hi - q_lo, batch, plan_has_patch_layout(p), p->io != 0, &gx, &slices, &bps);
   dim3 grid(gx, slices);
   const float* sigma_dev = stats + ADVX_STAT_QERR_STD;   // quantise error of the PREVIOUS image (not yet rotated)
 #define ADVX_EMIT_T(N, T)                                                                                           \
