@@ -179,6 +179,31 @@ def test_three_channel_gathers_equal_general(H, W, window):
         assert torch.equal(u, v), float((u - v).abs().max())
 
 
+@pytest.mark.parametrize("name", ["qwen512", "phi3_512", "mllama_big"])
+def test_three_channel_gathers_other_layouts(name):
+    """k_stage_bwd3 behind a patch layout with two temporal copies of the sums (Qwen2-VL), behind a second stage whose
+    gradient is added into the sums (Phi-3.5) and behind tiles (Mllama), at sizes that take it: the general kernels' bits."""
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan
+    mk = {"qwen512": lambda: Plan.qwen2vl(512, 512), "phi3_512": lambda: Plan.phi3(512, 512),
+          "mllama_big": lambda: Plan.mllama(600, 520)}[name]
+    gen = torch.Generator().manual_seed(3)
+    plan0 = mk()
+    img = torch.rand(3, plan0.in_h, plan0.in_w, generator=gen).to(DEV)
+    gout = (torch.randn(2, plan0.out_numel, generator=gen) * 0.1).to(DEV)
+
+    def go():
+        plan = mk()
+        pv = ops.emit(plan, img, 2)
+        return pv, ops.collect(plan, gout.view_as(pv), 2)
+
+    fast = go()
+    with ops.generic_kernels():
+        ref = go()
+    for u, v in zip(fast, ref):
+        assert torch.equal(u, v), (name, float((u - v).abs().max()))
+
+
 @pytest.mark.parametrize("name", ["llava512", "llava_odd", "mllama_wide", "phi3_tall", "qwen_small"])
 def test_prepared_chain_windowed_equals_general(name):
     """Three steps of the prepared chain (k_plan_head through the windowed kernel, ||g|| reduced by its block 0)."""
