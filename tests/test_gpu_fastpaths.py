@@ -204,7 +204,7 @@ def test_three_channel_gathers_other_layouts(name):
         assert torch.equal(u, v), (name, float((u - v).abs().max()))
 
 
-@pytest.mark.parametrize("name", ["llava512", "llava_odd", "mllama_wide", "phi3_tall", "qwen_small"])
+@pytest.mark.parametrize("name", ["llava512", "llava_odd", "mllama_wide", "phi3_tall", "qwen_small", "phi3_512", "qwen512"])
 def test_prepared_chain_windowed_equals_general(name):
     """Three steps of the prepared chain (k_plan_head through the windowed kernel, ||g|| reduced by its block 0)."""
     from adversarialvlm_amd import ops
