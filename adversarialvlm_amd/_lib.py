@@ -176,14 +176,33 @@ def check(rc, what=""):
 
 
 def ptr(t):
-    """Device (or host) pointer of a contiguous torch tensor / None."""
+    """Device (or host) pointer of a contiguous torch tensor / None, as the plain integer ctypes takes for a void*
+    (no c_void_p object per argument: a step of the pair passes nineteen pointers)."""
     if t is None:
         return None
     if not t.is_contiguous():
         raise AdvxError("advx: tensor must be contiguous")
-    return C.c_void_p(t.data_ptr())
+    return t.data_ptr()
+
+
+_raw_stream = None
 
 
 def current_stream(device=None):
+    """The current HIP stream of `device` as an integer handle (torch's raw-stream accessor: a tenth of the cost of
+    building a torch.cuda.Stream object per call; falls back to it where the accessor is missing)."""
+    global _raw_stream
     import torch
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        if device is None:
+            index = torch.cuda.current_device()
+        else:
+            if isinstance(device, str):
+                device = torch.device(device)
+            index = device.index if isinstance(device, torch.device) else int(device)
+            if index is None:
+                index = torch.cuda.current_device()
+        return _raw_stream(index)
+    return torch.cuda.current_stream(device).cuda_stream
