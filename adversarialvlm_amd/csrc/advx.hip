@@ -663,8 +663,10 @@ static inline TapRider no_rider() {
 // T = compiled window size that holds `need` taps per axis (0: none - the run-time-loop kernels take over)
 static inline int pick_window(int need) {
   if (g_generic_kernels) return 0;
-  // measured (profiles/r02): windows up to 4 x 4 pay (crop resize 7.3 -> 6.4 us, Phi-3.5's bicubic stage 11.7 ->
-  // 7.5); from 5 x 5 on the clamped loads of taps a row does not have cost more than the run-time loops save
+  // measured (profiles/r02): windows up to 4 x 4 pay against one thread per (c, y, x) with run-time loops (crop resize
+  // 7.3 -> 6.4 us, Phi-3.5's bicubic stage 11.7 -> 7.5); from 5 x 5 on the clamped loads of taps a row does not have cost
+  // more than the loops save.  Against the loops with three channels per thread (k_stage0_fwd_multi) they are level
+  // (Qwen2-VL 10.5 vs 10.9, Mllama 8.3 vs 7.8, LLaVA's trimmed 4-tap rows 10.4 vs 9.9) except for Phi-3.5's bicubic (8.2 vs 9.3).
   static const int sizes[] = {2, 3, 4};
   for (int t : sizes)
     if (need <= t) return t;
@@ -695,6 +697,18 @@ static void launch_stage_fwd(const DStage& D, const float* src, long long src_cs
     return;
   }
   const long long n = 3LL * D.can_h * D.can_w;
+  if (!g_generic_kernels && norm_count >= 0) {
+    // windows beyond 4 x 4 (LLaVA's antialiased 512 -> 336: five taps per axis): the run-time loops with the three
+    // channels of a position in one thread, k_stage0_fwd_multi for one plan (8.2 -> 7.3 us at five taps)
+    MultiFwd mf;
+    std::memset(&mf, 0, sizeof(mf));
+    mf.n = 1;
+    mf.st[0] = D;
+    mf.canvas[0] = canvas;
+    hipLaunchKernelGGL(k_stage0_fwd_multi, dim3((D.can_w + kRowBlock - 1) / kRowBlock, D.can_h, 1), dim3(kRowBlock), 0, st, mf, src,
+                       src_cstride, src_rstride, img_partials, img_nblk, n_img, stats, norm_rows, norm_count);
+    return;
+  }
   if (img_nblk > 0)
     hipLaunchKernelGGL(k_stage_fwd_img, dim3(grid_for(n)), dim3(kBlock), 0, st, D, src, src_cstride, src_rstride, canvas,
                        img_partials, img_nblk, n_img, stats);
@@ -1000,7 +1014,8 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
   // one window size for plans of different geometry loses to the run-time loops (20.7 vs 19.1 us); what pays is three
   // channels per thread on a (column chunk, row, plan) grid (11.5 us)
   hipLaunchKernelGGL(k_stage0_fwd_multi, dim3((max_w + kRowBlock - 1) / kRowBlock, max_h, n), dim3(kRowBlock), 0, st, mf, argument,
-                     (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats);
+                     (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats,
+                     (const double*)nullptr, 0);
   LAUNCH_CHECK();
   // the stages above stage 0 (Phi-3.5's global view), then the emits of all plans
   for (int i = 0; i < n; ++i) {

@@ -610,10 +610,14 @@ __device__ inline void stage_fwd_value3(const DStage& st, const float* __restric
 // grid = (column chunks of the widest canvas, rows of the tallest, plans)
 __global__ void __launch_bounds__(kBlock) k_stage0_fwd_multi(MultiFwd mf, const float* __restrict__ src, long long src_cstride,
                                                              int src_rstride, const double* __restrict__ img_partials, int nblk,
-                                                             long long n_img, float* __restrict__ stats) {
+                                                             long long n_img, float* __restrict__ stats,
+                                                             const double* __restrict__ norm_rows, int norm_count) {
   // nblk > 0: the image kernels of the same call left statistics partials; block (0,0,0) reduces them
-  // here (k_emit, the consumer of sigma, is a later launch)
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && nblk > 0) finalize_image_block<true>(img_partials, nblk, n_img, stats);
+  // here (k_emit, the consumer of sigma, is a later launch); norm_count > 0: the ||g|| partials of the prepared chain's tail
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    if (nblk > 0) finalize_image_block<true>(img_partials, nblk, n_img, stats);
+    if (norm_count > 0) finalize_norm_block(norm_rows, norm_count, stats);
+  }
   const int k = blockIdx.z;
   const DStage& st = mf.st[k];
   const int y = blockIdx.y;
