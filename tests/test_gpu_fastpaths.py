@@ -315,6 +315,42 @@ def test_trimmed_tap_rows_equal_full_rows(name):
         assert torch.equal(u, v), (name, float((u - v).abs().max()))
 
 
+@pytest.mark.parametrize("keep", [False, True])
+def test_cross_chain_with_crop_mixed_boundaries_equals_general(keep):
+    """Three plans with different boundary dtypes over one image, blur AND a crop window per step (the window's
+    transposed tables ride in the merged emit; the reductions cannot merge: different load variants), padding kept
+    zero or not: the general kernels' bits."""
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.pgd import PixelPGD
+    from adversarialvlm_amd.plan import Plan
+    gen = torch.Generator().manual_seed(33)
+    H, W = 120, 152
+    x0 = torch.rand(3, H, W, generator=gen)
+    mk = lambda: [Plan.phi3(H, W), Plan.qwen2vl(H, W, min_pixels=28 * 28, max_pixels=28 * 28 * 36), Plan.mllama(H, W, tile=48)]
+    dts = [torch.float16, torch.float32, torch.bfloat16]
+    plans = mk()
+    Bs = [2, 3, 2]
+    gs = [[torch.randn(b, pl.out_numel, generator=gen) * 0.05 for pl, b in zip(plans, Bs)] for _ in range(3)]
+    windows = [(3, 5, 100, 120), (0, 0, H, W), (20, 30, 64, 70)]
+
+    def go():
+        eng = PixelPGD(x0.to(DEV), mk(), lr=1e-2, blur_kernel=5, use_crop=True, cross_mode=True, model_weights=[0.2, 0.8, 1.6],
+                       io_dtype=dts, noise_on_padding=not keep, seed=9)
+        outs = []
+        for t in range(3):
+            pvs = eng.forward(Bs, blur_sigma=0.4 + 0.5 * t, crop=windows[t])
+            eng.backward_update([g.to(DEV).to(pv.dtype).view_as(pv) for g, pv in zip(gs[t], pvs)])
+            outs.append([pv.clone() for pv in pvs] + [eng.p.clone(), eng.grad.clone()])
+        return outs
+
+    fast = go()
+    with ops.generic_kernels():
+        ref = go()
+    for a, b in zip(fast, ref):
+        for u, v in zip(a, b):
+            assert u.dtype == v.dtype and torch.equal(u, v), float((u.float() - v.float()).abs().max())
+
+
 def test_large_image_takes_the_general_backward():
     """Beyond 2048 tiles (here 33 x 33 x 3) the merged backward has no room for its ||g|| partials and the host falls
     back to k_blur<1,2> + k_bwd_update<1>; the forward stays radius-templated.  Same bits either way."""
