@@ -351,6 +351,27 @@ def test_cross_chain_with_crop_mixed_boundaries_equals_general(keep):
             assert u.dtype == v.dtype and torch.equal(u, v), float((u.float() - v.float()).abs().max())
 
 
+def test_merged_reductions_streamed_loads():
+    """k_batch_reduce_multi with the non-temporal load variant: every plan's gradient is beyond the Infinity Cache
+    (Phi-3.5 and Qwen2-VL at 512 x 512, 64 prompts each: 465 MB and 390 MB read).  Same image gradient, bit for bit, as
+    one k_batch_reduce per plan."""
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan
+    mk = lambda: [Plan.phi3(512, 512), Plan.qwen2vl(512, 512)]
+    plans = mk()
+    B = 64
+    gen = torch.Generator(device=DEV).manual_seed(17)
+    grads = [torch.randn(B, pl.out_numel, generator=gen, device=DEV) * 0.01 for pl in plans]
+
+    def go():
+        return ops.collect_multi(mk(), grads, [B, B])
+
+    fast = go()
+    with ops.generic_kernels():
+        ref = go()
+    assert torch.equal(fast, ref), float((fast - ref).abs().max())
+
+
 def test_large_image_takes_the_general_backward():
     """Beyond 2048 tiles (here 33 x 33 x 3) the merged backward has no room for its ||g|| partials and the host falls
     back to k_blur<1,2> + k_bwd_update<1>; the forward stays radius-templated.  Same bits either way."""
