@@ -90,6 +90,12 @@ def cpu_baseline(seconds_budget=15.0):
                 sample=f"{n} steps of the same workload (336x336x3, B=64), {dt:.1f} s", steps_per_s=round(n / dt, 3))
 
 
+def profile_stride(steps):
+    """Every stride-th launch of a kernel carries HIP events: at least 10 timed launches per kernel whatever K >= 10 is
+    (64 from K = 640 up) - a timed launch costs ~0.6 us, so not every one is timed."""
+    return max(1, steps // (64 if steps >= 640 else 10))
+
+
 class stdout_to_stderr:
     """RCCL prints a version banner on fd 1 when a communicator is created; keep stdout for the
     single JSON line by pointing fd 1 at stderr while the process group comes up."""
@@ -229,12 +235,12 @@ def main():
         B*P_out movers carries its own start/stop HIP event pair on the launch stream (advx_profile_*,
         hipExtLaunchKernelGGL); the stride is chosen so that at least 10 launches per kernel are timed whatever
         K >= 10 is (64 from K = 640 up).  A timed launch is fenced off from its neighbours by the event
-        packets (measured: +2.5 us per step at stride 1), which is why not every launch is timed."""
+        packets (measured: +0.6 us per timed launch with fence-free events), which is why not every launch is timed."""
         steps = args.steps if steps is None else steps
         for _ in range(args.warmup if warmup is None else warmup):
             step()
         fence()
-        ops.profile_begin(max(steps, 1), stride=max(1, steps // (64 if steps >= 640 else 10)))
+        ops.profile_begin(max(steps, 1), stride=profile_stride(steps))
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
