@@ -8,7 +8,9 @@ it at ISOLATED pixels: AdamW's update m/(sqrt(v)+1e-8) - and the sign step - is 
 |g| is of the order of adam_eps (first steps, edge taps of a window, mask borders), so a 1e-9 absolute difference
 in g moves p by a per cent of a step.  `_check_p` accepts such a pixel only if its GRADIENT agrees elementwise
 (<= 1e-4 * max|g|) and was tiny (<= 1e-3 * max|g|) at some step so far, bounds their number and logs every one of
-them (ILL_CONDITIONED); the image s inherits exactly eps * that deviation."""
+them (ILL_CONDITIONED); the image s inherits exactly eps * that deviation.  Two scalar statistics inherit isolated pixels
+too and are compared with bounds DERIVED from those pixels, nothing looser (`_trajectory`): std(x) from the accepted pixels
+of p, and the quantise-error mean / std from pixels whose uint8 level verifiably differs between the implementations."""
 import numpy as np
 import pytest
 import torch
