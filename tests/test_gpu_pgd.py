@@ -8,9 +8,10 @@ it at ISOLATED pixels: AdamW's update m/(sqrt(v)+1e-8) - and the sign step - is 
 |g| is of the order of adam_eps (first steps, edge taps of a window, mask borders), so a 1e-9 absolute difference
 in g moves p by a per cent of a step.  `_check_p` accepts such a pixel only if its GRADIENT agrees elementwise
 (<= 1e-4 * max|g|) and was tiny (<= 1e-3 * max|g|) at some step so far, bounds their number and logs every one of
-them (ILL_CONDITIONED); the image s inherits exactly eps * that deviation.  Two scalar statistics inherit isolated pixels
-too and are compared with bounds DERIVED from those pixels, nothing looser (`_trajectory`): std(x) from the accepted pixels
-of p, and the quantise-error mean / std from pixels whose uint8 level verifiably differs between the implementations."""
+them (ILL_CONDITIONED).  After the vetting the ORACLE adopts the engine's value at such a pixel, so that nothing later
+inherits the different branch and every later tensor and statistic is again compared under the full bars.  One more
+discontinuity is allowed for by a bound DERIVED from its instances, nothing looser (`_trajectory`): the quantise-error mean /
+std move by 1/(255 n) resp. 1/(255 sqrt(n-1)) per pixel whose uint8 level verifiably differs between the implementations."""
 import numpy as np
 import pytest
 import torch
@@ -71,8 +72,6 @@ def _trajectory(dev, x0, oracles, plans, batches, steps, blur_kernel=None, crop_
         worst[k] = max(worst.get(k, 0.0), v)
 
     tiny = torch.zeros(x0.shape, dtype=torch.bool)      # pixels whose reference gradient was tiny at some step so far
-    had_offenders = False
-    x_std_slack = 0.0          # what the accepted pixels of p may move the NEXT step's std of x by (see below)
     gen = torch.Generator().manual_seed(11)
     shapes = [(B * pl.out_shape[0],) + pl.out_shape[1:] for pl, B in zip(plans, batches)]
     all_z = [[torch.randn(s, generator=gen) for s in shapes] for _ in range(steps + 1)]
@@ -89,10 +88,7 @@ def _trajectory(dev, x0, oracles, plans, batches, steps, blur_kernel=None, crop_
             pv = eng.forward(batches, [z.to(dev) for z in zs], blur_sigma=bs, crop=crop)
         for a, b in zip(pv, pv_ref):
             assert tuple(a.shape) == tuple(b.shape)
-            # elementwise bar: pixel_values of step t carry eps * (deviation of p at an accepted pixel) / std on
-            upd("pixel_values", rel_err(a.cpu(), b, elementwise=ELEMENTWISE_BAR if not had_offenders else None))
-            if had_offenders:
-                upd("pixel_values_max", max_err(a.cpu(), b) / 20.0)      # still bounded: 2e-3 of the largest value
+            upd("pixel_values", rel_err(a.cpu(), b))                      # L2 ratio and elementwise bar
         # the oracle differentiates weight_i * <pv_i, g_i> (/accum in single mode); the engine
         # receives what autograd would hand over: g_i * loss_scale(i)
         ref = ora.backward_update(gs)
@@ -105,13 +101,18 @@ def _trajectory(dev, x0, oracles, plans, batches, steps, blur_kernel=None, crop_
         upd("grad", rel_err(eng.grad.cpu(), ref["grad"]))                 # L2 ratio and elementwise bar
         gr = ref["grad"].abs()
         tiny = tiny | (gr <= 1e-3 * float(gr.max()))
-        off = torch.zeros(0, dtype=torch.long)
         if ora.p.detach().abs().max() > 0:
             off = _check_p(t, eng.p.cpu(), ora.p.detach(), eng.grad.cpu(), ref["grad"], tiny)
-            had_offenders = had_offenders or off.numel() > 0
             keep = torch.ones(x0.numel(), dtype=torch.bool)
             keep[off] = False                       # vetted one by one above; the L2 ratio is over all the others
             upd("p", rel_err(eng.p.cpu().flatten()[keep], ora.p.detach().flatten()[keep]))
+            if off.numel():
+                # A vetted pixel is where the two runs took different branches of a discontinuous update (with the sign
+                # optimiser a whole lr step).  Left alone it would be inherited, through tanh', the blur and the resizes, by
+                # every later tensor and statistic; the ORACLE adopts the engine's value there, so that the rest of the
+                # trajectory is compared like for like under the full bars.
+                with torch.no_grad():
+                    ora.p.view(-1)[off] = eng.p.cpu().view(-1)[off].to(ora.p.dtype)
         # sigma_next / qerr_mean are statistics of |q(s) - s| with q = trunc(clamp(s) * 255) / 255: a pixel whose s * 255 sits
         # on an integer to within the rounding differences of the two implementations truncates to different levels, and
         # that one pixel moves the statistics by 1 / (255 n) resp. 1 / (255 sqrt(n - 1)).  Pixels whose levels DO differ are
@@ -125,17 +126,9 @@ def _trajectory(dev, x0, oracles, plans, batches, steps, blur_kernel=None, crop_
         upd("imgfit", abs(st["img_loss"] - ref["img_loss"]) / max(ref["img_loss"], 1e-12))
         upd("grad_norm", abs(st["grad_norm"] - ref["grad_norm"]) / max(ref["grad_norm"], 1e-12))
         upd("qerr_mean", max(0.0, abs(st["qerr_mean"] - ref["qerr_mean"]) - q_mean_slack) / max(ref["qerr_mean"], 1e-12))
-        # x_std of step t is taken over x = [blur] eps * tanh(p_t): the accepted pixels of p_t shift it by at most
-        # 2 * ||delta x||_2 / sqrt(n) (a std is 1/sqrt(n)-Lipschitz in L2; a reflect-padded blur at most doubles a norm) -
-        # with the sign optimiser one such pixel is a whole lr step off and alone moves the std by 1e-4 of itself
-        d_std = max(0.0, abs(st["x_std"] - ref["x_std"]) - x_std_slack)
-        upd("x_std", d_std / max(ref["x_std"], 1e-12) if ref["x_std"] > 0 else 0.0)
-        x_std_slack = 0.0
-        if ora.p.detach().abs().max() > 0 and off.numel() > 0:
-            dx = eng.eps * (torch.tanh(eng.p.cpu().flatten()[off].double()) - torch.tanh(ora.p.detach().flatten()[off].double()))
-            x_std_slack = 2.0 * float(dx.norm()) / float(x0.numel()) ** 0.5
+        upd("x_std", abs(st["x_std"] - ref["x_std"]) / max(ref["x_std"], 1e-12) if ref["x_std"] > 0 else 0.0)
         assert eng.current_lr() == pytest.approx(ora.current_lr(), rel=1e-12)
-        upd("s", rel_err(eng.image().cpu(), ref["s"], elementwise=ELEMENTWISE_BAR if not had_offenders else None))
+        upd("s", rel_err(eng.image().cpu(), ref["s"]))                    # L2 ratio and elementwise bar
     for k, v in worst.items():
         assert v < TOL, (k, v, worst)
     return worst

@@ -254,7 +254,10 @@ def main():
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--budget-s", type=float, default=240.0)
+    ap.add_argument("--only", type=str, default="", help="comma-separated case numbers: draw every case of the seed's "
+                    "stream (the draws are what positions it) but run only these - to replay a reported failure (trajectory mode)")
     a = ap.parse_args()
+    only = {int(x) for x in a.only.split(",") if x.strip()}
     import test_gpu_pgd as T
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(a.seed)
@@ -262,6 +265,9 @@ def main():
     for k in range(a.cases):
         if time.time() - t0 > a.budget_s:
             break
+        if only and k not in only:
+            draw_case(rng)          # advance the stream exactly as a run of this case would
+            continue
         if a.relations:
             verdict, desc = run_relations(dev, rng, a.seed * 7919 + k)
             worst = {"-": 0.0}
