@@ -260,16 +260,42 @@ def _peer_is_competitive(ex, group=None, iters=20, slack=1.25):
     return bool(t[0] <= slack * t[1]) and not ex.timed_out()
 
 
+#: what the last make_exchange() call on this rank decided and why (every rank holds the same verdict; PixelPGD keeps a
+#: copy as `engine.exchange_report`, bench.py prints it in `config.exchange_report`)
+_last_report = {}
+
+
+def last_exchange_report():
+    return dict(_last_report)
+
+
+def _report(asked, chosen, reason, ex=None):
+    import sys
+    t = getattr(ex, "peer_vs_host_seconds", None) if ex is not None else _last_report.get("_timing")
+    _last_report.clear()
+    _last_report.update(asked=asked, chosen=chosen, reason=reason)
+    if t is not None:
+        _last_report["peer_us"], _last_report["host_us"] = round(t[0] * 1e6, 2), round(t[1] * 1e6, 2)
+    if asked == "auto" and chosen == "host" and not reason.startswith("gloo"):
+        # a fall-back must not be silent: the first multi-GPU run is also the first test of the peer path
+        dist = torch.distributed
+        if not dist.is_initialized() or dist.get_rank() == 0:
+            print(f"[advx] exchange_transport=auto FELL BACK to the host library's all-reduce: {reason}", file=sys.stderr, flush=True)
+
+
 def make_exchange(floats, device, group=None, transport="auto", timeout_s=5.0):
     """transport: "rccl" -> None (torch.distributed all-reduce); "peer" -> PeerExchange or an
-    error; "auto" -> PeerExchange if it can be set up AND passes the probe, else None."""
+    error; "auto" -> PeerExchange if it can be set up AND passes the probe, else None - said loudly on
+    stderr and recorded in `last_exchange_report()` with the reason."""
     if transport not in ("auto", "peer", "rccl"):
         raise ValueError("transport must be auto, peer or rccl")
     if transport == "rccl":
+        _report(transport, "host", "asked for")
         return None
     dist = torch.distributed
     if dist.is_initialized() and dist.get_backend(group) == "gloo" and transport == "auto":
-        return None          # CPU rehearsal groups keep the host all-reduce
+        _report(transport, "host", "gloo group: CPU rehearsal groups keep the host all-reduce")
+        return None
     # memory kinds in order of preference (include/advx.h ADVX_COMM_MEM_*): 0 = uncached if it can
     # be exported, 2 = fine-grained.  Every rank sees every rank's errors (they are gathered in the
     # constructor) and the probe's verdict is agreed, so all ranks walk this list in step.
@@ -282,12 +308,18 @@ def make_exchange(floats, device, group=None, transport="auto", timeout_s=5.0):
             continue
         if probe_peer_exchange(ex, group):
             if transport == "auto" and ex.world > 1 and not _peer_is_competitive(ex, group):
+                timing = ex.peer_vs_host_seconds
+                _last_report["_timing"] = timing
                 ex.close()
-                return None      # correct but slower than the host library on this machine
+                _report(transport, "host", f"peer exchange correct but slower here ({timing[0] * 1e6:.1f} us vs "
+                                           f"{timing[1] * 1e6:.1f} us per all-reduce)")
+                return None
+            _report(transport, "peer", f"self-test passed ({ex.mem_kind} segments)", ex)
             return ex
         ex.close()
         from . import _lib as L
         last_error = L.AdvxError("peer exchange failed its self-test on this machine")
     if transport == "peer":
         raise last_error
+    _report(transport, "host", f"peer exchange unavailable: {last_error}")
     return None

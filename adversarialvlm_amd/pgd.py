@@ -93,9 +93,11 @@ class PixelPGD:
         # for a group of one rank: lets a single GPU exercise the RCCL path
         self.exchange = self.world > 1 or bool(force_exchange)
         self.peer = None
+        self.exchange_report = None
         if self.exchange:
             self.peer = dp.make_exchange(self.x0.numel(), dev, process_group, exchange_transport,
                                          timeout_s=float(exchange_timeout_s))
+            self.exchange_report = dp.last_exchange_report()
         # factor every rank applies to its contribution before the SUM all-reduce: 1/world gives
         # the data-parallel average; cross-model groups pass 1/group_size (average inside a
         # model's group, sum across models - crossattack_models.py:391)

@@ -2,6 +2,7 @@
 """bench.py - the owned pixel-space hot path of the PGD loop on N MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+        (N > 1 without a launcher: this process starts the N ranks itself, before it touches the GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -28,6 +29,8 @@ import argparse
 import collections
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -111,6 +114,65 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
+def launch_ranks(n, argv, backend, limit_s):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks as fresh child
+    processes - one per GPU, torchrun's environment variables, rendezvous on 127.0.0.1 - BEFORE this process makes
+    any GPU call (a process that has initialised HIP must never fork/exec GPU work), wait for them and hand rank 0's
+    single JSON line through on stdout.  -> exit status (0 only if every rank returned 0).
+    The reference runs its models serially in one process (crossattack_models.py:352-391); this is the
+    one-process-per-GPU form of SURVEY 8(e).  With fewer GPUs than ranks (a one-GPU box) the ranks fold onto the
+    devices there are and the host collectives travel over gloo, since RCCL refuses two ranks on one device: a
+    rehearsal of the entry point, said so in the line's `config.launcher`."""
+    n_dev = torch.cuda.device_count()          # counts devices without creating a HIP context on this image
+    if n_dev == 0:
+        print("bench.py needs a GPU (there is no CPU fallback)", file=sys.stderr)
+        return 2
+    extra, note = [], f"self-launched: {n} ranks on {min(n, n_dev)} GPU(s)"
+    if n_dev < n and backend == "nccl":
+        extra = ["--backend", "gloo"]
+        note += f"; REHEARSAL: {n} ranks folded onto {n_dev} device(s), host collectives over gloo (RCCL refuses two ranks per device)"
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ADVX_BENCH_LAUNCHER=note)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL and the peer exchange need it
+        env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores()[0] // n)))
+        # rank 0 inherits stdout (its one JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv) + extra, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    deadline = time.monotonic() + limit_s
+    failed_at = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        now = time.monotonic()
+        if failed_at is None and any(c not in (None, 0) for c in codes):
+            failed_at = now                   # a rank died: its peers get 15 s to notice, then they are stopped
+        if now > deadline or (failed_at is not None and now - failed_at > 15.0):
+            for p in procs:                   # exactly the PIDs started above
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            codes = [p.returncode for p in procs]
+            print(f"bench.py: ranks stopped ({'time limit' if now > deadline else 'a rank failed'}), exit codes {codes}",
+                  file=sys.stderr)
+            return 1
+        time.sleep(0.05)
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,18 +198,26 @@ def main():
                     help="cold = rotate through --ring gradient / output buffers (beyond the Infinity Cache; the headline), "
                          "hot = one resident pair (the round-1 loop), both = cold timed first, hot reported as in_cache")
     ap.add_argument("--ring", type=int, default=8, help="distinct gradient tensors / output blocks of the cold loop")
-    ap.add_argument("--no-graph", action="store_true", help="skip the supplementary hipGraph replay of the cold loop")
+    ap.add_argument("--graph", action="store_true",
+                    help="supplementary figure: the cold loop as a captured hipGraph, on an engine of its own")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="N > 1: skip the supplementary strong-scaling region (64 prompts in total) after the weak one")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="self-launched ranks (no WORLD_SIZE in the environment) are stopped after this many seconds")
     ap.add_argument("--nt-loads", action="store_true", help="experiment: the pair's backward reads grad_out non-temporally")
     args = ap.parse_args()
     io_dtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.io]
     io_bytes = 4 if args.io == "f32" else 2
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's form, `python bench.py --gpus N`: no launcher around us - be the launcher.  Nothing above
+        # this line has created a HIP context (importing torch and counting devices do not).
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.backend, args.launch_timeout))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start {args.gpus} ranks (or none: bench.py launches them)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     local_rank = local_rank % max(1, torch.cuda.device_count())      # rehearsal: several ranks on one GPU
     torch.cuda.set_device(local_rank)
@@ -196,9 +266,9 @@ def main():
         exchange = "none (single rank)"
     else:
         exchange = f"peer ({eng.peer.mem_kind} IPC segments)" if eng.peer is not None else f"{args.backend} all-reduce"
-        timing = getattr(eng.peer, "peer_vs_host_seconds", None)
-        if timing is not None:
-            exchange += f"; at start-up peer {timing[0] * 1e6:.1f} us vs {args.backend} {timing[1] * 1e6:.1f} us per all-reduce"
+        rep = eng.exchange_report or {}
+        if "peer_us" in rep:
+            exchange += f"; at start-up peer {rep['peer_us']:.1f} us vs {args.backend} {rep['host_us']:.1f} us per all-reduce"
     # the synthetic upstream gradients: `ring` distinct tensors, every rank its own; each rank pre-scales its share
     # so that the SUM all-reduce is the DP average
     dgen = torch.Generator(device=dev).manual_seed(1 + rank)
@@ -266,21 +336,47 @@ def main():
     if args.steps < 500 and "cold" in runs:
         long_run = timed(step_cold, steps=1000, warmup=0)
         held.clear()
-    # The same cold steps as a captured hipGraph (supplementary figure): `ring` steps of the pair - forward and backward
-    # with their per-step scalars in device memory (advx_fused_*_sched) - captured once and replayed; no host work per
-    # launch.  Single rank, pair chain only.
+    # Strong scaling beside the weak figure (N > 1): the same cold loop with the GLOBAL batch held at 64 prompts
+    # (64/N per rank, SURVEY 8(e) form A) on the same engine and exchange - the batch is an argument of forward().
+    strong_run = None
+    if world > 1 and args.scaling == "weak" and not args.no_strong and "cold" in runs and BATCH % world == 0:
+        Bs = BATCH // world
+        gs_s = [(torch.randn(Bs, 3, H, W, generator=dgen, device=dev) * eng.loss_scale(0)).to(io_dtype) for _ in range(ring)]
+        held_s = collections.deque(maxlen=ring)
+        cnt_s = [0]
+
+        def step_strong():
+            held_s.append(eng.forward(Bs)[0])
+            eng.backward_update([gs_s[cnt_s[0] % ring]])
+            cnt_s[0] += 1
+
+        sdt, _ = timed(step_strong, steps=max(args.steps, 200), warmup=max(args.warmup, 10))
+        strong_run = (sdt, max(args.steps, 200), Bs)
+        held_s.clear()
+    # The same cold steps as a captured hipGraph (--graph; supplementary figure): `ring` steps of the pair - forward and
+    # backward with their per-step scalars in device memory (advx_fused_*_sched) - captured once and replayed; no host work
+    # per launch.  Single rank, pair chain only, on an engine of its OWN: whatever happens during capture, the engine the
+    # replica / time-out checks below read is not involved.  Only "capture is not supported here" is reduced to a note.
     graph_run = None
-    if args.cache != "hot" and world == 1 and eng.mode == "pair" and not eng.exchange and ring % 2 == 0 and not args.no_graph:
+    if args.graph and args.cache != "hot" and world == 1 and eng.mode == "pair" and not eng.exchange and ring % 2 == 0:
+        geng = PixelPGD(x0, [Plan.llava(H, W)], epsilon=0.5, lr=1e-2, sigma0=1e-3, seed=4321, io_dtype=io_dtype, fused_mode="pair")
+        geng.forward(B)
+        geng.backward_update([gs_ring[0]])              # one eager step: the replayable form needs a prepared engine
+        outs_g = [torch.empty((B, 3 * H * W), dtype=io_dtype, device=dev) for _ in range(ring)]
+        replays = max(1, args.steps // ring)
+        sched = geng.make_schedule(ring * (replays + 1))
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
         try:
-            outs_g = [torch.empty((B, 3 * H * W), dtype=io_dtype, device=dev) for _ in range(ring)]
-            replays = max(1, args.steps // ring)
-            sched = eng.make_schedule(ring * (replays + 1))
-            graph = torch.cuda.CUDAGraph()
-            torch.cuda.synchronize()
             with torch.cuda.graph(graph):
                 for k in range(ring):
-                    eng.forward_sched(B, sched, outs_g[k])
-                    eng.backward_update_sched(gs_ring[k], sched)
+                    geng.forward_sched(B, sched, outs_g[k])
+                    geng.backward_update_sched(gs_ring[k], sched)
+        except RuntimeError as e:
+            if "captur" not in str(e).lower():
+                raise
+            graph_run = f"{type(e).__name__}: {e}"
+        else:
             graph.replay()                                   # warm-up replay (also the first real `ring` steps)
             fence()
             t0 = time.perf_counter()
@@ -288,10 +384,9 @@ def main():
                 graph.replay()
             fence()
             gdt = time.perf_counter() - t0
-            eng.advance(ring * (replays + 1))
+            geng.advance(ring * (replays + 1))
             graph_run = (gdt, ring * replays)
-        except Exception as e:      # supplementary: never cost the run its line
-            graph_run = f"{type(e).__name__}: {e}"
+        del geng
     main_key = "cold" if "cold" in runs else "hot"
     dt, prof = runs[main_key]
     # after the timed regions: the replicas of p must still hold the same bits on every rank, and no
@@ -336,18 +431,23 @@ def main():
     steps_per_s = args.steps / dt
     dom_name, dom_bytes, dom_ms = dominant(runs[main_key])
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = None
+    traffic = traffic_source = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path) and args.scaling == "weak":
         # measured by separate rocprofv3 --pmc passes of `bench.py --cache <state>` (tools/pmc_summary.py);
         # keyed by cache state, kernel and boundary dtype so that it follows whichever kernel dominates here
         with open(pmc_path) as f:
             table = json.load(f)
+        meta = table.get("_meta", {}).get(main_key)
         table = table.get(main_key, table)
         traffic = table.get(dom_name if args.io == "f32" else f"{dom_name}:{args.io}", {}).get("traffic_bytes_per_launch")
+        if traffic is not None:
+            traffic_source = ("stored rocprofv3 PMC pass (profiles/pmc_traffic.json), not a live counter of this run: " +
+                              (f"commit {meta['commit']}, {meta['date_utc']} UTC" if meta else "round 2, unstamped"))
     if rank == 0:
         roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": traffic_source,
                     "cache_state": ("cold: every step reads a gradient tensor and writes an output block last touched "
                                     f"{ring} steps ago ({ring_bytes / 2**20:.0f} MiB in rotation vs the 256 MiB Infinity Cache)"
                                     if main_key == "cold" else "in_cache: one resident gradient tensor and output block"),
@@ -369,6 +469,12 @@ def main():
                        "prompts_per_gpu": B, "global_prompts": B * world, "image": [3, H, W],
                        "noise": "in-kernel Philox4x32-10", "optimizer": "AdamW", "parallelism": f"dp{world}",
                        "path": eng.mode, "boundary_dtype": args.io, "exchange": exchange,
+                       "exchange_report": eng.exchange_report,
+                       "exchange_fell_back": bool(eng.exchange_report and eng.exchange_report["asked"] == "auto"
+                                                  and eng.exchange_report["chosen"] == "host"
+                                                  and not eng.exchange_report["reason"].startswith("gloo")) if eng.exchange else None,
+                       "backend": args.backend if eng.exchange else None,
+                       "launcher": os.environ.get("ADVX_BENCH_LAUNCHER", "external (torchrun environment)" if world > 1 else "none"),
                        "cache_state": main_key, "ring": ring,
                        "replicas_identical": replicas_identical, "exchange_timed_out": exchange_timed_out},
             "steps_per_s": round(steps_per_s, 1),
@@ -394,6 +500,12 @@ def main():
                                 "ms_per_step": round(ldt / 1000 * 1e3, 5), "kernel_ms": kernel_ms(lprof),
                                 "note": f"the same cold loop over 1000 steps, timed after the K = {args.steps} above: fixed costs "
                                         "of a short region (first launch, fence, timed launches) amortised; supplementary"}
+        if strong_run is not None:
+            sdt, ssteps, Bs = strong_run
+            line["strong"] = {"value": round(ssteps / sdt * Bs * world, 1), "unit": "prompt-steps/s", "scaling": "strong",
+                              "steps": ssteps, "ms_per_step": round(sdt / ssteps * 1e3, 5), "steps_per_s": round(ssteps / sdt, 1),
+                              "prompts_per_gpu": Bs, "global_prompts": Bs * world,
+                              "note": "same engine and exchange, global batch held at 64 prompts; timed after the weak region"}
         if isinstance(graph_run, str):
             line["graph_replay"] = {"error": graph_run[:300]}
         elif graph_run is not None:

@@ -6,7 +6,9 @@
 
 With <state> (cold | hot, the --cache mode of the profiled bench.py run) the per-kernel table is also
 stored under that key in <merged.json> (profiles/pmc_traffic.json), where bench.py looks its dominant
-kernel up for `roofline.traffic`.
+kernel up for `roofline.traffic`.  The merged file is stamped (`_meta`: commit from $ADVX_COMMIT - .git does not
+travel to the GPU box -, UTC date, command) and bench.py echoes the stamp as `roofline.traffic_source`: the
+figure is a STORED counter pass, not a live counter of the benchmark run.
 
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KiB;
 on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced
@@ -14,7 +16,9 @@ streaming read -> doubled; WRITE_SIZE is exact for 16-byte-per-lane streaming st
 """
 import collections
 import csv
+import datetime
 import json
+import os
 import re
 import sys
 
@@ -45,9 +49,14 @@ def main():
             merged = json.load(open(merged_path))
         except (OSError, ValueError):
             merged = {}
-        if not all(k in ("cold", "hot") for k in merged):
+        if not all(k in ("cold", "hot", "_meta") for k in merged):
             merged = {}                      # a round-1 table (kernels at the top level)
         merged[state] = out
+        meta = merged.setdefault("_meta", {})
+        meta[state] = {"commit": os.environ.get("ADVX_COMMIT", "unknown"),
+                       "date_utc": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%d %H:%M"),
+                       "collected_by": "tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "
+                                       f"`bench.py --cache {state} --steps 300`; FETCH_SIZE doubled per MI355X_MICROARCH.md"}
         json.dump(merged, open(merged_path, "w"), indent=1)
     for k, v in out.items():
         print(f"{k:20s} fetch(corr) {v['fetch_bytes_corrected'] / 1e6:8.2f} MB  write {v['write_bytes'] / 1e6:8.2f} MB  "

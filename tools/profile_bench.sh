@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 3000 $OUT/${TAG}_bench.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_steps20.json 2>> $OUT/${TAG}_bench.err
-CMD="python3 bench.py --cache $STATE --steps 300 --warmup 20 --no-cpu-baseline --no-graph"
+CMD="python3 bench.py --cache $STATE --steps 300 --warmup 20 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o s -- $CMD > $OUT/${TAG}_stats.log 2>&1
 cp $(find $OUT/${TAG}_stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -o f -- $CMD > $OUT/${TAG}_fetch.log 2>&1
