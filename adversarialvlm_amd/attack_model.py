@@ -304,7 +304,7 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
         if stepped:
             global_iteration += 1
         last = iteration == num_iterations - 1
-        if world > 1 and (iteration % check_every == 0 or last):
+        if world > 1 and (iteration % check_every == 0 or iteration % save_steps == 0 or last):
             # before anything of this step is written: a lost peer or diverged replicas end the run on EVERY rank
             assert_replicas(engine, exp_path, rank, iteration, global_iteration)
         if rank == 0 and (iteration % log_every == 0 or iteration == num_iterations - 1):

@@ -192,7 +192,7 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
         if stepped:
             global_iteration += 1
         last = iteration == num_iterations - 1
-        if world > 1 and (iteration % check_every == 0 or last):
+        if world > 1 and (iteration % check_every == 0 or iteration % save_steps == 0 or last):
             # the sum this exchange replaces (crossattack_models.py:383-406) cannot silently drop a term
             assert_replicas(engine, exp_path, rank, iteration, global_iteration)
         if rank == 0 and (iteration % log_every == 0 or iteration == num_iterations - 1):

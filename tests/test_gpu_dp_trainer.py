@@ -189,3 +189,48 @@ def test_cross_trainer_two_ranks_share_their_draws(tmp_path):
     files = set(os.listdir(os.path.join(tmp, "cross")))
     assert {"state_iter_1.pt", "state_iter_3.pt", "state_iter_5.pt"} <= files
     assert {"test_results_iter_0_rank0.csv", "test_results_iter_0_rank1.csv"} <= files
+
+
+# ------------------------------------------- every checkpoint is preceded by a replica check
+def _cadence_rank(rank, world, port, tmp, out):
+    from adversarialvlm_amd import attack_model, crossattack_models
+    from adversarialvlm_amd.processors import load_components
+    _init(rank, world, port)
+    seen = {"single": [], "cross": []}
+    plain = attack_model.assert_replicas
+
+    def recorder(kind):
+        def check(engine, exp_path, rank_, iteration, global_iteration):
+            seen[kind].append(int(iteration))
+            return plain(engine, exp_path, rank_, iteration, global_iteration)
+        return check
+
+    attack_model.assert_replicas = recorder("single")
+    crossattack_models.assert_replicas = recorder("cross")
+    attack_model.train(**_kw(tmp, "cadence_single", 8, replica_check_every=5, exchange_transport="rccl"))
+    comps = {"synthetic/tiny-llava": load_components("synthetic/tiny-llava")}
+    comps["synthetic/tiny-llava-b"] = comps["synthetic/tiny-llava"]
+    crossattack_models.train(
+        exp_name="cadence_cross", img_orig=_gray(tmp), prompt="list", target_text="sure here it is",
+        model_names=["synthetic/tiny-llava", "synthetic/tiny-llava-b"], lr=1e-2, num_iterations=8, save_steps=3,
+        batch_size=2, grad_accum_steps=1, scheduler_step_size=100, scheduler_gamma=0.9, restart_num=0, mask_type=None,
+        mask_size=None, clamp_method="tanh", epsilon=0.4, sigma=1e-3, start_from_white=False, target_text_random=False,
+        DPO_flag=False, base_path=tmp, components=comps, replica_check_every=5, exchange_transport="rccl", seed=5)
+    out[rank] = seen
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_every_checkpoint_follows_a_replica_check(tmp_path):
+    """with --replica_check_every 5 and --save_steps 3 the checkpoints of iterations 3 and 6
+    used to be written without the collective check that would have caught a timed-out exchange.  Both trainers
+    now check at iteration % check_every == 0, at every save iteration and at the last one - on every rank."""
+    tmp = str(tmp_path)
+    _gray(tmp)
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_cadence_rank, args=(2, _free_port(), tmp, out), nprocs=2, join=True)
+    for r in range(2):
+        assert out[r]["single"] == [0, 3, 5, 6, 7], out[r]
+        assert out[r]["cross"] == [0, 3, 5, 6, 7], out[r]
