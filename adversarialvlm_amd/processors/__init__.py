@@ -51,6 +51,16 @@ MODEL_MAP = {
         "input_class": "AdvLlavaInputs",
         "processor_class": "DifferentiableLlavaImageProcessor",
     },
+    "synthetic/tiny-mllama": {
+        "module": "adversarialvlm_amd.processors.synthetic_vlms",
+        "input_class": "AdvMllamaInputs",
+        "processor_class": "DifferentiableMllamaImageProcessor",
+    },
+    "synthetic/tiny-qwen2vl": {
+        "module": "adversarialvlm_amd.processors.synthetic_vlms",
+        "input_class": "AdvQwen2VLInputs",
+        "processor_class": "DifferentiableQwen2VLImageProcessor",
+    },
     "synthetic/llava-1.5-7b": {
         "module": "adversarialvlm_amd.processors.synthetic",
         "input_class": "AdvLlavaInputs",

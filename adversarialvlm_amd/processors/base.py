@@ -88,6 +88,7 @@ class AdvInputsBase:
     """
     refuses: List[str] = []
     extra_token: str = ""
+    PER_TOKEN_KEYS = ("mm_token_type_ids", "token_type_ids")     # [1, S] tensors of a sample that follow input_ids' padding
 
     def __init__(self, questions: list, test_questions: list, batch_size: int, original_image, processor,
                  device: str = "cuda:0", target_text: Union[str, list] = "sure, here it is!", rng=None):
@@ -194,7 +195,18 @@ class AdvInputsBase:
             if k in ("input_ids", "attention_mask"):
                 continue
             if torch.is_tensor(v):
-                if k == "cross_attention_mask":
+                if k in self.PER_TOKEN_KEYS:
+                    # one id per token (Qwen2-VL's modality ids of transformers 5.x): padded like input_ids, with zeros
+                    full = torch.zeros((len(ids), L), dtype=v.dtype)
+                    for r, s in enumerate(samples):
+                        t = s[k][0]
+                        n = int(t.shape[0])
+                        if left:
+                            full[r, L - n:] = t
+                        else:
+                            full[r, :n] = t
+                    data[k] = full
+                elif k == "cross_attention_mask":
                     # [1, S, images, tiles]: per-token; pad along S like the ids.  Left padding: pad tokens precede
                     # the image, rows of zeros.  Right padding: HF lets the last image's span run to the padded
                     # length (convert_sparse_cross_attention_mask_to_dense), i.e. the last row repeats.

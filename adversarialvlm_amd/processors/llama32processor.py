@@ -26,6 +26,12 @@ class AdvMllamaInputs(AdvInputsBase):
     def _render_inference(self, question):
         return chat_template_render(self.processor, question, None, image_first=True)
 
+    def _encode(self, prompts, images):
+        """`MllamaProcessor` counts images PER SAMPLE: a flat list of n images for n prompts is rejected for n > 1
+        ("The number of image tokens in each text ... should be the same as the number of provided images per batch");
+        one image per prompt goes in as [[im], [im], ...] (the batched generation probe encodes several prompts at once)."""
+        return self.processor(text=prompts, images=[[im] for im in images], padding=True, return_tensors="pt")
+
 
 class DifferentiableMllamaImageProcessor(DifferentiableProcessorBase):
     """Canvas selection, AA resize, zero pad THEN normalise, tile split, zero tiles up to

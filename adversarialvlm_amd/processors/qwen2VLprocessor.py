@@ -33,8 +33,11 @@ class DifferentiableQwen2VLImageProcessor(DifferentiableProcessorBase):
         super().__init__(orig_processor, device)
         self.patch_size = orig_processor.patch_size
         self.merge_size = orig_processor.merge_size
-        self.min_pixels = orig_processor.min_pixels
-        self.max_pixels = orig_processor.max_pixels
+        # transformers 4.51 (the reference's pin) keeps min_pixels / max_pixels as attributes (qwen2VLprocessor.py:141-142);
+        # 5.x moved them into size = {"shortest_edge": min_pixels, "longest_edge": max_pixels}
+        size = getattr(orig_processor, "size", None) or {}
+        self.min_pixels = getattr(orig_processor, "min_pixels", None) or size["shortest_edge"]
+        self.max_pixels = getattr(orig_processor, "max_pixels", None) or size["longest_edge"]
         self.temporal_patch_size = orig_processor.temporal_patch_size
 
     def _make_plan(self, H, W):

@@ -208,8 +208,12 @@ def _cadence_rank(rank, world, port, tmp, out):
     attack_model.assert_replicas = recorder("single")
     crossattack_models.assert_replicas = recorder("cross")
     attack_model.train(**_kw(tmp, "cadence_single", 8, replica_check_every=5, exchange_transport="rccl"))
-    comps = {"synthetic/tiny-llava": load_components("synthetic/tiny-llava")}
-    comps["synthetic/tiny-llava-b"] = comps["synthetic/tiny-llava"]
+    load, AdvInputs, DiffProc = load_components("synthetic/tiny-llava")
+
+    def load_b(name, device):
+        return load("synthetic/tiny-llava", device, seed=1)
+
+    comps = {"synthetic/tiny-llava": (load, AdvInputs, DiffProc), "synthetic/tiny-llava-b": (load_b, AdvInputs, DiffProc)}
     crossattack_models.train(
         exp_name="cadence_cross", img_orig=_gray(tmp), prompt="list", target_text="sure here it is",
         model_names=["synthetic/tiny-llava", "synthetic/tiny-llava-b"], lr=1e-2, num_iterations=8, save_steps=3,

@@ -1,0 +1,157 @@
+"""GPU tier: a Llama-3.2-Vision and a Qwen2-VL ARCHITECTURE inside the loop (missing 2).
+
+BASELINE configs[2..4] name Llama-3.2-11B-Vision, Qwen2-VL-7B and Phi-3.5-Vision.  No weights exist here, but the
+first two architectures ship with the installed transformers, so tiny random models of them
+(adversarialvlm_amd/processors/synthetic_vlms.py) stand where the reference's `model(**inputs)` stands
+(attack_model.py:314-328): the plugin's `get_inputs_train()` (llama32processor.py:119-147: `aspect_ratio_ids`,
+`aspect_ratio_mask`, `cross_attention_mask`; qwen2VLprocessor.py:68-96: `image_grid_thw`) -> the HIP engine's
+`pixel_values` in the family's layout ([B,1,4,3,T,T] / [B*n_patches, 1176]) -> model forward -> `get_loss` ->
+backward -> PixelPGD.  The oracle (oracle/pgd.py + MllamaOracle / Qwen2VLOracle) drives the SAME model on the CPU.
+Bars: loss <= 1e-4 relative, pixel gradient <= 1e-4 (L2 and elementwise).  Then one `crossattack_models.train()`
+over [tiny-llava, tiny-mllama, tiny-qwen2vl] with blur: configs[3]/[4] at the level the reference runs them
+(crossattack_models.py:352-384).  Phi-3.5-Vision's modelling code is remote code: no offline twin exists."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from conftest import rel_err
+from oracle.pgd import PGDOracle
+from oracle.processors import MllamaOracle, Qwen2VLOracle
+
+pytestmark = pytest.mark.gpu
+
+QUESTIONS = ["what is in this image", "describe the scene please", "hi"]
+
+
+def _family(name, H, W):
+    from adversarialvlm_amd.processors import load_components
+    from adversarialvlm_amd.processors import synthetic_vlms as S
+    load, AdvInputs, DiffProc = load_components(name)
+    if name.endswith("mllama"):
+        oracle = MllamaOracle(tile=S.MLLAMA_TILE, max_tiles=S.MLLAMA_MAX_TILES)
+    else:
+        oracle = Qwen2VLOracle(min_pixels=S.QWEN_MIN_PIXELS, max_pixels=S.QWEN_MAX_PIXELS)
+    return load, AdvInputs, DiffProc, oracle
+
+
+@pytest.mark.parametrize("name,size,batch", [("synthetic/tiny-mllama", (60, 90), 3), ("synthetic/tiny-mllama", (56, 56), 2),
+                                             ("synthetic/tiny-mllama", (130, 40), 2), ("synthetic/tiny-qwen2vl", (60, 90), 3),
+                                             ("synthetic/tiny-qwen2vl", (84, 84), 2)])
+def test_two_pgd_steps_loss_and_grad_parity(name, size, batch):
+    from adversarialvlm_amd.pgd import PixelPGD
+    dev = torch.device("cuda:0")
+    H, W = size
+    load, AdvInputs, DiffProc, proc_oracle = _family(name, H, W)
+    model_g, proc = load(name, dev, seed=0)
+    model_c, _ = load(name, "cpu", seed=0)
+    image = Image.fromarray((np.random.default_rng(0).random((H, W, 3)) * 255).astype(np.uint8))
+    adv = DiffProc(proc.image_processor, dev)
+    x0 = adv.pil_to_tensor(image)
+    plan = adv.plan_for(H, W)
+    ora = PGDOracle(x0, [proc_oracle], lr=1e-2)
+    eng = PixelPGD(x0.to(dev), [plan], lr=1e-2)
+    assert eng.mode == "prepared"
+
+    def inputs_for(device):
+        ip = AdvInputs(questions=QUESTIONS, test_questions=["hi"], batch_size=batch, original_image=image, processor=proc,
+                       device=device, target_text="sure here it is", rng=random.Random(5))
+        ip.bind_geometry(adv, H, W)
+        return ip
+    ip_g, ip_c = inputs_for(dev), inputs_for("cpu")
+    gen = torch.Generator().manual_seed(9)
+    lead = plan.out_shape[0]
+    for step in range(2):
+        z = torch.randn((batch * lead,) + plan.out_shape[1:], generator=gen)
+        inputs_c, inputs_g = ip_c.get_inputs_train(), ip_g.get_inputs_train()
+        for k in inputs_c.keys():
+            assert torch.equal(inputs_c[k], inputs_g[k].cpu()), k
+        # ---- reference path (CPU, autograd through everything)
+        pv_ref = ora.forward(batch, [z])[0]
+        losses = {}
+
+        def loss_fn(pv):
+            out = model_c(**inputs_c, pixel_values=pv)
+            l = ip_c.get_loss(out.logits[:, :-1, :])
+            losses["c"] = float(l.detach())
+            return l
+        ref = ora.backward_update(loss_fns=[loss_fn])
+        # ---- HIP path (GPU): pixel ops in libadvx, the VLM under torch
+        pv = eng.forward(batch, [z.to(dev)])[0]
+        assert pv.shape == pv_ref.shape, (pv.shape, pv_ref.shape)
+        assert rel_err(pv.cpu(), pv_ref) < 1e-5
+        pv.requires_grad_(True)
+        inputs = dict(inputs_g)
+        inputs["pixel_values"] = pv                                       # attack_model.py:321
+        out = model_g(**inputs)
+        loss = ip_g.get_loss(out.logits[:, :-1, :])
+        (loss * eng.loss_scale(0)).backward()
+        eng.backward_update([pv.grad])
+        st = eng.stats_dict()
+        assert abs(float(loss.detach()) - losses["c"]) <= 1e-4 * abs(losses["c"]), (float(loss), losses["c"])
+        assert float(ref["grad"].abs().max()) > 0.0                       # the image really reaches the loss
+        assert rel_err(eng.grad.cpu(), ref["grad"]) < 1e-4                # L2 AND elementwise (conftest)
+        assert abs(st["img_loss"] - ref["img_loss"]) <= 1e-4 * max(ref["img_loss"], 1e-12)
+        assert abs(st["sigma_next"] - ref["sigma_next"]) <= 1e-4 * ref["sigma_next"]
+        # the two copies of the VLM run their GEMMs on different devices: p is compared where AdamW's
+        # m / (sqrt(v) + eps) is well conditioned (as in test_gpu_e2e.py)
+        gmask = ref["grad"].abs() > 1e-3 * ref["grad"].abs().max()
+        assert rel_err(eng.p.cpu()[gmask], ora.p.detach()[gmask], elementwise=None) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["synthetic/tiny-mllama", "synthetic/tiny-qwen2vl"])
+def test_single_trainer_runs_the_family(tmp_path, name):
+    """attack_model.train() end to end on the family's plugin: artefacts, finite losses, the target gets more likely,
+    and the batched generation probe (it crashed for Mllama at the first save step)."""
+    from adversarialvlm_amd import attack_model
+    tmp = str(tmp_path)
+    path = os.path.join(tmp, "gray.png")
+    Image.fromarray(np.full((60, 90, 3), 128, np.uint8)).save(path)
+    hist = attack_model.train(exp_name="fam", img_orig=path, prompt="describe the scene please", target_text="sure here it is", model_name=name,
+                              lr=1e-2, num_iterations=8, save_steps=4, batch_size=3, grad_accum_steps=1,
+                              scheduler_step_size=100, scheduler_gamma=1.0, restart_num=0, mask_type="corner", mask_size=40,
+                              clamp_method="tanh", epsilon=0.5, sigma=1e-3, start_from_white=False, target_text_random=False,
+                              base_path=tmp, generation_probe=True, resaved_loss_every=4)
+    files = set(os.listdir(os.path.join(tmp, "fam")))
+    assert {"optimized_image_iter_1.png", "optimized_image_iter_5.png", "optimized_image_iter_final.bin",
+            "test_results_iter_0.csv", "test_results_iter_4.csv", "state_iter_5.pt"} <= files, sorted(files)
+    assert len(hist) == 8 and all(np.isfinite(h["loss"]) for h in hist)
+    assert hist[-1]["ce_loss"] < hist[0]["ce_loss"]
+    assert "loss_resaved" in hist[0] and np.isfinite(hist[4]["loss_resaved"])
+    raw = np.fromfile(os.path.join(tmp, "fam", "optimized_image_iter_final.bin"), dtype=np.float32).reshape(3, 60, 90)
+    assert np.all(raw[:, 40:, :] == np.float32(128 / 255)) and np.any(raw[:, :40, :40] != np.float32(128 / 255))   # the mask held
+
+
+def test_cross_trainer_three_families_with_blur(tmp_path):
+    """configs[3]/[4] at the reference's level: crossattack_models.train() over a LLaVA, a Mllama and a Qwen2-VL
+    architecture with Gaussian blur (sigma redrawn per step) and crop, weights, multi-answer - one engine, three
+    plans, three models' gradients summed (crossattack_models.py:352-391)."""
+    import json
+
+    from adversarialvlm_amd import crossattack_models
+    tmp = str(tmp_path)
+    path = os.path.join(tmp, "gray.png")
+    Image.fromarray(np.full((70, 70, 3), 128, np.uint8)).save(path)
+    ans = os.path.join(tmp, "answers.json")
+    json.dump(["sure here it is", "of course the answer is"], open(ans, "w"))
+    names = ["synthetic/tiny-llava", "synthetic/tiny-mllama", "synthetic/tiny-qwen2vl"]
+    eng, hist = crossattack_models.train(
+        exp_name="cross3", img_orig=path, prompt="list", target_text="unused", model_names=names, lr=1e-2, num_iterations=3,
+        save_steps=2, batch_size=2, grad_accum_steps=1, scheduler_step_size=100, scheduler_gamma=0.9, restart_num=0,
+        mask_type=None, mask_size=None, clamp_method="tanh", epsilon=0.4, sigma=1e-3, start_from_white=False,
+        target_text_random=True, answers_file=ans, DPO_flag=False, model_weights=[0.5, 0.3, 0.2], use_gaussian_blur=True,
+        gblur_kernel_size=5, use_local_crop=True, base_path=tmp, return_engine=True, generation_probe=True, seed=2)
+    assert len(eng.plans) == 3 and eng.mode == "generic"
+    assert len(hist) == 3 and all(np.isfinite(h["loss_per_iteration"]) for h in hist)
+    for h in hist:
+        per_model = [h[f"loss_{i}_{n.replace('/', '_')}"] for i, n in enumerate(names)]
+        assert all(np.isfinite(v) and v > 0 for v in per_model), h
+    assert float(eng.p.abs().max()) > 0 and bool(torch.isfinite(eng.p).all())
+    files = set(os.listdir(os.path.join(tmp, "cross3")))
+    assert {"optimized_image_iter_1.png", "optimized_image_iter_3.png", "optimized_image_iter_final.bin", "state_iter_3.pt",
+            "test_results_iter_0.csv"} <= files, sorted(files)
+    header = open(os.path.join(tmp, "cross3", "test_results_iter_0.csv")).readline().strip().split(",")
+    assert header == ["question"] + names

@@ -1,0 +1,64 @@
+"""CPU tier: the encode step of the batched generation probe (train_test._generate_batched -> ip._encode) for the
+plugins whose HF processor takes images per SAMPLE.  ADVICE r02 (high): a flat image list made `MllamaProcessor`
+raise for more than one prompt, so every run with --generation_probe and a Llama-3.2 model died at its first save
+step.  Also the Qwen2-VL batch against one processor call (the processor is the toy joining of
+the real image processor and a real fast tokenizer, since `Qwen2VLProcessor` does not construct without
+torchvision - see DESIGN.md section 2)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+QUESTIONS = ["what is in this image", "describe the scene please", "hi", "describe this image now please"]
+
+
+def _image(H, W):
+    return Image.fromarray((np.random.default_rng(0).random((H, W, 3)) * 255).astype(np.uint8))
+
+
+def test_mllama_probe_encodes_several_prompts():
+    from adversarialvlm_amd.processors.synthetic_vlms import AdvMllamaInputs, mllama_processor
+    proc, _ = mllama_processor()
+    img = _image(60, 90)
+    ip = AdvMllamaInputs(questions=QUESTIONS, test_questions=QUESTIONS, batch_size=2, original_image=img, processor=proc,
+                         device="cpu", target_text="sure here it is")
+    prompts = [ip._render_inference(q) for q in QUESTIONS[:3]]
+    with pytest.raises(ValueError):                      # what the probe used to do
+        proc(text=prompts, images=[img] * 3, padding=True, return_tensors="pt")
+    enc = ip._encode(prompts, [img] * 3)
+    assert enc["input_ids"].shape[0] == 3 and enc["pixel_values"].shape[:3] == (3, 1, 4)
+    assert enc["cross_attention_mask"].shape[:2] == enc["input_ids"].shape
+    assert int(enc["attention_mask"].min()) == 0          # rows of different length: left padding is really exercised
+    one = ip._encode(prompts[:1], [img])                 # the serial probe and get_inputs_train use the same method
+    assert torch.equal(one["aspect_ratio_ids"], enc["aspect_ratio_ids"][:1])
+
+
+@pytest.mark.parametrize("size", [(60, 90), (130, 40), (56, 56)])
+def test_qwen2vl_batches_equal_one_processor_call(size):
+    """get_inputs_train() (cached tokenisation, hand-assembled left padding, image_grid_thw from the PLAN) against
+    ONE call of the processor on the same prompts, key by key - qwen2VLprocessor.py:68-96 keeps whatever that call
+    returns.  `mm_token_type_ids` (transformers 5.x) follows input_ids' padding."""
+    from adversarialvlm_amd.processors.synthetic_vlms import (AdvQwen2VLInputs, DifferentiableQwen2VLImageProcessor,
+                                                              qwen2vl_processor)
+    proc, _ = qwen2vl_processor()
+    H, W = size
+    img = _image(H, W)
+    adv = DifferentiableQwen2VLImageProcessor(proc.image_processor, "cpu")
+    ip = AdvQwen2VLInputs(questions=QUESTIONS, test_questions=["hi"], batch_size=5, original_image=img, processor=proc,
+                          device="cpu", target_text="sure here it is", rng=random.Random(4))
+    ip.bind_geometry(adv, H, W)
+    for _ in range(3):
+        state = ip.rng.getstate()
+        got = ip.get_inputs_train()
+        ip.rng.setstate(state)
+        drawn = ip.rng.choices(QUESTIONS, k=5)
+        want = proc(text=[ip._render_train(q, ip.target_text) for q in drawn], images=[img] * 5)
+        assert set(got.keys()) == set(want.keys()) - {"pixel_values"}
+        for k in got.keys():
+            assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k]), k
+    assert int(got["attention_mask"].min()) == 0 and int(got["mm_token_type_ids"].max()) == 1
+    n_img = int((got["input_ids"][0] == proc.image_token_id).sum())
+    t, gh, gw = got["image_grid_thw"][0].tolist()
+    assert n_img == t * gh * gw // 4                      # one placeholder per merged 2x2 patch group
