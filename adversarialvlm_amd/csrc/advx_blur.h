@@ -299,7 +299,7 @@ __device__ inline void blur_bwd_body(const float* __restrict__ gsrc, const float
             adamw_element(pv, m1, v1, g, o);
             p[i] = pv; m[i] = m1; v[i] = v1;
           } else {
-            float sg = (g > 0.0f) ? 1.0f : ((g < 0.0f) ? -1.0f : 0.0f);
+            float sg = sign_direction(g);
             p[i] = pv - o.lr * sg;
           }
         }

@@ -1072,6 +1072,18 @@ struct OptScalars {
   float lr, decay, w1, beta2, w2, bias2_sqrt, eps, neg_step_size;
 };
 
+// The direction of the sign optimiser (ADVX_OPT_SIGN; north_star's "sign" update - the reference has AdamW only).  A gradient
+// below the smallest NORMAL fp32 counts as zero.  Why: where a pixel's true gradient is of the order of 2^-149 - the far tail
+// of a narrow blur kernel times the image-fit term - two correctly rounded evaluations of the same sum (this library's
+// separable transposed blur, torchvision's k x k product kernel fl(w_i w_j)) land on 0 and on 1.4e-45 respectively; neither
+// side flushes (tools/diag_denormal.py, profiles/r03/diag_denormal.log), it is one unit in the last place at the bottom of
+// the format.  sign() turns that ulp into a whole lr step.  With the dead zone the discontinuity sits at 1.18e-38, where
+// the two evaluations agree to 1e-7 relative.  oracle/pgd.py applies the same rule.
+constexpr float kSignDeadZone = 1.17549435e-38f;
+__device__ inline float sign_direction(float g) {
+  return (g >= kSignDeadZone) ? 1.0f : ((g <= -kSignDeadZone) ? -1.0f : 0.0f);
+}
+
 // torch.optim.AdamW single-tensor arithmetic on one element
 __device__ inline void adamw_element(float& p, float& m, float& v, float g, const OptScalars& o) {
   p = p * o.decay;                       // param.mul_(1 - lr*wd)
@@ -1097,7 +1109,7 @@ __global__ void __launch_bounds__(kBlock) k_update(float* __restrict__ p, float*
         adamw_element(pp, mm, vv, g, o);
         p[i] = pp; m[i] = mm; v[i] = vv;
       } else {
-        float sg = (g > 0.0f) ? 1.0f : ((g < 0.0f) ? -1.0f : 0.0f);
+        float sg = sign_direction(g);
         p[i] = p[i] - o.lr * sg;
       }
     }
@@ -1153,7 +1165,7 @@ __global__ void __launch_bounds__(kBlock) k_bwd_update(const float* __restrict__
         adamw_element(pp, mm, vv, g, o);
         p[i] = pp; m[i] = mm; v[i] = vv;
       } else {
-        float sg = (g > 0.0f) ? 1.0f : ((g < 0.0f) ? -1.0f : 0.0f);
+        float sg = sign_direction(g);
         p[i] = pp - o.lr * sg;
       }
     }
@@ -1350,7 +1362,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_bwd(const void* __restrict__ g
           adamw_element(pp, mm, vv, gp, o);
           p[i] = pp; m[i] = mm; v[i] = vv;
         } else {
-          float sg = (gp > 0.0f) ? 1.0f : ((gp < 0.0f) ? -1.0f : 0.0f);
+          float sg = sign_direction(gp);
           pp = pp - o.lr * sg;
           p[i] = pp;
         }
@@ -1401,7 +1413,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_update(float* __restrict__ p, 
       adamw_element(pp, mm, vv, g, o);
       p[i] = pp; m[i] = mm; v[i] = vv;
     } else {
-      float sg = (g > 0.0f) ? 1.0f : ((g < 0.0f) ? -1.0f : 0.0f);
+      float sg = sign_direction(g);
       pp = pp - o.lr * sg;
       p[i] = pp;
     }
@@ -1461,7 +1473,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_tail(DStage st, CanvasGrad cg, 
       adamw_element(pp, mm, vv, gp, o);
       p[i] = pp; m[i] = mm; v[i] = vv;
     } else {
-      float sg = (gp > 0.0f) ? 1.0f : ((gp < 0.0f) ? -1.0f : 0.0f);
+      float sg = sign_direction(gp);
       pp = pp - o.lr * sg;
       p[i] = pp;
     }
@@ -1523,7 +1535,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_update(float* __restrict__ p, f
       adamw_element(pp, mm, vv, gp, o);
       p[i] = pp; m[i] = mm; v[i] = vv;
     } else {
-      float sg = (gp > 0.0f) ? 1.0f : ((gp < 0.0f) ? -1.0f : 0.0f);
+      float sg = sign_direction(gp);
       pp = pp - o.lr * sg;
       p[i] = pp;
     }
@@ -1649,7 +1661,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_step_wave(const float* __restr
       adamw_element(pp, mm, vv, gp, o);
       p[i] = pp; m[i] = mm; v[i] = vv;
     } else {
-      float sg = (gp > 0.0f) ? 1.0f : ((gp < 0.0f) ? -1.0f : 0.0f);
+      float sg = sign_direction(gp);
       pp = pp - o.lr * sg;
       p[i] = pp;
     }

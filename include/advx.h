@@ -62,7 +62,7 @@ extern "C" {
 #define ADVX_STATS_N 16
 
 #define ADVX_OPT_ADAMW 0 /* torch.optim.AdamW, attack_model.py:184 */
-#define ADVX_OPT_SIGN 1  /* p -= lr*sign(g): PGD-style variant named by the north star (not in the reference) */
+#define ADVX_OPT_SIGN 1  /* p -= lr*sign(g): PGD-style variant named by the north star (not in the reference); |g| below FLT_MIN (1.18e-38) counts as 0 */
 
 typedef struct advx_plan advx_plan;
 

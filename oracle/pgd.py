@@ -108,7 +108,12 @@ class PGDOracle:
             else:
                 with torch.no_grad():
                     lr = self.lr0 * self.gamma ** (self.opt_steps // self.step_size)
-                    self.p.sub_(lr * torch.sign(self.p.grad))
+                    # sign with a dead zone below the smallest normal fp32: at the 2^-149 level two correctly rounded
+                    # evaluations of the gradient differ between 0 and 1.4e-45 (separable vs product-kernel blur), and a
+                    # bare sign() would make that ulp a whole step - same rule as csrc/advx_kernels.h sign_direction()
+                    gp = self.p.grad
+                    gp = torch.where(gp.abs() >= torch.finfo(torch.float32).tiny, gp, torch.zeros_like(gp))
+                    self.p.sub_(lr * torch.sign(gp))
                     self.p.grad = None
             self.opt_steps += 1
             stepped = True

@@ -17,6 +17,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: full-size GPU cases whose oracle takes tens of seconds of CPU")
 
 
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """How many exceptions the trajectory comparison made in this run (tests/test_gpu_pgd.py): the deterministic tests
+    allow two pixels per trajectory, the random trajectories eight - the count belongs in the log the driver keeps."""
+    mod = sys.modules.get("test_gpu_pgd")
+    if mod is not None:
+        terminalreporter.write_line(f"trajectory comparison: {len(mod.ILL_CONDITIONED)} ill-conditioned pixel-steps of p accepted "
+                                    f"(AdamW, every gradient of the pixel <= max(1e3 adam_eps, 1e-3 max|g|); <= 2 per deterministic trajectory, <= 8 per random one), {mod.QUANTISER_FLIPS[0]} quantiser-level flips "
+                                    "allowed for, 0 oracle values adopted")
+
+
 def pytest_collection_modifyitems(config, items):
     if torch.cuda.is_available():
         return
@@ -51,16 +61,18 @@ def max_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-def rel_err(a, b, elementwise=ELEMENTWISE_BAR):
+def rel_err(a, b, elementwise=ELEMENTWISE_BAR, slack=0.0):
     """L2-norm ratio ||a - b|| / ||b|| (what the callers bound, at 5e-6 ... 1e-4).  A norm ratio can hide a handful
     of entries that are off by far more, so every comparison ALSO has to meet the elementwise bar
-    max|a - b| <= elementwise * max|b| (None switches it off where a caller states why)."""
+    max|a - b| <= elementwise * max|b| (None switches it off where a caller states why).  `slack`: an ABSOLUTE allowance
+    added to that bar, for a caller that derives it from counted instances (test_gpu_pgd.py: what the vetted pixels of
+    p can move downstream)."""
     a = torch.as_tensor(a).double().flatten()
     b = torch.as_tensor(b).double().flatten()
     if elementwise is not None and a.numel():
         worst = (a - b).abs()
         k = int(worst.argmax())
-        bar = elementwise * float(b.abs().max())
+        bar = elementwise * float(b.abs().max()) + float(slack)
         assert float(worst[k]) <= bar + 1e-30, (f"elementwise bar: |a-b| = {float(worst[k]):.3e} at flat index {k} "
                                                 f"(a = {float(a[k]):.9g}, b = {float(b[k]):.9g}) > {elementwise:g} * max|b| = {bar:.3e}")
     return float((a - b).norm() / (b.norm() + 1e-30))

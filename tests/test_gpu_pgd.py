@@ -3,15 +3,33 @@ against the CPU oracle (oracle/pgd.py) on identical inputs: noise, blur sigma an
 window are passed to both.  Bar: p, grad, sigma within 1e-4 relative (north star) - as an L2-norm ratio
 AND elementwise, max|a - b| <= 1e-4 * max|b|.
 
-The elementwise bar holds everywhere for pixel_values and for the pixel gradient.  The optimised tensor p can miss
-it at ISOLATED pixels: AdamW's update m/(sqrt(v)+1e-8) - and the sign step - is discontinuous in the gradient where
-|g| is of the order of adam_eps (first steps, edge taps of a window, mask borders), so a 1e-9 absolute difference
-in g moves p by a per cent of a step.  `_check_p` accepts such a pixel only if its GRADIENT agrees elementwise
-(<= 1e-4 * max|g|) and was tiny (<= 1e-3 * max|g|) at some step so far, bounds their number and logs every one of
-them (ILL_CONDITIONED).  After the vetting the ORACLE adopts the engine's value at such a pixel, so that nothing later
-inherits the different branch and every later tensor and statistic is again compared under the full bars.  One more
-discontinuity is allowed for by a bound DERIVED from its instances, nothing looser (`_trajectory`): the quantise-error mean /
-std move by 1/(255 n) resp. 1/(255 sqrt(n-1)) per pixel whose uint8 level verifiably differs between the implementations."""
+The oracle is never touched by the engine: it runs its own trajectory from its own p (round 2 let it adopt the
+engine's value at vetted pixels; that is gone).  The elementwise bar holds everywhere for pixel_values and for the
+pixel gradient.  The optimised tensor p can miss it at ISOLATED pixels under AdamW only.  AdamW's step m^/(sqrt(v^)+1e-8)
+normalises the gradient by its own history, so what matters is the RELATIVE error of a pixel's gradients: the two
+implementations agree to ~1e-7 * max|g| absolutely, which is 1e-3 relative - a tenth of a per cent of every step, the size of
+the bar - at a pixel whose gradients have all been below 1e-4 * max|g| (a zero crossing of the gradient field, the edge tap
+of a crop window, the border of a mask), and a per cent of a step where they are of the order of adam_eps.
+`_check_p` accepts such a pixel only if
+  * the optimiser is AdamW (the sign step has a dead zone below FLT_MIN on both sides - csrc sign_direction,
+    oracle/pgd.py - and gets no exception at all),
+  * its GRADIENT agrees elementwise at this step (<= 1e-4 * max|g|),
+  * |g| <= max(1e3 * adam_eps, 1e-3 * max|g|) at this and at EVERY earlier optimiser step of the trajectory, in both
+    implementations (round 2 asked for "at some step so far"; a pixel that has once seen a real gradient is well
+    conditioned and gets no exception),
+  * the trajectory's budget `max_ill` is not exceeded: an absolute handful, DET_MAX_ILL = 2 pixels for the deterministic
+    tests (measured need: one pixel of 338 688 in the 336 x 336 baseline case - g = 1.1e-7 against max|g| = 0.65 at step 0 -
+    and one or two in four smaller cases, profiles/r03/pgd_tests_budget0.log; zero is not attainable and the premise that it
+    is was wrong) and FUZZ_MAX_ILL = 8 for the random trajectories;
+it stays excluded from p's comparison for the rest of the trajectory (its moments differ from then on) and every
+acceptance is logged (ILL_CONDITIONED; the count is printed in pytest's summary line, tests/conftest.py).  What such a
+pixel can move DOWNSTREAM is bounded from its measured difference, nothing looser: d = eps * max|p_engine - p_oracle|
+over the vetted pixels bounds the change of x = eps tanh(p) at them; blur, crop and resize weights are (near-)convex
+combinations (bicubic: sum|w| <= 1.3) and the normalisation divides by std >= 0.26, so the image `s` gets the absolute
+allowance d and `pixel_values` 5 d on top of their elementwise bars (zero when nothing was vetted).
+One more discontinuity is allowed for by a bound DERIVED from its instances, nothing looser (`_trajectory`): the
+quantise-error mean / std move by 1/(255 n) resp. 1/(255 sqrt(n-1)) per pixel whose uint8 level verifiably differs
+between the implementations (QUANTISER_FLIPS counts them)."""
 import numpy as np
 import pytest
 import torch
@@ -23,28 +41,37 @@ from oracle.processors import LlavaOracle, MllamaOracle, Phi3Oracle, Qwen2VLOrac
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+ADAM_EPS = 1e-8
+DET_MAX_ILL = 2             # pixels of p a deterministic test's trajectory may have vetted, in total over its steps
+FUZZ_MAX_ILL = 8            # the same for a RANDOM trajectory (tools/fuzz_pgd.py, test_random_trajectories)
 ILL_CONDITIONED = []        # (step, flat pixel index, p engine, p oracle, g engine, g oracle, max|g|) of accepted pixels
+QUANTISER_FLIPS = [0]       # pixels whose uint8 level differed between the implementations (allowed for by a derived bound)
 
 
-def _check_p(step, p_eng, p_ref, g_eng, g_ref, tiny_so_far):
-    """Elementwise bar on p with the documented exception (module docstring).  -> offenders (flat indices)."""
+def _check_p(step, p_eng, p_ref, g_eng, g_ref, always_tiny, excluded, budget, optimizer):
+    """Elementwise bar on p with the documented exception (module docstring).  `excluded` (bool, flat) is updated
+    in place with the newly vetted pixels; -> number accepted at this step."""
     dp = (p_eng.double() - p_ref.double()).abs().flatten()
     bar = ELEMENTWISE_BAR * float(p_ref.abs().max())
-    off = torch.nonzero(dp > bar).flatten()
+    off = torch.nonzero((dp > bar) & ~excluded).flatten()
     if off.numel() == 0:
-        return off
+        return 0
     gmax = float(g_ref.abs().max())
     ge, gr = g_eng.double().flatten(), g_ref.double().flatten()
-    limit = max(4, p_ref.numel() // 1000)
-    assert off.numel() <= limit, f"step {step}: {off.numel()} pixels of p miss the elementwise bar (at most {limit} tolerated)"
+    first = off[0].item()
+    what = (f"step {step}: {off.numel()} pixel(s) of p miss the elementwise bar, e.g. flat index {first}: p {float(p_eng.flatten()[first]):.9g} "
+            f"vs {float(p_ref.flatten()[first]):.9g}, g {float(ge[first]):.3e} vs {float(gr[first]):.3e} (max|g| {gmax:.3e})")
+    assert optimizer == "adamw", f"{what} - the sign step has no ill-conditioned pixels"
+    assert off.numel() <= budget, f"{what}; this trajectory may vet {budget} more"
     for k in off.tolist():
         rec = (step, k, float(p_eng.flatten()[k]), float(p_ref.flatten()[k]), float(ge[k]), float(gr[k]), gmax)
         assert abs(ge[k] - gr[k]) <= ELEMENTWISE_BAR * gmax, f"p AND its gradient differ at a pixel: {rec}"
-        assert bool(tiny_so_far.flatten()[k]), f"p misses the elementwise bar at a pixel whose gradient was never tiny: {rec}"
+        assert bool(always_tiny[k]), f"p misses the elementwise bar at a pixel that has seen a gradient above max(1e3 adam_eps, 1e-3 max|g|): {rec}"
         ILL_CONDITIONED.append(rec)
         print(f"ill-conditioned pixel accepted: step {step}, index {k}, p {rec[2]:.9g} vs {rec[3]:.9g}, "
               f"g {rec[4]:.3e} vs {rec[5]:.3e} (max|g| {gmax:.3e})")
-    return off
+    excluded[off] = True
+    return int(off.numel())
 
 
 @pytest.fixture(scope="module")
@@ -59,7 +86,8 @@ def _plans():
 
 def _trajectory(dev, x0, oracles, plans, batches, steps, blur_kernel=None, crop_fn=None, blur_sigma_fn=None,
                 mask=None, accum=1, weights=None, cross=False, optimizer="adamw", fused=True, gamma=1.0, step_size=100,
-                lr=1e-2, fused_mode="auto", noise_ahead=False):
+                lr=1e-2, fused_mode="auto", noise_ahead=False, max_ill=DET_MAX_ILL):
+    """max_ill: how many pixels of p `_check_p` may vet over the whole trajectory (module docstring)."""
     from adversarialvlm_amd.pgd import PixelPGD
     ora = PGDOracle(x0, oracles, lr=lr, mask=mask, grad_accum_steps=accum, blur_kernel=blur_kernel, model_weights=weights,
                     cross_mode=cross, optimizer=optimizer, scheduler_gamma=gamma, scheduler_step_size=step_size)
@@ -71,7 +99,10 @@ def _trajectory(dev, x0, oracles, plans, batches, steps, blur_kernel=None, crop_
     def upd(k, v):
         worst[k] = max(worst.get(k, 0.0), v)
 
-    tiny = torch.zeros(x0.shape, dtype=torch.bool)      # pixels whose reference gradient was tiny at some step so far
+    always_tiny = torch.ones(x0.numel(), dtype=torch.bool)    # pixels whose gradient has stayed below the threshold, on both sides
+    excluded = torch.zeros(x0.numel(), dtype=torch.bool)      # pixels of p vetted at an earlier step
+    budget = int(max_ill)
+    drift = 0.0              # eps * max|p_engine - p_oracle| over the vetted pixels: what they can move downstream
     gen = torch.Generator().manual_seed(11)
     shapes = [(B * pl.out_shape[0],) + pl.out_shape[1:] for pl, B in zip(plans, batches)]
     all_z = [[torch.randn(s, generator=gen) for s in shapes] for _ in range(steps + 1)]
@@ -88,7 +119,7 @@ def _trajectory(dev, x0, oracles, plans, batches, steps, blur_kernel=None, crop_
             pv = eng.forward(batches, [z.to(dev) for z in zs], blur_sigma=bs, crop=crop)
         for a, b in zip(pv, pv_ref):
             assert tuple(a.shape) == tuple(b.shape)
-            upd("pixel_values", rel_err(a.cpu(), b))                      # L2 ratio and elementwise bar
+            upd("pixel_values", rel_err(a.cpu(), b, slack=5.0 * drift))   # L2 ratio and elementwise bar
         # the oracle differentiates weight_i * <pv_i, g_i> (/accum in single mode); the engine
         # receives what autograd would hand over: g_i * loss_scale(i)
         ref = ora.backward_update(gs)
@@ -99,20 +130,15 @@ def _trajectory(dev, x0, oracles, plans, batches, steps, blur_kernel=None, crop_
             eng.backward_update([g.to(dev) * eng.loss_scale(i) for i, g in enumerate(gs)])
         st = eng.stats_dict()
         upd("grad", rel_err(eng.grad.cpu(), ref["grad"]))                 # L2 ratio and elementwise bar
-        gr = ref["grad"].abs()
-        tiny = tiny | (gr <= 1e-3 * float(gr.max()))
+        if ref["stepped"]:      # the gradients the optimiser has seen (a window's partial sums are not among them)
+            small = max(1e3 * ADAM_EPS, 1e-3 * float(ref["grad"].abs().max()))
+            always_tiny &= (ref["grad"].abs().flatten() <= small) & (eng.grad.cpu().abs().flatten() <= small)
         if ora.p.detach().abs().max() > 0:
-            off = _check_p(t, eng.p.cpu(), ora.p.detach(), eng.grad.cpu(), ref["grad"], tiny)
-            keep = torch.ones(x0.numel(), dtype=torch.bool)
-            keep[off] = False                       # vetted one by one above; the L2 ratio is over all the others
+            budget -= _check_p(t, eng.p.cpu(), ora.p.detach(), eng.grad.cpu(), ref["grad"], always_tiny, excluded, budget, optimizer)
+            keep = ~excluded                        # vetted one by one; the L2 ratio and the bar are over all the others
             upd("p", rel_err(eng.p.cpu().flatten()[keep], ora.p.detach().flatten()[keep]))
-            if off.numel():
-                # A vetted pixel is where the two runs took different branches of a discontinuous update (with the sign
-                # optimiser a whole lr step).  Left alone it would be inherited, through tanh', the blur and the resizes, by
-                # every later tensor and statistic; the ORACLE adopts the engine's value there, so that the rest of the
-                # trajectory is compared like for like under the full bars.
-                with torch.no_grad():
-                    ora.p.view(-1)[off] = eng.p.cpu().view(-1)[off].to(ora.p.dtype)
+            if excluded.any():
+                drift = eng.eps * float((eng.p.cpu().flatten()[excluded] - ora.p.detach().flatten()[excluded]).abs().max())
         # sigma_next / qerr_mean are statistics of |q(s) - s| with q = trunc(clamp(s) * 255) / 255: a pixel whose s * 255 sits
         # on an integer to within the rounding differences of the two implementations truncates to different levels, and
         # that one pixel moves the statistics by 1 / (255 n) resp. 1 / (255 sqrt(n - 1)).  Pixels whose levels DO differ are
@@ -120,6 +146,7 @@ def _trajectory(dev, x0, oracles, plans, batches, steps, blur_kernel=None, crop_
         s_eng, s_ref = eng.image().cpu(), ref["s"]
         flips = int((torch.trunc(s_eng.clamp(0, 1) * 255) != torch.trunc(s_ref.clamp(0, 1) * 255)).sum())
         assert flips <= max(2, s_ref.numel() // 20000), f"step {t}: {flips} pixels quantise to another level"
+        QUANTISER_FLIPS[0] += flips
         q_mean_slack = flips / (255.0 * s_ref.numel())
         q_std_slack = flips ** 0.5 / (255.0 * (s_ref.numel() - 1) ** 0.5)
         upd("sigma", max(0.0, abs(st["sigma_next"] - ref["sigma_next"]) - q_std_slack) / max(ref["sigma_next"], 1e-12))
@@ -128,7 +155,7 @@ def _trajectory(dev, x0, oracles, plans, batches, steps, blur_kernel=None, crop_
         upd("qerr_mean", max(0.0, abs(st["qerr_mean"] - ref["qerr_mean"]) - q_mean_slack) / max(ref["qerr_mean"], 1e-12))
         upd("x_std", abs(st["x_std"] - ref["x_std"]) / max(ref["x_std"], 1e-12) if ref["x_std"] > 0 else 0.0)
         assert eng.current_lr() == pytest.approx(ora.current_lr(), rel=1e-12)
-        upd("s", rel_err(eng.image().cpu(), ref["s"]))                    # L2 ratio and elementwise bar
+        upd("s", rel_err(eng.image().cpu(), ref["s"], slack=drift))       # L2 ratio and elementwise bar
     for k, v in worst.items():
         assert v < TOL, (k, v, worst)
     return worst
@@ -222,9 +249,8 @@ def test_random_trajectories(dev):
     """Seeded subset of tools/fuzz_pgd.py: random image sizes, processors (single and weighted
     cross-model sets), batches, blur, crop windows, masks, accumulation, optimiser, scheduler and
     chain, 3-5 steps each, under the trajectory parity bar (L2 ratio and elementwise).  Isolated pixels of p
-    at which the update is discontinuous are vetted and logged by `_check_p`; a case may additionally be classified
-    "ill-conditioned" by fuzz_pgd.run_case when one pixel's uint8 truncation flips in the quantise-error statistics
-    (the oracle, replayed with 3e-7 relative input noise, moves as far); none may fail."""
+    at which AdamW is ill-conditioned are vetted and logged by `_check_p` (at most FUZZ_MAX_ILL per trajectory, in total);
+    none may fail, and none may need fuzz_pgd.run_case's "ill-conditioned" classification."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -239,7 +265,7 @@ def test_random_trajectories(dev):
         elif verdict != "ok":
             failed.append((desc, verdict))
     assert not failed, failed
-    assert soft <= 4, soft
+    assert soft == 0, soft
 
 
 def test_random_relations(dev):

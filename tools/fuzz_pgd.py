@@ -154,7 +154,8 @@ def run_case(T, dev, rng, seed):
     desc, procs, batches, steps, mask, kw = draw_case(rng)
     x0 = torch.rand(3, desc["H"], desc["W"], generator=torch.Generator().manual_seed(seed)) * 1.1 - 0.05
     try:
-        worst = T._trajectory(dev, x0, [p[1] for p in procs], [p[2] for p in procs], batches, steps, mask=mask, **kw)
+        worst = T._trajectory(dev, x0, [p[1] for p in procs], [p[2] for p in procs], batches, steps, mask=mask,
+                               max_ill=T.FUZZ_MAX_ILL, **kw)
         return "ok", desc, worst
     except AssertionError as e:
         arg = e.args[0] if e.args else None
