@@ -14,6 +14,7 @@ ADVX_OK = 0
 KIND_LLAVA, KIND_MLLAMA, KIND_PHI3, KIND_QWEN2VL = 0, 1, 2, 3
 MODE_AA_BILINEAR, MODE_BILINEAR, MODE_BICUBIC = 0, 1, 2
 OPT_ADAMW, OPT_SIGN = 0, 1
+PHILOX_STEP_CHAIN = 2     # use_philox of advx_fused_fwd: the one-launch chain's counter addressing
 STAT_SIGMA, STAT_QERR_STD, STAT_QERR_MEAN, STAT_QERR_L1, STAT_IMGFIT, STAT_X_MEAN, STAT_X_STD, STAT_GRAD_NORM = range(8)
 STATS_N = 16
 MAX_STAGES = 2

@@ -247,7 +247,9 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
                       use_crop=use_local_crop, optimizer=optimizer, seed=seed + 7919 * rank,
                       process_group=torch.distributed.group.WORLD if world > 1 else None,
                       noise_on_padding=noise_on_padding, exchange_transport=exchange_transport,
-                      exchange_timeout_s=exchange_timeout_s)
+                      exchange_timeout_s=exchange_timeout_s,
+                      # small batches (the reference's presets: 1-4) take the one-launch chain; it has a float32 boundary only
+                      batch_hint=local_batch if pixel_io == "float32" else None)
     if pixel_io == "model" and engine.mode != "step":
         model_dtype = next(model.parameters()).dtype
         if model_dtype in IO_DTYPES:

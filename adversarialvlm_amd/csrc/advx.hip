@@ -1711,6 +1711,8 @@ static int32_t fused_fwd_impl(advx_plan* p, const float* pp, const float* x0, fl
   REQUIRE(parity == 0 || parity == 1, ADVX_E_BADARG, "advx_fused_fwd: parity must be 0 or 1");
   REQUIRE(advx_fused_supported(p), ADVX_E_UNSUPPORTED, "advx_fused_fwd: plan is not an identity LLaVA plan");
   REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_fused_fwd: batch out of range");
+  REQUIRE(use_philox != ADVX_PHILOX_STEP_CHAIN || io == 0, ADVX_E_UNSUPPORTED,
+          "advx_fused_fwd: the step chain's noise addressing exists for the float32 boundary");
   REQUIRE(aligned16(out) && aligned16(scratch) && aligned16(v_buf) && aligned16(s_buf) && aligned16(x0) &&
               (!unit_noise || aligned16(unit_noise)), ADVX_E_BADARG,
           "advx_fused_fwd: pointers must be 16-byte aligned");
@@ -1731,8 +1733,14 @@ static int32_t fused_fwd_impl(advx_plan* p, const float* pp, const float* x0, fl
     bps = 4;
     slices = batch / 4;
   }
+  int noise = unit_noise ? 1 : (use_philox == ADVX_PHILOX_STEP_CHAIN ? 3 : (use_philox ? 2 : 0));
+  if (noise == 3) {
+    // the one-launch chain's addressing: one generator block = four consecutive batch rows of a pixel
+    REQUIRE(!sched, ADVX_E_UNSUPPORTED, "advx_fused_fwd: the step chain's noise addressing has no scheduled form");
+    bps = 4;
+    slices = (batch + 3) / 4;
+  }
   dim3 grid(gx, slices + 1);  // y == 0: statistics blocks, y >= 1: batch slices
-  int noise = unit_noise ? 1 : (use_philox ? 2 : 0);
 #define ADVX_FF_S(N, T, S)                                                                                       \
   ADVX_LAUNCH_TIMED(PROF_FWD, (k_fused_fwd<N, T, S>), grid, dim3(kBlock), st, (const float*)v_buf, (const float*)s_buf, x0, n, \
                     batch, bps, stats, unit_noise, seed, offset, out, f.hdr, f.img_rows[parity],                  \
@@ -1740,7 +1748,8 @@ static int32_t fused_fwd_impl(advx_plan* p, const float* pp, const float* x0, fl
 #define ADVX_FF(N, T) do { if (sched) ADVX_FF_S(N, T, true); else ADVX_FF_S(N, T, false); } while (0)
 #define ADVX_FF_IO(N) \
   do { if (io == 0) ADVX_FF(N, 0); else if (io == 1) ADVX_FF(N, 1); else ADVX_FF(N, 2); } while (0)
-  if (noise == 0) ADVX_FF_IO(0); else if (noise == 1) ADVX_FF_IO(1); else ADVX_FF_IO(2);
+  if (noise == 0) ADVX_FF_IO(0); else if (noise == 1) ADVX_FF_IO(1); else if (noise == 2) ADVX_FF_IO(2);
+  else ADVX_FF_S(3, 0, false);      // float32 boundary only, like the chain it serves
 #undef ADVX_FF_IO
 #undef ADVX_FF
 #undef ADVX_FF_S

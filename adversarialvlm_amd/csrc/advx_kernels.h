@@ -1221,7 +1221,10 @@ __global__ void __launch_bounds__(kBlock) k_fused_prep(const float* __restrict__
   }
 }
 
-// NOISE: 0 none, 1 unit-noise tensor supplied, 2 in-kernel Philox
+// NOISE: 0 none, 1 unit-noise tensor supplied, 2 in-kernel Philox, 3 in-kernel Philox addressed as k_fused_step_wave
+// addresses it (one block = four consecutive batch rows of ONE pixel; the host launches four rows per thread): the
+// forward the one-launch chain runs on its own - first step, first step after a resume - draws the noise the chain's
+// own emission would have drawn, so a resumed run continues bit for bit
 template <int NOISE, int IO, bool SCHED = false>   // SCHED: step scalars from device memory (graph replay), else arguments
 __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ v_buf, const float* __restrict__ s_buf,
                                                       const float* __restrict__ x0, long long n, int batch,
@@ -1269,6 +1272,21 @@ __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ 
   const float4 v = *reinterpret_cast<const float4*>(v_buf + i0);
   const int b0 = ((int)blockIdx.y - 1) * b_per_slice;
   const int b1 = min(batch, b0 + b_per_slice);
+  if (NOISE == 3) {
+    // b_per_slice == 4 and b0 % 4 == 0 (host): rows b0..b0+3 of pixel i0+k come from ONE block
+    const float4 z0 = philox_normal4_pixel((unsigned long long)i0, (unsigned)(b0 >> 2), offset, seed);
+    const float4 z1 = philox_normal4_pixel((unsigned long long)i0 + 1, (unsigned)(b0 >> 2), offset, seed);
+    const float4 z2 = philox_normal4_pixel((unsigned long long)i0 + 2, (unsigned)(b0 >> 2), offset, seed);
+    const float4 z3 = philox_normal4_pixel((unsigned long long)i0 + 3, (unsigned)(b0 >> 2), offset, seed);
+    const float zr[4][4] = {{z0.x, z1.x, z2.x, z3.x}, {z0.y, z1.y, z2.y, z3.y}, {z0.z, z1.z, z2.z, z3.z}, {z0.w, z1.w, z2.w, z3.w}};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (b0 + k < b1)
+        io_store4<IO>(out, (size_t)(b0 + k) * n + i0, make_float4(v.x + zr[k][0] * sigma, v.y + zr[k][1] * sigma,
+                                                                  v.z + zr[k][2] * sigma, v.w + zr[k][3] * sigma));
+    }
+    return;
+  }
   for (int b = b0; b < b1; ++b) {
     float4 o = v;
     if (NOISE == 1) {

@@ -308,7 +308,8 @@ def io_code(dtype):
 
 
 def fused_fwd(plan, p, x0, epsilon, batch, stats, scratch, s_buf, v_buf, prepared, unit_noise=None, philox=None, out=None,
-              parity=0, out_dtype=torch.float32):
+              parity=0, out_dtype=torch.float32, step_chain_noise=False):
+    """step_chain_noise: address the generator as advx_fused_step does (ADVX_PHILOX_STEP_CHAIN)."""
     _require_cuda(p, x0, stats, scratch, s_buf, v_buf)
     if out is None:
         out = torch.empty((batch, plan.out_numel), dtype=out_dtype, device=p.device)
@@ -316,7 +317,8 @@ def fused_fwd(plan, p, x0, epsilon, batch, stats, scratch, s_buf, v_buf, prepare
         raise L.AdvxError("out must be a contiguous [batch, out_numel] tensor")
     seed, offset = (philox if philox is not None else (0, 0))
     L.check(L.load().advx_fused_fwd_io(plan.handle, L.ptr(p), L.ptr(x0), float(epsilon), int(batch), L.ptr(unit_noise),
-                                       int(philox is not None), int(seed), int(offset), L.ptr(out), io_code(out.dtype),
+                                       (L.PHILOX_STEP_CHAIN if step_chain_noise else 1) if philox is not None else 0,
+                                       int(seed), int(offset), L.ptr(out), io_code(out.dtype),
                                        L.ptr(s_buf), L.ptr(v_buf), int(bool(prepared)), int(parity), L.ptr(stats),
                                        L.ptr(scratch), _stream(p)), "advx_fused_fwd_io")
     return out

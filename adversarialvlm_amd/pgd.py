@@ -33,11 +33,14 @@ from . import dp, ops
 
 
 class PixelPGD:
+    STEP_CHAIN_MAX_BATCH = 16      # fused_mode="auto" with a batch_hint up to this many prompts: the one-launch chain
+
     def __init__(self, x0, plans, epsilon=0.5, lr=1e-2, sigma0=1e-3, mask=None, scheduler_step_size=100,
                  scheduler_gamma=1.0, grad_accum_steps=1, blur_kernel=None, use_crop=False, model_weights=None,
                  optimizer="adamw", cross_mode=False, betas=(0.9, 0.999), adam_eps=1e-8, weight_decay=1e-2, seed=0,
                  process_group=None, allow_fused=True, fused_mode="auto", grad_prescale=None, force_exchange=False,
-                 io_dtype=torch.float32, exchange_transport="auto", noise_on_padding=True, exchange_timeout_s=5.0):
+                 io_dtype=torch.float32, exchange_transport="auto", noise_on_padding=True, exchange_timeout_s=5.0,
+                 batch_hint=None):
         """io_dtype: dtype of the pixel_values handed to the VLM (every chain but `step`).  float32 is
         the reference's own boundary; float16 / bfloat16 emit the tensor already cast to the
         model's dtype (the cast the model's first layer would apply) and let backward_update
@@ -52,7 +55,9 @@ class PixelPGD:
         (no generator work and no traffic for 3/4 resp. 2/7 of the tensor; the tensor returned by
         forward() is then only valid until the next forward()).
         exchange_timeout_s: wall-clock bound of every wait of the peer exchange; a wait that gives up sets
-        a sticky error word (`self.peer.timed_out()`, `dp.check_replicas`) and lets its kernel go on."""
+        a sticky error word (`self.peer.timed_out()`, `dp.check_replicas`) and lets its kernel go on.
+        batch_hint: the prompt batch forward() will be called with, if the caller knows it: fused_mode="auto" then
+        picks the one-launch `step` chain for small batches on a single rank (see STEP_CHAIN_MAX_BATCH)."""
         if not x0.is_cuda:
             raise L.AdvxError("PixelPGD needs x0 on a ROCm device (there is no CPU fallback)")
         if not isinstance(plans, (list, tuple)):
@@ -121,9 +126,13 @@ class PixelPGD:
                 raise L.AdvxError(f"fused_mode='{fused_mode}' needs an identity-resize LLaVA plan without blur / crop / accumulation")
             self.mode = "prepared" if can_prepare else "generic"
         elif fused_mode == "auto":
-            # measured on MI355X (profiles/r01): the two-launch pair is currently the faster
-            # chain; the one-launch step is kept behind fused_mode="step"
-            self.mode = "pair"
+            # measured on MI355X (profiles/r03/small_batch.log, tools/small_batch_bench.py): from 32 prompts up the
+            # two-launch pair is the faster chain (34.3 vs 38.8 us per step at 64); up to 16 prompts a step of the pair
+            # is two launches the host cannot issue faster than 18.7-19.3 us, and the one-launch step runs in
+            # 13.8-16.7 us (0.73-0.89 of it).  The reference's presets run batch 1-4 (attack_clamp_tanh_llava.sh:30-32).
+            # The step chain has a float32 boundary only and cannot host a gradient exchange.
+            small = batch_hint is not None and int(batch_hint) <= self.STEP_CHAIN_MAX_BATCH
+            self.mode = "step" if (small and not self.exchange and io_dtype == torch.float32) else "pair"
         else:
             if fused_mode == "step" and self.exchange:
                 raise L.AdvxError("the one-launch step cannot host the gradient all-reduce: use fused_mode='pair'")
@@ -248,7 +257,7 @@ class PixelPGD:
                 out = ops.fused_fwd(pl, self.p, self.x0, self.eps, B, self.stats, self.fused_scratch,
                                     self.s_bufs[self.s_cur], self.v_buf, self.prepared, unit_noise=unit_noises[0],
                                     philox=ph, parity=self.par if self.mode == "step" else 0,
-                                    out_dtype=self.io_dtype)
+                                    out_dtype=self.io_dtype, step_chain_noise=self.mode == "step")
                 self.prepared = True
                 self.img_rows = self.rows_fwd
                 self._out_next = None

@@ -307,6 +307,11 @@ int64_t advx_update_scratch_floats(int64_t n);
  * for the life of the loop.  advx_fused_flush reduces the pending gradient norm and, with
  * image_too != 0 (only meaningful between a fused_fwd and its fused_bwd), the image statistics. */
 int32_t advx_fused_supported(const advx_plan* plan);
+/* use_philox: 0 = no in-kernel noise, 1 = Philox addressed (float4 column, batch row, offset) like every other chain,
+ * ADVX_PHILOX_STEP_CHAIN = addressed as advx_fused_step addresses it (pixel, group of four batch rows, offset): the
+ * forward the one-launch chain runs on its own - first step, first step after a resume - then draws exactly what the
+ * chain's own emission would have drawn (float32 boundary only). */
+#define ADVX_PHILOX_STEP_CHAIN 2
 int32_t advx_fused_fwd(advx_plan* plan, const float* p, const float* x0, float epsilon, int32_t batch,
                        const float* unit_noise, int32_t use_philox, uint64_t seed, uint64_t offset,
                        float* out, float* s_buf, float* v_buf, int32_t prepared,

@@ -151,19 +151,21 @@ def _kw(tmp, name, iters, **extra):
     return kw
 
 
-@pytest.mark.parametrize("size,mode", [(56, "pair"), (70, "prepared")])
-def test_resume_continues_bit_for_bit(tmp_path, size, mode):
+@pytest.mark.parametrize("size,batch,mode", [(56, 4, "step"), (56, 20, "pair"), (70, 4, "prepared")])
+def test_resume_continues_bit_for_bit(tmp_path, size, batch, mode):
     """optimiser moments, schedule, RNG streams and noise counters are saved, so
-    4 iterations + resume + 3 more equal 7 iterations in one go, bit for bit - in the fused pair
-    (native-size image) and in the prepared chain (70x70 image resized to the model's 56x56)."""
+    4 iterations + resume + 3 more equal 7 iterations in one go, bit for bit - in the one-launch step chain (what
+    `auto` picks for a native-size image and up to 16 prompts), in the fused pair (more prompts) and in the prepared
+    chain (70x70 image resized to the model's 56x56)."""
     from adversarialvlm_amd import attack_model
     tmp = str(tmp_path)
     img = _gray(tmp, size)
-    eng, _ = attack_model.train(**_kw(tmp, "full", 7, img_orig=img, return_engine=True))
+    eng, _ = attack_model.train(**_kw(tmp, "full", 7, img_orig=img, batch_size=batch, return_engine=True))
     assert eng.mode == mode
-    attack_model.train(**_kw(tmp, "part", 4, img_orig=img))
+    attack_model.train(**_kw(tmp, "part", 4, img_orig=img, batch_size=batch))
     # iteration 3 (save_steps=3) wrote state_iter_4.pt: resume from it and run iterations 4..6
-    attack_model.train(**_kw(tmp, "rest", 7, img_orig=img, resume_from=os.path.join(tmp, "part", "state_iter_4.pt")))
+    attack_model.train(**_kw(tmp, "rest", 7, img_orig=img, batch_size=batch,
+                             resume_from=os.path.join(tmp, "part", "state_iter_4.pt")))
     a = np.fromfile(os.path.join(tmp, "full", "optimized_image_iter_final.bin"), dtype=np.float32)
     b = np.fromfile(os.path.join(tmp, "rest", "optimized_image_iter_final.bin"), dtype=np.float32)
     assert a.size == 3 * size * size and np.array_equal(a, b)
