@@ -20,6 +20,7 @@ STATS_N = 16
 MAX_STAGES = 2
 TUNE_GENERIC_KERNELS = 1
 TUNE_FULL_TAP_ROWS = 3
+TUNE_SEPARATE_CROP = 4
 
 
 class AdvxError(RuntimeError):
@@ -76,6 +77,8 @@ SIGNATURES = {
     "advx_emit": (_I32, [_P, _P, _I32, _P, _P, _I32, _U64, _U64, _P, _P, _I64, _P]),
     "advx_emit_ex": (_I32, [_P, _P, _I32, _P, _P, _I32, _U64, _U64, _P, _P, _I64, _I32, _P]),
     "advx_collect": (_I32, [_P, _P, _I32, _P, _I32, _P, _I64, _P]),
+    "advx_crop_composes": (_I32, [_P, _I32, _I32, _P]),
+    "advx_collect_crop": (_I32, [_P, _P, _I32, _P, _I32, _P, _I64, _I32, _I32, _P, _P, _P]),
     "advx_emit_multi": (_I32, [_I32, _P, _P, _P, _P, _P, _I32, _U64, _P, _P, _P, _P, _I32, _P]),
     "advx_collect_multi": (_I32, [_I32, _P, _P, _P, _P, _I32, _P, _P, _P]),
     "advx_forward_multi": (_I32, [_P, _P, _I32, _I32, _F, _I32, _F, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _I32, _U64, _P, _P, _P,

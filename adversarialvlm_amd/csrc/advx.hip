@@ -46,6 +46,7 @@ static int32_t fail(int32_t code, const std::string& msg) {
 static int g_generic_kernels = 0;
 static int g_pair_nt_loads = 0;
 static int g_full_tap_rows = 0;
+static int g_separate_crop = 0;   // ADVX_TUNE_SEPARATE_CROP: never compose a crop window with stage 0 (two launches each way)
 static long long kRows3MinPositions = 250000;   // three channels per thread (k_stage_bwd3, k_crop_bwd_rows3) from here up (measured)
 extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
   if (what == ADVX_TUNE_GENERIC_KERNELS) {
@@ -58,6 +59,10 @@ extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
   }
   if (what == ADVX_TUNE_FULL_TAP_ROWS) {
     g_full_tap_rows = value ? 1 : 0;
+    return ADVX_OK;
+  }
+  if (what == ADVX_TUNE_SEPARATE_CROP) {
+    g_separate_crop = value ? 1 : 0;
     return ADVX_OK;
   }
   return fail(ADVX_E_BADARG, "advx_set_tuning: unknown switch");
@@ -705,8 +710,10 @@ static void launch_stage_fwd(const DStage& D, const float* src, long long src_cs
     mf.n = 1;
     mf.st[0] = D;
     mf.canvas[0] = canvas;
+    TapBuild none;
+    std::memset(&none, 0, sizeof(none));
     hipLaunchKernelGGL(k_stage0_fwd_multi, dim3((D.can_w + kRowBlock - 1) / kRowBlock, D.can_h, 1), dim3(kRowBlock), 0, st, mf, src,
-                       src_cstride, src_rstride, img_partials, img_nblk, n_img, stats, norm_rows, norm_count);
+                       src_cstride, src_rstride, img_partials, img_nblk, n_img, stats, norm_rows, norm_count, none, none, 0);
     return;
   }
   if (img_nblk > 0)
@@ -984,7 +991,8 @@ struct PendingImageStats {   // what an advx_image_fwd left for the launches aft
 static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* argument, const int32_t* batches,
                                const float* sigma_dev, const float* const* unit_noises, int32_t use_philox, uint64_t seed,
                                const uint64_t* offsets, void* const* outs, float* const* wss, const int64_t* ws_floats,
-                               int32_t pad_mode, const PendingImageStats& pend, void* stream) {
+                               int32_t pad_mode, const PendingImageStats& pend, void* stream,
+                               const DStage* stage0_override = nullptr) {
   int32_t rc = check_multi(n, plans, batches, wss, ws_floats, "advx_emit_multi");
   if (rc) return rc;
   REQUIRE(argument && outs && offsets, ADVX_E_BADARG, "advx_emit_multi: null argument");
@@ -1005,7 +1013,8 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
     mf.st[i] = p->dstage[0];
     mf.canvas[i] = wss[i] + p->dplan.canvas_off[0];
   }
-  const DStage& D0 = plans[0]->dstage[0];
+  if (stage0_override) mf.st[0] = *stage0_override;      // crop window o stage 0 (n == 1): `argument` is the image itself
+  const DStage& D0 = mf.st[0];
   int max_h = 0, max_w = 0;
   for (int i = 0; i < n; ++i) {
     max_h = std::max(max_h, mf.st[i].can_h);
@@ -1013,9 +1022,29 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
   }
   // one window size for plans of different geometry loses to the run-time loops (20.7 vs 19.1 us); what pays is three
   // channels per thread on a (column chunk, row, plan) grid (11.5 us)
-  hipLaunchKernelGGL(k_stage0_fwd_multi, dim3((max_w + kRowBlock - 1) / kRowBlock, max_h, n), dim3(kRowBlock), 0, st, mf, argument,
-                     (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats,
-                     (const double*)nullptr, 0);
+  // composed crop: the transposed rows of the composed tables ride in THIS launch (its z == 0 layer), not in the emit
+  TapRider rider = pend.later;
+  {
+    const int gx0 = (max_w + kRowBlock - 1) / kRowBlock;
+    int tr_blocks = 0;
+    if (stage0_override && rider.blocks > 0) {
+      const int rows = std::max(rider.t[0].row_hi - rider.t[0].row_lo, rider.t[1].row_hi - rider.t[1].row_lo);
+      tr_blocks = (rows + kRowBlock - 1) / kRowBlock;
+      if ((long long)gx0 * max_h < 2LL * tr_blocks) tr_blocks = 0;       // no room in one layer: the emit's fallback below
+    }
+    if (tr_blocks > 0) {
+      hipLaunchKernelGGL(k_stage0_fwd_multi, dim3(gx0, max_h, n + 1), dim3(kRowBlock), 0, st, mf, argument,
+                         (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats,
+                         (const double*)nullptr, 0, rider.t[0], rider.t[1], tr_blocks);
+      rider = no_rider();
+    } else {
+      TapBuild none;
+      std::memset(&none, 0, sizeof(none));
+      hipLaunchKernelGGL(k_stage0_fwd_multi, dim3(gx0, max_h, n), dim3(kRowBlock), 0, st, mf, argument,
+                         (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats,
+                         (const double*)nullptr, 0, none, none, 0);
+    }
+  }
   LAUNCH_CHECK();
   // the stages above stage 0 (Phi-3.5's global view), then the emits of all plans
   for (int i = 0; i < n; ++i) {
@@ -1062,8 +1091,8 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
   }
   // the crop window's transposed tables ride in the (first) emit launch when its grid has the blocks, else they get
   // a launch of their own
-  TapRider rider = pend.later;
-  if (rider.blocks > 0 && 2 * rider.blocks > ((n > 1 && same_noise && !g_generic_kernels) ? max_gx : me.a[0].gx)) {
+  // (composed rows never ride in an emit: k_emit's rider builds the window's own tables only)
+  if (rider.blocks > 0 && (stage0_override || 2 * rider.blocks > ((n > 1 && same_noise && !g_generic_kernels) ? max_gx : me.a[0].gx))) {
     const int rows = std::max(rider.t[0].row_hi, rider.t[1].row_hi);
     hipLaunchKernelGGL(k_build_taps, dim3((rows + kBlock - 1) / kBlock, 2), dim3(kBlock), 0, st, rider.t[0], rider.t[1]);
     LAUNCH_CHECK();
@@ -1204,7 +1233,15 @@ constexpr int kMaxCropTStride = 40;
 
 long long blur_tiles(int H, int W) { return (long long)((H + kBlurTile - 1) / kBlurTile) * ((W + kBlurTile - 1) / kBlurTile) * 3; }
 long long partial_floats(int H, int W) { return 2 * kStatSlots * std::max<long long>(kMaxStatBlocks, blur_tiles(H, W)); }
-long long crop_table_floats(int H, int W) { return 2LL * (H + W) * (2 + 8) + 2LL * (H + W) * (2 + kMaxCropTStride) + 512; }
+constexpr int kMaxComposedStride = 16;        // forward taps per axis of a composed (crop window o plan) table
+constexpr int kMaxComposedTStride = 16;       // transposed ones: the backward gathers T x T canvas elements per pixel
+// the crop window's own tables, or - never both in one step - the composed ones: forward rows of a canvas of up to twice
+// the image's size per axis, one transposed row per image row
+long long crop_table_floats(int H, int W) {
+  const long long own = 2LL * (H + W) * (2 + 8) + 2LL * (H + W) * (2 + kMaxCropTStride);
+  const long long composed = 2LL * (H + W) * (2 + kMaxComposedStride) + (long long)(H + W) * (2 + kMaxComposedTStride);
+  return std::max(own, composed) + 1024;
+}
 
 struct CropTables {
   DStage st;
@@ -1220,6 +1257,7 @@ struct CropCache {
   hipStream_t stream = nullptr;
 };
 thread_local CropCache g_crop_cache;
+void g_compose_cache_invalidate();
 
 // carve the crop's tap tables out of scratch and launch their device-side construction
 // `deferred`: do not launch k_build_taps; hand the two descriptors to the caller, who builds the
@@ -1245,6 +1283,8 @@ int32_t build_crop_stage(int H, int W, const int32_t* crop, Bump& b, hipStream_t
     a[ax].mode = ADVX_MODE_AA_BILINEAR; a[ax].in_size = ins[ax]; a[ax].out_size = outs[ax];
     a[ax].stride = strides[ax]; a[ax].tstride = tstrides[ax];
     a[ax].row_lo = 0; a[ax].row_hi = outs[ax] + ins[ax];
+    a[ax].compose = 0; a[ax].mid_size = 0; a[ax].mode_b = 0; a[ax].offset = 0;
+    a[ax].b_start = nullptr; a[ax].b_count = nullptr; a[ax].b_w = nullptr; a[ax].b_stride = 0;
     a[ax].start = reinterpret_cast<int*>(b.take(outs[ax]));
     a[ax].count = reinterpret_cast<int*>(b.take(outs[ax]));
     a[ax].w = b.take((long long)outs[ax] * strides[ax]);
@@ -1268,6 +1308,7 @@ int32_t build_crop_stage(int H, int W, const int32_t* crop, Bump& b, hipStream_t
     }
     cc.where = where; cc.H = H; cc.W = W; cc.stream = stq;
     cc.crop[0] = ci; cc.crop[1] = cj; cc.crop[2] = ch; cc.crop[3] = cw;
+    g_compose_cache_invalidate();          // the same scratch now holds other tables
   }
   DStage D;
   std::memset(&D, 0, sizeof(D));
@@ -1278,9 +1319,149 @@ int32_t build_crop_stage(int H, int W, const int32_t* crop, Bump& b, hipStream_t
   *out = D;
   return ADVX_OK;
 }
+// ---- crop window o stage 0 as ONE table per axis (k_stage0_fwd_multi / k_stage_bwd* then go image <-> canvas directly)
+struct ComposeCache {
+  const float* where = nullptr;
+  const advx_plan* plan = nullptr;
+  int H = 0, W = 0, crop[4] = {0, 0, 0, 0};
+  hipStream_t stream = nullptr;
+};
+thread_local ComposeCache g_compose_cache;
+void g_compose_cache_invalidate() { g_compose_cache = ComposeCache(); }
+
+struct ComposeGeom {
+  int s[2], ts[2];      // forward / transposed row lengths per axis
+};
+// Whether the plan's stage 0 composes with this window, and the row lengths if it does.  Bounds, not exact maxima:
+// forward  - a canvas row reads cB intermediate rows, each reading cA window rows that advance by in/mid <= 1 per row;
+// transposed - a window row is read by <= tA intermediate rows, which spread over tA*out/mid canvas rows plus B's own reach.
+bool compose_geom(const advx_plan* p, int H, int W, const int32_t* crop, ComposeGeom* g) {
+  if (g_generic_kernels || g_separate_crop || !p || !crop || p->st[0].info.src != 0) return false;
+  const advx_stage_info& D = p->st[0].info;       // host geometry: valid before the plan is uploaded
+  if (D.src_h != H || D.src_w != W) return false;
+  for (int k = 1; k < p->info.n_stage; ++k)
+    if (p->st[k].info.src == 0) return false;      // a later stage that reads the image would need the resized window
+  const int ch = crop[2], cw = crop[3];
+  if (!(ch > 0 && cw > 0 && crop[0] >= 0 && crop[1] >= 0 && crop[0] + ch <= H && crop[1] + cw <= W)) return false;
+  if (D.res_h + D.res_w > 2 * (H + W)) return false;                 // the tables' room (crop_table_floats)
+  const int ins[2] = {ch, cw}, mids[2] = {H, W}, outs[2] = {D.res_h, D.res_w};
+  auto tbound = [](int mode, int in_size, int out_size) {
+    if (mode != ADVX_MODE_AA_BILINEAR) return (int)std::ceil(4.0 * out_size / in_size) + 3;       // 2- and 4-tap kernels
+    float scale = tap_scale(in_size, out_size);
+    float support = (scale >= 1.0f) ? scale : 1.0f;
+    return (int)std::ceil(2.0 * support / scale) + 2;
+  };
+  for (int ax = 0; ax < 2; ++ax) {
+    const int sA = tap_stride(ADVX_MODE_AA_BILINEAR, ins[ax], mids[ax]), sB = tap_stride(D.mode, mids[ax], outs[ax]);
+    if (sA > 8 || sB > 8) return false;
+    if (sA > 3) return false;                                           // the window never exceeds the image: A up-samples
+    g->s[ax] = sA + (int)std::ceil((double)(sB - 1) * ins[ax] / mids[ax]) + 1;
+    const int tA = std::min(mids[ax], tbound(ADVX_MODE_AA_BILINEAR, ins[ax], mids[ax]));
+    const int tB = std::min(outs[ax], tbound(D.mode, mids[ax], outs[ax]));
+    g->ts[ax] = (int)std::ceil((double)tA * outs[ax] / mids[ax]) + tB + 1;
+    if (g->s[ax] > kMaxComposedStride || g->ts[ax] > kMaxComposedTStride) return false;
+  }
+  return true;
+}
+
+// carve the composed tables out of scratch (the crop tables' place) and launch - or hand over, `deferred` - their construction
+int32_t build_composed_stage(const advx_plan* p, int H, int W, const int32_t* crop, Bump& b, hipStream_t stq, DStage* out,
+                             bool may_reuse = false, TapBuild* deferred = nullptr) {
+  ComposeGeom g;
+  REQUIRE(compose_geom(p, H, W, crop, &g), ADVX_E_UNSUPPORTED, "this crop window does not compose with the plan's stage 0");
+  const DStage& D0 = p->dstage[0];
+  const float* where = b.base + b.used;
+  const int ins[2] = {crop[2], crop[3]}, mids[2] = {H, W}, outs[2] = {D0.res_h, D0.res_w}, offs[2] = {crop[0], crop[1]};
+  TapBuild a[2];
+  DevTaps f[2], t[2];
+  for (int ax = 0; ax < 2; ++ax) {
+    std::memset(&a[ax], 0, sizeof(TapBuild));
+    a[ax].compose = 1; a[ax].mode = ADVX_MODE_AA_BILINEAR; a[ax].mode_b = D0.mode;
+    a[ax].in_size = ins[ax]; a[ax].mid_size = mids[ax]; a[ax].out_size = outs[ax]; a[ax].offset = offs[ax];
+    a[ax].stride = g.s[ax]; a[ax].tstride = g.ts[ax];
+    a[ax].row_lo = 0; a[ax].row_hi = outs[ax] + mids[ax];
+    a[ax].start = reinterpret_cast<int*>(b.take(outs[ax]));
+    a[ax].count = reinterpret_cast<int*>(b.take(outs[ax]));
+    a[ax].w = b.take((long long)outs[ax] * g.s[ax]);
+    a[ax].tstart = reinterpret_cast<int*>(b.take(mids[ax]));
+    a[ax].tcount = reinterpret_cast<int*>(b.take(mids[ax]));
+    a[ax].tw = b.take((long long)mids[ax] * g.ts[ax]);
+    const DevTaps& B = (ax == 0) ? D0.th : D0.tw;          // the plan's own forward rows, on the device since its upload
+    a[ax].b_start = B.start; a[ax].b_count = B.count; a[ax].b_w = B.w; a[ax].b_stride = B.stride;
+    f[ax] = DevTaps{outs[ax], g.s[ax], a[ax].start, a[ax].count, a[ax].w};
+    t[ax] = DevTaps{mids[ax], g.ts[ax], a[ax].tstart, a[ax].tcount, a[ax].tw};
+  }
+  ComposeCache& cc = g_compose_cache;
+  const bool same = may_reuse && cc.where == where && cc.plan == p && cc.H == H && cc.W == W && cc.stream == stq &&
+                    cc.crop[0] == crop[0] && cc.crop[1] == crop[1] && cc.crop[2] == crop[2] && cc.crop[3] == crop[3];
+  if (!same) {
+    if (deferred) {
+      deferred[0] = a[0];
+      deferred[1] = a[1];
+    } else {
+      // the transposed rows read the finished forward table: two launches
+      TapBuild fw[2] = {a[0], a[1]}, tr[2] = {a[0], a[1]};
+      for (int ax = 0; ax < 2; ++ax) {
+        fw[ax].row_hi = outs[ax];
+        tr[ax].row_lo = outs[ax];
+      }
+      hipLaunchKernelGGL(k_build_taps, dim3((std::max(outs[0], outs[1]) + kBlock - 1) / kBlock, 2), dim3(kBlock), 0, stq, fw[0], fw[1]);
+      LAUNCH_CHECK();
+      const int rows = std::max(a[0].row_hi, a[1].row_hi);
+      hipLaunchKernelGGL(k_build_taps, dim3((rows + kBlock - 1) / kBlock, 2), dim3(kBlock), 0, stq, tr[0], tr[1]);
+      LAUNCH_CHECK();
+    }
+    cc.where = where; cc.plan = p; cc.H = H; cc.W = W; cc.stream = stq;
+    for (int k = 0; k < 4; ++k) cc.crop[k] = crop[k];
+    g_crop_cache = CropCache();            // the same scratch now holds other tables
+  }
+  DStage D = D0;                           // canvas geometry, padding, normalisation, nesting: the plan's
+  D.src_h = H; D.src_w = W;                // the source is the whole image; rows outside the window have no taps
+  D.th = f[0]; D.tw = f[1]; D.tth = t[0]; D.ttw = t[1];
+  *out = D;
+  return ADVX_OK;
+}
 }  // namespace
 
 extern "C" int64_t advx_crop_scratch_floats(int32_t H, int32_t W) { return crop_table_floats(H, W); }
+
+extern "C" int32_t advx_crop_composes(const advx_plan* p, int32_t H, int32_t W, const int32_t* crop) {
+  ComposeGeom g;
+  return compose_geom(p, H, W, crop, &g) ? 1 : 0;
+}
+
+// Backward of a step whose advx_forward_multi composed the crop window with stage 0: batch reduction, the upper stages,
+// then ONE transposed gather canvas -> IMAGE through the composed table (exact zeros outside the window).  grad_s is the
+// gradient w.r.t. s = x0 + x: hand it to advx_image_bwd* WITHOUT a crop window.
+extern "C" int32_t advx_collect_crop(advx_plan* p, const void* grad_out, int32_t batch, float* grad_s, int32_t accumulate,
+                                     float* ws, int64_t ws_floats, int32_t H, int32_t W, const int32_t* crop,
+                                     float* image_scratch, void* stream) {
+  REQUIRE(p && grad_out && grad_s && ws && crop && image_scratch, ADVX_E_BADARG, "advx_collect_crop: null argument");
+  REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_collect_crop: batch out of range");
+  REQUIRE(ws_floats >= p->info.workspace_floats, ADVX_E_SHAPE, "advx_collect_crop: workspace too small");
+  int32_t rc = advx_plan_upload(p, stream);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  Bump b{image_scratch};
+  (void)b.take(partial_floats(H, W));          // the tables sit behind the statistics partials, as in advx_forward_multi
+  DStage D;
+  rc = build_composed_stage(p, H, W, crop, b, st, &D, /*may_reuse=*/true);     // the forward's tables, if still there
+  if (rc) return rc;
+  rc = reduce_to_canvas(p, grad_out, batch, ws, st);
+  if (rc) return rc;
+  for (int k = p->info.n_stage - 1; k >= 1; --k) {
+    const DStage& Dk = p->dstage[k];
+    const advx_stage_info& sk = p->st[k].info;
+    REQUIRE(sk.src >= 1, ADVX_E_UNSUPPORTED, "advx_collect_crop: only stage 0 may read the image");
+    int acc = 0;
+    float* gsrc = dgrad_target(p, sk.src - 1, ws, &acc);
+    launch_stage_bwd(Dk, stage_grad(p, k, ws), gsrc, (long long)Dk.src_h * Dk.src_w, Dk.src_w, acc, st);
+    LAUNCH_CHECK();
+  }
+  launch_stage_bwd(D, stage_grad(p, 0, ws), grad_s, (long long)H * W, W, accumulate, st);
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
 
 extern "C" int64_t advx_image_scratch_floats(int32_t H, int32_t W, int32_t blur_k) {
   if (H <= 0 || W <= 0) return 0;
@@ -1299,13 +1480,18 @@ static int32_t check_blur(int H, int W, int k, float sigma) {
 
 // `defer`: without a crop window, leave the one-block reduction of the statistics to the caller's next
 // launch and describe it in *defer (with a crop it rides in the window's resize anyway)
+// `compose` (with `defer`): the crop window is not resized into `argument` here; the tables of window o stage 0 of that
+// plan are built instead (*composed), the statistics are left to the caller's next launch like without a crop, and the
+// caller resamples the IMAGE s with *composed.
 static int32_t image_fwd_impl(const float* p, const float* x0, int32_t H, int32_t W, float eps, int32_t blur_k,
                               float blur_sigma, const int32_t* crop, float* s, float* argument, float* stats,
-                              float* scratch, PendingImageStats* defer, void* stream) {
+                              float* scratch, PendingImageStats* defer, void* stream, const advx_plan* compose = nullptr,
+                              DStage* composed = nullptr) {
   REQUIRE(p && x0 && s && stats && scratch, ADVX_E_BADARG, "advx_image_fwd: null argument");
   REQUIRE(H > 0 && W > 0 && H <= 16384 && W <= 16384, ADVX_E_SHAPE, "advx_image_fwd: bad image size");
-  REQUIRE(!crop || argument, ADVX_E_BADARG, "advx_image_fwd: crop needs an argument buffer");
+  REQUIRE(!crop || argument || compose, ADVX_E_BADARG, "advx_image_fwd: crop needs an argument buffer");
   REQUIRE(!crop || argument != s, ADVX_E_BADARG, "advx_image_fwd: with a crop, argument must not alias s");
+  REQUIRE(!compose || (crop && defer && composed), ADVX_E_BADARG, "advx_image_fwd: composing needs a crop window and a following emit");
   hipStream_t st = (hipStream_t)stream;
   const long long n = 3LL * H * W;
   Bump b{scratch};
@@ -1314,9 +1500,10 @@ static int32_t image_fwd_impl(const float* p, const float* x0, int32_t H, int32_
   TapBuild taps[2];
   int tap_blocks = 0;          // per axis; > 0: the first launch below also builds the crop window's tap tables
   if (crop) {
-    int32_t rc = build_crop_stage(H, W, crop, b, st, &crop_stage, false, taps);
+    int32_t rc = compose ? build_composed_stage(compose, H, W, crop, b, st, composed, false, taps)
+                         : build_crop_stage(H, W, crop, b, st, &crop_stage, false, taps);
     if (rc) return rc;
-    tap_blocks = (std::max(H + crop[2], W + crop[3]) + kBlock - 1) / kBlock;
+    tap_blocks = (std::max(taps[0].row_hi, taps[1].row_hi) + kBlock - 1) / kBlock;
     if (defer && !g_generic_kernels) {
       // the forward needs only the forward tables; a transposed row costs two binary searches and several rows of
       // weights and made the launch it rode in 3 us longer.  Those rows go to the caller's emit (17 us: hidden there).
@@ -1325,8 +1512,10 @@ static int32_t image_fwd_impl(const float* p, const float* x0, int32_t H, int32_
         defer->later.t[ax].row_lo = taps[ax].out_size;
         taps[ax].row_hi = taps[ax].out_size;
       }
-      defer->later.blocks = (std::max(crop[2], crop[3]) + kBlock - 1) / kBlock;
-      tap_blocks = (std::max(H, W) + kBlock - 1) / kBlock;
+      // transposed rows: one per window row (own tables) or per image row (composed); forward rows: out_size
+      defer->later.blocks = (std::max(defer->later.t[0].row_hi - defer->later.t[0].row_lo,
+                                      defer->later.t[1].row_hi - defer->later.t[1].row_lo) + kBlock - 1) / kBlock;
+      tap_blocks = (std::max(taps[0].out_size, taps[1].out_size) + kBlock - 1) / kBlock;
     }
   }
   int nblk;
@@ -1376,7 +1565,7 @@ static int32_t image_fwd_impl(const float* p, const float* x0, int32_t H, int32_
       hipLaunchKernelGGL(k_prep<true>, dim3(nblk), dim3(kBlock), 0, st, p, x0, eps, n, s, partials);
     LAUNCH_CHECK();
   }
-  if (crop) {
+  if (crop && !compose) {
     // block 0 of the window's resize reduces the statistics partials: no one-block launch in between
     const float* src = s + (size_t)crop[0] * W + crop[1];
     launch_stage_fwd(crop_stage, src, (long long)H * W, W, argument, (const double*)partials, nblk, n, nullptr, 0, stats, st);
@@ -1392,7 +1581,7 @@ static int32_t image_fwd_impl(const float* p, const float* x0, int32_t H, int32_
     hipLaunchKernelGGL(k_finalize_image, dim3(1), dim3(kBlock), 0, st, partials, nblk, n, stats);
     LAUNCH_CHECK();
   }
-  if (argument && argument != s) {
+  if (argument && argument != s && !compose) {
     HIP_TRY(hipMemcpyAsync(argument, s, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
   }
   return ADVX_OK;
@@ -1414,11 +1603,22 @@ extern "C" int32_t advx_forward_multi(const float* p, const float* x0, int32_t H
                                       const uint64_t* offsets, void* const* outs, float* const* wss,
                                       const int64_t* ws_floats, int32_t pad_mode, void* stream) {
   PendingImageStats pend;
-  int32_t rc = image_fwd_impl(p, x0, H, W, eps, blur_k, blur_sigma, crop, s, argument, stats, image_scratch, &pend, stream);
+  // one plan and a crop window whose resize composes with the plan's stage 0: the window is never resized into `argument`
+  // (advx_crop_composes; the backward of such a step is advx_collect_crop)
+  ComposeGeom cg_unused;
+  const bool compose = (n == 1 && crop && plans && plans[0] && compose_geom(plans[0], H, W, crop, &cg_unused));
+  DStage composed;
+  int32_t rc;
+  if (compose) {
+    rc = advx_plan_upload(plans[0], stream);
+    if (rc) return rc;
+  }
+  rc = image_fwd_impl(p, x0, H, W, eps, blur_k, blur_sigma, crop, s, argument, stats, image_scratch, &pend, stream,
+                      compose ? plans[0] : nullptr, compose ? &composed : nullptr);
   if (rc) return rc;
-  const float* arg = (crop || (argument && argument != s)) ? argument : s;
+  const float* arg = compose ? s : ((crop || (argument && argument != s)) ? argument : s);
   rc = emit_multi_impl(n, plans, arg, batches, stats + ADVX_STAT_SIGMA, unit_noises, use_philox, seed, offsets, outs, wss,
-                       ws_floats, pad_mode, pend, stream);
+                       ws_floats, pad_mode, pend, stream, compose ? &composed : nullptr);
   if (rc && pend.nblk > 0) {
     // the emit was refused after the image kernels ran: do not leave the statistics unreduced
     hipLaunchKernelGGL(k_finalize_image, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, pend.partials, pend.nblk, pend.n_img,

@@ -68,7 +68,9 @@ __global__ void __launch_bounds__(kBlock) k_blur_fwd_r(const float* __restrict__
     const int tb = (int)(blockIdx.y * gridDim.x + blockIdx.x);
     if (tb < 2 * tap_blocks) {
       const int axis = tb / tap_blocks;
-      build_taps_row(axis == 0 ? taps0 : taps1, (tb - axis * tap_blocks) * (int)blockDim.x + (int)threadIdx.x);
+      // a branch per axis, not a select between the two argument structs: selecting makes the compiler copy both to scratch
+      if (axis == 0) build_taps_row_c(taps0, tb * (int)blockDim.x + (int)threadIdx.x);
+      else build_taps_row_c(taps1, (tb - tap_blocks) * (int)blockDim.x + (int)threadIdx.x);
     }
     return;
   }

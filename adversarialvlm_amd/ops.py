@@ -21,6 +21,17 @@ class generic_kernels:
         L.check(L.load().advx_set_tuning(L.TUNE_GENERIC_KERNELS, 0), "advx_set_tuning")
 
 
+class separate_crop:
+    """Context manager (tests, measurements): a crop window is never composed with the plan's stage 0 - the window is resized
+    into `argument` and the plan resamples that (two launches each way, bit-identical to the unfused kernels)."""
+
+    def __enter__(self):
+        L.check(L.load().advx_set_tuning(L.TUNE_SEPARATE_CROP, 1), "advx_set_tuning")
+
+    def __exit__(self, *exc):
+        L.check(L.load().advx_set_tuning(L.TUNE_SEPARATE_CROP, 0), "advx_set_tuning")
+
+
 class full_tap_rows:
     """Context manager (tests): plans UPLOADED inside keep ATen's full tap rows on the device instead of the rows with the
     zero-weight end taps dropped.  Results must be bit-identical."""
@@ -111,6 +122,31 @@ def collect(plan, grad_out, batch, grad_argument=None, accumulate=False, workspa
     L.check(L.load().advx_collect(plan.handle, L.ptr(grad_out), int(batch), L.ptr(grad_argument), int(accumulate),
                                   L.ptr(workspace), int(workspace.numel()), _stream(grad_out)), "advx_collect")
     return grad_argument
+
+
+def crop_composes(plan, H, W, crop):
+    """True when advx_forward_multi applies this window's resize and the plan's stage-0 resize as ONE table per axis
+    (one plan, include/advx.h "Composed crop"); the backward of such a step is collect_crop + image_bwd* without a window."""
+    if crop is None:
+        return False
+    _keep, cp = _crop_arg(crop)
+    return bool(L.load().advx_crop_composes(plan.handle, int(H), int(W), cp))
+
+
+def collect_crop(plan, grad_out, batch, crop, image_scratch, grad_s, accumulate=False, workspace=None):
+    """Backward of a forward_multi that composed: grad_out [batch, out_numel] -> gradient w.r.t. the IMAGE s [3,H,W]
+    (exact zeros outside the window)."""
+    _require_cuda(grad_out, grad_s, image_scratch)
+    grad_out = _boundary(plan, grad_out, "grad_out")
+    if grad_out.numel() != batch * plan.out_numel:
+        raise L.AdvxError("grad_out has the wrong number of elements")
+    if workspace is None:
+        workspace = torch.empty(plan.workspace_floats, dtype=torch.float32, device=grad_out.device)
+    _keep, cp = _crop_arg(crop)
+    L.check(L.load().advx_collect_crop(plan.handle, L.ptr(grad_out), int(batch), L.ptr(grad_s), int(accumulate), L.ptr(workspace),
+                                       int(workspace.numel()), int(plan.in_h), int(plan.in_w), cp,
+                                       L.ptr(image_scratch), _stream(grad_out)), "advx_collect_crop")
+    return grad_s
 
 
 def _ptr_array(tensors):

@@ -306,7 +306,10 @@ class PixelPGD:
                                    unit_noises=unit_noises if given else None, philox=ph, workspaces=self.workspaces,
                                    outs=bufs, keep_padding=keep)
         outs = [o.view((B * pl.out_shape[0],) + pl.out_shape[1:]) for o, pl, B in zip(res, self.plans, batches)]
-        self._last = dict(batches=list(batches), blur=blur, crop=crop)
+        # one plan and a window that composes with its stage 0: the library applied both resizes as one table
+        # (include/advx.h "Composed crop") - the backward then goes canvas -> image in one gather
+        composed = bool(crop is not None and n == 1 and ops.crop_composes(self.plans[0], self.H, self.W, crop))
+        self._last = dict(batches=list(batches), blur=blur, crop=crop, composed=composed)
         return outs
 
     # ----------------------------------------------------------------- backward
@@ -385,6 +388,11 @@ class PixelPGD:
                 # batch reductions, then every plan's transposed resize summed in one launch
                 ops.collect_multi(self.plans, [g.reshape(B, pl.out_numel) for pl, g, B in zip(self.plans, grads, st["batches"])],
                                   st["batches"], grad_argument=self.garg, workspaces=self.workspaces)
+            elif st.get("composed"):
+                pl, g, B = self.plans[0], grads[0], st["batches"][0]
+                ops.collect_crop(pl, g.reshape(B, pl.out_numel), B, st["crop"], self.img_scratch, grad_s=self.garg,
+                                 workspace=self.workspaces[0])
+                st = dict(st, crop=None)            # self.garg is the gradient w.r.t. the image already
             else:
                 pl, g, B = self.plans[0], grads[0], st["batches"][0]
                 ops.collect(pl, g.reshape(B, pl.out_numel), B, grad_argument=self.garg, workspace=self.workspaces[0])

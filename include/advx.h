@@ -120,6 +120,9 @@ const char* advx_last_error(void);
  * is what the tests use it for.  Process-wide, not thread-safe. */
 #define ADVX_TUNE_GENERIC_KERNELS 1
 #define ADVX_TUNE_PAIR_NT_LOADS 2   /* advx_fused_bwd reads grad_out with non-temporal loads (same results) */
+#define ADVX_TUNE_SEPARATE_CROP 4   /* never compose a crop window with a plan's stage 0 (advx_forward_multi): the window is resized
+                                     * into `argument` and the plan resamples that, two launches each way, bit-identical to the
+                                     * unfused kernels */
 #define ADVX_TUNE_FULL_TAP_ROWS 3   /* plans uploaded from now on keep ATen's full tap rows on the device; by default the
                                      * device copies drop the zero-weight taps at the ends of a row (same results) */
 int32_t advx_set_tuning(int32_t what, int32_t value);
@@ -220,7 +223,19 @@ int32_t advx_collect_multi(int32_t n, advx_plan* const* plans, const void* const
  * statistics of the image are reduced by one block of the plans' resize launch instead of a launch of
  * their own; with one, the window's transposed tap tables (read only by advx_image_bwd*) are built by the first
  * workgroups of the emit launch instead of the step's first image kernel.  The emits read their sigma from
- * stats[ADVX_STAT_SIGMA].  Arguments as for the two calls. */
+ * stats[ADVX_STAT_SIGMA].  Arguments as for the two calls.
+ *
+ * Composed crop.  With ONE plan whose stage 0 reads the image and a window for which advx_crop_composes() is 1, the
+ * window's resize back to H x W (attack_model.py:309-310) and the plan's own resize (process(), :314) are applied as
+ * ONE table per axis, w_C[y][j] = sum_k w_plan[y][k] * w_window[k][j] (built on the device, per step): one gather
+ * image -> canvas instead of two launches around an image-sized intermediate.  `argument` is then NOT written, and
+ * the backward of that step is advx_collect_crop (one transposed gather canvas -> image) followed by
+ * advx_image_bwd* WITHOUT a crop window.  The composed map drops the float32 rounding of the intermediate image: held
+ * to the reference at 1e-4 (tests), not bit-identical to the two-launch form; ADVX_TUNE_SEPARATE_CROP (or ADVX_TUNE_GENERIC_KERNELS) switches it off. */
+int32_t advx_crop_composes(const advx_plan* plan, int32_t H, int32_t W, const int32_t* crop_ijhw);
+int32_t advx_collect_crop(advx_plan* plan, const void* grad_out, int32_t batch, float* grad_s, int32_t accumulate,
+                          float* workspace, int64_t workspace_floats, int32_t H, int32_t W, const int32_t* crop_ijhw,
+                          float* image_scratch, void* stream);
 int32_t advx_forward_multi(const float* p, const float* x0, int32_t H, int32_t W, float epsilon,
                            int32_t blur_kernel, float blur_sigma, const int32_t* crop_ijhw, float* s,
                            float* argument, float* stats, float* image_scratch, int32_t n,

@@ -54,7 +54,10 @@ def _run(H, W, k, crop, steps, generic, accumulate=1, optimizer="adamw", masked=
     if generic:
         with ops.generic_kernels():
             return go()
-    return go()
+    # the merged kernels with the crop window resized on its own (two launches each way): what is bit-identical to the
+    # general kernels; the composed window o plan table is compared with this form in tests/test_gpu_compose.py
+    with ops.separate_crop():
+        return go()
 
 
 @pytest.mark.parametrize("H,W,k", [(64, 64, 5), (40, 52, 9), (20, 24, 5), (97, 130, 9), (70, 33, 15), (130, 45, 3)])

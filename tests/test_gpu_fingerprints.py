@@ -4,7 +4,13 @@ tests/golden/chain_bits.json holds sha256 digests of everything sixteen chain co
 on seeded inputs (pixel_values, p, m, v, masked gradient, image), recorded in round 2 BEFORE the data-layout and
 launch-structure changes of that round (canvas-order gradient sums, merged image backward, multi-plan launches, windowed
 resizes).  Restructured kernels keep every element's operations and their order, so the digests must not move; a change that
-means to alter the arithmetic re-records them (`python tools/regress_bits.py write tests/golden/chain_bits.json`) and says so."""
+means to alter the arithmetic re-records them (`python tools/regress_bits.py write tests/golden/chain_bits.json`) and says so.
+
+Round 3 re-recorded TWO of the sixteen - llava_generic_blur_crop and llava_generic_crop_accum - and says so here: a crop window
+over one plan is now applied together with the plan's stage-0 resize as one composed table per axis (include/advx.h "Composed
+crop"), which drops the float32 rounding of the intermediate image and is meant to change those bits (agreement with the
+two-launch form to 2e-6 and with the oracle under the 1e-4 bars: tests/test_gpu_compose.py; with ops.separate_crop() the old
+digests still come out).  The other fourteen digests are the round-2 ones, unchanged (profiles/r03/regress_check.log)."""
 import json
 import os
 import sys
