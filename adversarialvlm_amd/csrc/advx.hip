@@ -1460,6 +1460,9 @@ extern "C" int32_t advx_collect_crop(advx_plan* p, const void* grad_out, int32_t
   }
   launch_stage_bwd(D, stage_grad(p, 0, ws), grad_s, (long long)H * W, W, accumulate, st);
   LAUNCH_CHECK();
+  // the tables have served their step: the image-level backward that follows carves its buffers over them, so a later call
+  // with the same window must rebuild, not trust the cache
+  g_compose_cache_invalidate();
   return ADVX_OK;
 }
 

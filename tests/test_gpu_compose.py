@@ -106,3 +106,31 @@ def test_composed_forward_and_backward_are_adjoint():
     rhs = float((x.double() * gs.double()).sum())
     assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), 1.0), (lhs, rhs)
     assert float(gs[:, :7].abs().max()) == 0.0 and float(gs[:, :, :9].abs().max()) == 0.0       # exact zeros outside the window
+
+
+def test_windows_that_do_not_compose_take_the_two_launch_path():
+    """A window so small that a window row would feed more than sixteen canvas rows does not compose (advx_crop_composes = 0):
+    the engine resizes it on its own as before - same API, same bars against the oracle; and advx_collect_crop refuses it."""
+    from adversarialvlm_amd import _lib as L
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.pgd import PixelPGD
+    from adversarialvlm_amd.plan import Plan
+    H, W = 96, 128
+    plan = Plan.llava(H, W, 56, 72)
+    tiny = (10, 20, 8, 10)
+    assert not ops.crop_composes(plan, H, W, tiny) and ops.crop_composes(plan, H, W, (3, 5, 80, 100))
+    gen = torch.Generator().manual_seed(1)
+    x0 = torch.rand(3, H, W, generator=gen)
+    eng = PixelPGD(x0.to(DEV), [plan], lr=1e-2, use_crop=True, allow_fused=False)
+    ora = PGDOracle(x0, [LlavaOracle(56, 72)], lr=1e-2)
+    for win in (tiny, (3, 5, 80, 100), tiny):
+        z, g = torch.randn(2, 3, 56, 72, generator=gen), torch.randn(2, 3, 56, 72, generator=gen) * 0.05
+        pv_ref = ora.forward(2, [z], crop=win)[0]
+        pv = eng.forward(2, [z.to(DEV)], crop=win)[0]
+        assert rel_err(pv.cpu(), pv_ref) < 1e-5
+        ref = ora.backward_update([g])
+        eng.backward_update([g.to(DEV)])
+        assert rel_err(eng.grad.cpu(), ref["grad"]) < 1e-4
+    with pytest.raises(L.AdvxError):
+        ops.collect_crop(plan, torch.zeros(1, plan.out_numel, device=DEV), 1, tiny, ops.image_scratch(H, W, 0, DEV),
+                         grad_s=torch.empty(3, H, W, device=DEV))
