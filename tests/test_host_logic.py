@@ -140,3 +140,27 @@ def test_get_loss_against_the_reference_method(k):
     loss.backward()
     assert float(loss.detach()) == pytest.approx(float(g[f"ce{k}_loss"]), rel=1e-6)
     assert float((logits.grad - torch.tensor(g[f"ce{k}_logits_grad"])).abs().max()) < 1e-7
+
+
+def test_crop_composes_is_a_host_side_predicate():
+    """advx_crop_composes needs no GPU (plan geometry only): the trainers' windows (scale 0.6-1, ratio 3/4-4/3) compose with the
+    stage 0 of LLaVA, Mllama and Qwen2-VL; windows below ~1/4 of the image per axis do not (a window row would feed more than
+    sixteen canvas rows), nor does a window outside the image, nor anything while ADVX_TUNE_SEPARATE_CROP is set.  Phi-3.5's
+    stage 0 UP-samples (512 -> 672, two-tap bilinear): its transposed rows are longer and only near-full windows stay within the
+    sixteen-row bound - smaller ones take the two-launch path."""
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan
+    H = W = 512
+    plans = [Plan.llava(H, W), Plan.mllama(H, W), Plan.qwen2vl(H, W), Plan.phi3(H, W)]
+    for plan in plans[:3]:
+        assert ops.crop_composes(plan, H, W, (0, 0, H, W))
+        assert ops.crop_composes(plan, H, W, (40, 30, 400, 420))
+        assert ops.crop_composes(plan, H, W, (100, 30, 343, 458))          # 0.6 of the area at ratio 3/4
+        assert not ops.crop_composes(plan, H, W, (5, 5, 40, 40))
+        assert not ops.crop_composes(plan, H, W, (100, 60, 343, 458))      # reaches beyond the right edge
+        assert not ops.crop_composes(plan, H, W, None)
+    assert ops.crop_composes(plans[3], H, W, (0, 0, H, W)) and not ops.crop_composes(plans[3], H, W, (40, 30, 400, 420))
+    with ops.separate_crop():
+        assert not any(ops.crop_composes(plan, H, W, (40, 30, 400, 420)) for plan in plans)
+    assert ops.crop_composes(plans[0], H, W, (40, 30, 400, 420))
+    assert not ops.crop_composes(plans[0], 336, 336, (0, 0, 300, 300))     # not this plan's image size
