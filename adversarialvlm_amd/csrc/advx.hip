@@ -1346,7 +1346,11 @@ bool compose_geom(const advx_plan* p, int H, int W, const int32_t* crop, Compose
   if (D.res_h + D.res_w > 2 * (H + W)) return false;                 // the tables' room (crop_table_floats)
   const int ins[2] = {ch, cw}, mids[2] = {H, W}, outs[2] = {D.res_h, D.res_w};
   auto tbound = [](int mode, int in_size, int out_size) {
-    if (mode != ADVX_MODE_AA_BILINEAR) return (int)std::ceil(4.0 * out_size / in_size) + 3;       // 2- and 4-tap kernels
+    // outputs that read one source index: a source j is read by the outputs whose centre falls within the kernel's reach of j
+    // (bilinear: (j - 1, j + 1); bicubic: (j - 2, j + 2); the border sources also collect the clamped taps, which stay inside
+    // the same reach).  tests/test_host_logic.py checks these bounds against the tables themselves on a sweep of geometries.
+    if (mode == ADVX_MODE_BILINEAR) return (int)std::ceil(2.0 * out_size / in_size) + 2;
+    if (mode == ADVX_MODE_BICUBIC) return (int)std::ceil(4.0 * out_size / in_size) + 3;
     float scale = tap_scale(in_size, out_size);
     float support = (scale >= 1.0f) ? scale : 1.0f;
     return (int)std::ceil(2.0 * support / scale) + 2;
@@ -1428,6 +1432,16 @@ extern "C" int64_t advx_crop_scratch_floats(int32_t H, int32_t W) { return crop_
 extern "C" int32_t advx_crop_composes(const advx_plan* p, int32_t H, int32_t W, const int32_t* crop) {
   ComposeGeom g;
   return compose_geom(p, H, W, crop, &g) ? 1 : 0;
+}
+// the row lengths the composed tables are built with (per axis: forward, transposed) - upper bounds of what a row needs;
+// a row longer than its bound would be cut, so the bounds are checked against the tables themselves (tests/test_host_logic.py)
+extern "C" int32_t advx_crop_compose_strides(const advx_plan* p, int32_t H, int32_t W, const int32_t* crop, int32_t forward[2],
+                                             int32_t transposed[2]) {
+  REQUIRE(p && crop && forward && transposed, ADVX_E_BADARG, "advx_crop_compose_strides: null argument");
+  ComposeGeom g;
+  REQUIRE(compose_geom(p, H, W, crop, &g), ADVX_E_UNSUPPORTED, "this crop window does not compose with the plan's stage 0");
+  for (int ax = 0; ax < 2; ++ax) { forward[ax] = g.s[ax]; transposed[ax] = g.ts[ax]; }
+  return ADVX_OK;
 }
 
 // Backward of a step whose advx_forward_multi composed the crop window with stage 0: batch reduction, the upper stages,

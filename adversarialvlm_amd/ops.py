@@ -133,6 +133,14 @@ def crop_composes(plan, H, W, crop):
     return bool(L.load().advx_crop_composes(plan.handle, int(H), int(W), cp))
 
 
+def crop_compose_strides(plan, H, W, crop):
+    """((forward_h, forward_w), (transposed_h, transposed_w)): the row lengths the composed tables are built with."""
+    _keep, cp = _crop_arg(crop)
+    f, t = (C.c_int32 * 2)(), (C.c_int32 * 2)()
+    L.check(L.load().advx_crop_compose_strides(plan.handle, int(H), int(W), cp, f, t), "advx_crop_compose_strides")
+    return (int(f[0]), int(f[1])), (int(t[0]), int(t[1]))
+
+
 def collect_crop(plan, grad_out, batch, crop, image_scratch, grad_s, accumulate=False, workspace=None):
     """Backward of a forward_multi that composed: grad_out [batch, out_numel] -> gradient w.r.t. the IMAGE s [3,H,W]
     (exact zeros outside the window)."""

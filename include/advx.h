@@ -233,6 +233,9 @@ int32_t advx_collect_multi(int32_t n, advx_plan* const* plans, const void* const
  * advx_image_bwd* WITHOUT a crop window.  The composed map drops the float32 rounding of the intermediate image: held
  * to the reference at 1e-4 (tests), not bit-identical to the two-launch form; ADVX_TUNE_SEPARATE_CROP (or ADVX_TUNE_GENERIC_KERNELS) switches it off. */
 int32_t advx_crop_composes(const advx_plan* plan, int32_t H, int32_t W, const int32_t* crop_ijhw);
+/* row lengths (upper bounds) of the composed tables per axis (0 = H, 1 = W); host only, for the tests */
+int32_t advx_crop_compose_strides(const advx_plan* plan, int32_t H, int32_t W, const int32_t* crop_ijhw, int32_t forward[2],
+                                  int32_t transposed[2]);
 int32_t advx_collect_crop(advx_plan* plan, const void* grad_out, int32_t batch, float* grad_s, int32_t accumulate,
                           float* workspace, int64_t workspace_floats, int32_t H, int32_t W, const int32_t* crop_ijhw,
                           float* image_scratch, void* stream);

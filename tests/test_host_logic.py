@@ -144,23 +144,72 @@ def test_get_loss_against_the_reference_method(k):
 
 def test_crop_composes_is_a_host_side_predicate():
     """advx_crop_composes needs no GPU (plan geometry only): the trainers' windows (scale 0.6-1, ratio 3/4-4/3) compose with the
-    stage 0 of LLaVA, Mllama and Qwen2-VL; windows below ~1/4 of the image per axis do not (a window row would feed more than
-    sixteen canvas rows), nor does a window outside the image, nor anything while ADVX_TUNE_SEPARATE_CROP is set.  Phi-3.5's
-    stage 0 UP-samples (512 -> 672, two-tap bilinear): its transposed rows are longer and only near-full windows stay within the
-    sixteen-row bound - smaller ones take the two-launch path."""
+    stage 0 of all four families; windows below ~1/4 of the image per axis do not (a window row would feed more than sixteen
+    canvas rows), nor does a window outside the image, nor anything while ADVX_TUNE_SEPARATE_CROP is set."""
     from adversarialvlm_amd import ops
     from adversarialvlm_amd.plan import Plan
     H = W = 512
     plans = [Plan.llava(H, W), Plan.mllama(H, W), Plan.qwen2vl(H, W), Plan.phi3(H, W)]
-    for plan in plans[:3]:
+    for plan in plans:
         assert ops.crop_composes(plan, H, W, (0, 0, H, W))
         assert ops.crop_composes(plan, H, W, (40, 30, 400, 420))
         assert ops.crop_composes(plan, H, W, (100, 30, 343, 458))          # 0.6 of the area at ratio 3/4
         assert not ops.crop_composes(plan, H, W, (5, 5, 40, 40))
         assert not ops.crop_composes(plan, H, W, (100, 60, 343, 458))      # reaches beyond the right edge
         assert not ops.crop_composes(plan, H, W, None)
-    assert ops.crop_composes(plans[3], H, W, (0, 0, H, W)) and not ops.crop_composes(plans[3], H, W, (40, 30, 400, 420))
     with ops.separate_crop():
         assert not any(ops.crop_composes(plan, H, W, (40, 30, 400, 420)) for plan in plans)
     assert ops.crop_composes(plans[0], H, W, (40, 30, 400, 420))
     assert not ops.crop_composes(plans[0], 336, 336, (0, 0, 300, 300))     # not this plan's image size
+
+
+def _row_sets(start, count):
+    return [(int(s), int(s + c)) for s, c in zip(start, count)]
+
+
+def test_composed_table_row_lengths_are_upper_bounds():
+    """The device builds the composed (window o plan) tables into rows of a length the HOST bounds (advx_crop_compose_strides);
+    a row longer than its bound would be cut silently.  Brute force over a sweep of plans and windows: compose the two host
+    tables (the plan's stage 0 and the window's antialiased resize, both ATen's tap geometry) and compare the longest forward
+    and transposed rows with the bounds, per axis."""
+    import numpy as np
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan, taps_compute
+    rng = np.random.default_rng(11)
+    plans = [(512, 512, Plan.llava(512, 512)), (512, 512, Plan.mllama(512, 512)), (512, 512, Plan.qwen2vl(512, 512)),
+             (512, 512, Plan.phi3(512, 512)), (336, 336, Plan.llava(336, 336)), (336, 336, Plan.mllama(336, 336)),
+             (97, 130, Plan.llava(97, 130, 56, 72)), (60, 90, Plan.mllama(60, 90, tile=56, max_tiles=4)),
+             (300, 200, Plan.phi3(300, 200)), (120, 150, Plan.qwen2vl(120, 150, min_pixels=56 * 56, max_pixels=28 * 28 * 64))]
+    checked = 0
+    for H, W, plan in plans:
+        windows = [(0, 0, H, W)]
+        for _ in range(25):
+            h, w = int(rng.integers(max(4, H // 4), H + 1)), int(rng.integers(max(4, W // 4), W + 1))
+            windows.append((int(rng.integers(0, H - h + 1)), int(rng.integers(0, W - w + 1)), h, w))
+        for win in windows:
+            if not ops.crop_composes(plan, H, W, win):
+                continue
+            fwd_bound, tr_bound = ops.crop_compose_strides(plan, H, W, win)
+            for axis, (size, off, ext) in enumerate(((H, win[0], win[2]), (W, win[1], win[3]))):
+                bs, bc, _ = plan.taps(0, axis)                              # plan: size -> res, per canvas row
+                as_, ac, _ = taps_compute(0, ext, size)                     # window: ext -> size, antialiased bilinear
+                B, A = _row_sets(bs, bc), _row_sets(as_, ac)
+                # forward: the window rows a canvas row reaches
+                rows = []
+                for lo, hi in B:
+                    if hi <= lo:
+                        rows.append((0, 0))
+                        continue
+                    rows.append((min(A[k][0] for k in range(lo, hi)), max(A[k][1] for k in range(lo, hi))))
+                assert max(b - a for a, b in rows) <= fwd_bound[axis], (H, W, win, axis, "forward")
+                # transposed: the canvas rows that reach one window row (contiguous: starts and ends are monotone)
+                first = np.full(ext, len(rows), np.int64)
+                last = np.full(ext, -1, np.int64)
+                for y, (a, b) in enumerate(rows):
+                    if b > a:
+                        first[a:b] = np.minimum(first[a:b], y)
+                        last[a:b] = np.maximum(last[a:b], y)
+                need = int((last - first + 1).clip(min=0).max())
+                assert need <= tr_bound[axis], (H, W, win, axis, "transposed", need, tr_bound[axis])
+                checked += 1
+    assert checked > 300
