@@ -44,3 +44,17 @@ def test_bench_launcher_refuses_without_a_gpu():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"],
                          capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
     assert res.returncode == 2 and "needs a GPU" in res.stderr and res.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_launcher_reports_a_failing_rank():
+    """A rank that fails must fail the whole call: no JSON line on stdout, exit status 1, the ranks' exit codes on stderr - never a
+    hang and never a line from a partial run.  (The one-launch chain cannot host the gradient exchange: every rank raises.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--chain", "step"],
+                         capture_output=True, text=True, env=env, cwd=ROOT, timeout=540)
+    assert res.returncode == 1, (res.returncode, res.stderr[-1500:])
+    assert res.stdout.strip() == ""
+    assert "rank exit codes" in res.stderr or "ranks stopped" in res.stderr
+    assert "cannot host the gradient all-reduce" in res.stderr
