@@ -11,8 +11,9 @@ and `crossattack_models.py:329-406,425-432` (several models):
                        mask, ||g||, AdamW|sign, StepLR                   (HIP)
 
 Four kernel chains implement this, chosen at construction (`self.mode`):
-  * generic  - any plan(s), blur, crop, gradient accumulation (advx_image_* / advx_emit /
-               advx_collect / advx_update): nine launches per step;
+  * generic  - any plan(s), blur, crop, gradient accumulation (advx_forward_multi / advx_collect[_multi] /
+               advx_image_bwd_update): five to eight launches per step; with ONE plan a crop window is composed
+               with the plan's own resize (advx_crop_composes: one gather each way, advx_collect_crop);
   * prepared - ONE plan (LLaVA from a non-native image, Mllama, Qwen2-VL, Phi-3.5) without
                blur/crop/accumulation: the backward leaves the next step's canvas behind, four
                launches per step (advx_prepared_fwd / advx_prepared_bwd); under data parallelism
@@ -24,6 +25,8 @@ Four kernel chains implement this, chosen at construction (`self.mode`):
   * step     - same plans on one GPU: ONE launch per step (advx_fused_step): the backward of
                step t and the forward of step t+1 run in the same kernel, so forward() of
                step t+1 only hands out the tensor that backward_update() of step t produced.
+               `auto` takes it when the caller's batch_hint is at most 16 prompts (the pair is then
+               bound by the host's launch rate), else the pair.
 All statistics stay on the device (`self.stats`); nothing here synchronises the stream.
 """
 import torch
