@@ -69,3 +69,24 @@ def test_config4_rank_workload_cross_three_models_blur_full_size(dev):
     worst = T._trajectory(dev, x0, [Phi3Oracle(), Qwen2VLOracle(), MllamaOracle()], plans, [16, 16, 16], 2, blur_kernel=5,
                           blur_sigma_fn=lambda t: sig[t], weights=[0.2, 0.8, 1.6], cross=True, gamma=0.9)
     assert worst["grad"] < 1e-5 and worst["pixel_values"] < 1e-5, worst
+
+
+@pytest.mark.timeout(900)
+def test_llava_512_blur9_crop_batch64_full_size_composed(dev):
+    """The reference's production preset for LLaVA (scripts/attacks/attack_clamp_tanh_llava_gblur.sh:24-60 with --use_local_crop:
+    512 x 512 image, Gaussian blur 9, a random-resized-crop window per step) at the benchmark's batch, against the oracle: the
+    crop window's resize and the processor's 512 -> 336 resize go through the composed tables (round 3), one gather each way."""
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan
+    from oracle.processors import LlavaOracle
+    x0 = torch.rand(3, 512, 512, generator=torch.Generator().manual_seed(45))
+    plan = Plan.llava(512, 512)
+    windows = [(40, 30, 400, 420), (100, 30, 343, 458), (0, 0, 512, 512)]
+    assert all(ops.crop_composes(plan, 512, 512, w) for w in windows)
+    sig = [10.0, 7.0, 1.3]
+    # Vetting budget: how many pixels have a first gradient within a few adam_eps of zero is N * P(|g| < tau) ~ N * 2 tau / (2.5 sd(g)):
+    # here N = 786 432 and the blurred gradient field has max|g| = 0.06 (sd ~ 0.015), i.e. about ten pixels below tau = 3e-7 -
+    # measured with the default budget of 2: six (g = 1.9e-7 against max|g| = 6e-2, the gradients agreeing to 3e-9).  Twelve, absolute.
+    worst = T._trajectory(dev, x0, [LlavaOracle()], [plan], [64], 3, blur_kernel=9, blur_sigma_fn=lambda t: sig[t],
+                          crop_fn=lambda t: windows[t], fused=False, max_ill=12)
+    assert worst["grad"] < 1e-5 and worst["pixel_values"] < 1e-5, worst

@@ -20,7 +20,8 @@ of a crop window, the border of a mask), and a per cent of a step where they are
   * the trajectory's budget `max_ill` is not exceeded: an absolute handful, DET_MAX_ILL = 2 pixels for the deterministic
     tests (measured need: one pixel of 338 688 in the 336 x 336 baseline case - g = 1.1e-7 against max|g| = 0.65 at step 0 -
     and one or two in four smaller cases, profiles/r03/pgd_tests_budget0.log; zero is not attainable and the premise that it
-    is was wrong) and FUZZ_MAX_ILL = 8 for the random trajectories;
+    is was wrong; the full-size 512 x 512 blur + crop case, 786 432 pixels with a blurred gradient field of max|g| = 0.06, states its
+    own budget of 12 with the expectation it follows from: tests/test_gpu_fullsize.py) and FUZZ_MAX_ILL = 8 for the random trajectories;
 it stays excluded from p's comparison for the rest of the trajectory (its moments differ from then on) and every
 acceptance is logged (ILL_CONDITIONED; the count is printed in pytest's summary line, tests/conftest.py).  What such a
 pixel can move DOWNSTREAM is bounded from its measured difference, nothing looser: d = eps * max|p_engine - p_oracle|
