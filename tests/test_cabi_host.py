@@ -288,3 +288,22 @@ def test_multi_plan_entry_points_validate_before_any_device_work(lib):
     assert lib.advx_image_bwd_update(fake(1), fake(2), fake(3), 0, 52, 0.5, 0, 0.0, None, 1.0, fake(4), 0, fake(5), fake(5),
                                      fake(6), C.byref(opt), fake(7), fake(8), fake(9), 1, None) == E_SHAPE
     assert lib.advx_update_flush(0, fake(1), fake(2), None) == E_BADARG
+
+
+def test_plain_c_host_compiles_and_links_against_the_header(tmp_path):
+    """CPU tier: tests/cabi/pair_steps.c - a host that is neither Python nor torch - builds with gcc against include/advx.h and
+    links libadvx_hip.so (it RUNS in the GPU tier, tests/test_gpu_cabi_c_host.py): the header is plain C and every symbol it
+    uses is exported."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("gcc or the HIP headers are not here")
+    from adversarialvlm_amd.build import build_library
+    lib_dir = os.path.dirname(build_library())
+    exe = str(tmp_path / "pair_steps")
+    res = subprocess.run(["gcc", "-O2", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "cabi", "pair_steps.c"),
+                          "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L" + lib_dir, "-ladvx_hip",
+                          "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert os.path.exists(exe)
