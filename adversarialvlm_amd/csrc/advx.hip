@@ -46,7 +46,7 @@ static int32_t fail(int32_t code, const std::string& msg) {
 static int g_generic_kernels = 0;
 static int g_pair_nt_loads = 0;
 static int g_full_tap_rows = 0;
-static int g_separate_crop = 0;   // ADVX_TUNE_SEPARATE_CROP: never compose a crop window with stage 0 (two launches each way)
+static int g_separate_crop = 0;   // ADVX_TUNE_SEPARATE_CROP: 1 = never compose a crop window with stage 0; 2 = compose wherever the tables fit (tests)
 static long long kRows3MinPositions = 250000;   // three channels per thread (k_stage_bwd3, k_crop_bwd_rows3) from here up (measured)
 extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
   if (what == ADVX_TUNE_GENERIC_KERNELS) {
@@ -62,7 +62,7 @@ extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
     return ADVX_OK;
   }
   if (what == ADVX_TUNE_SEPARATE_CROP) {
-    g_separate_crop = value ? 1 : 0;
+    g_separate_crop = (value == 2) ? 2 : (value ? 1 : 0);
     return ADVX_OK;
   }
   return fail(ADVX_E_BADARG, "advx_set_tuning: unknown switch");
@@ -1336,7 +1336,15 @@ struct ComposeGeom {
 // forward  - a canvas row reads cB intermediate rows, each reading cA window rows that advance by in/mid <= 1 per row;
 // transposed - a window row is read by <= tA intermediate rows, which spread over tA*out/mid canvas rows plus B's own reach.
 bool compose_geom(const advx_plan* p, int H, int W, const int32_t* crop, ComposeGeom* g) {
-  if (g_generic_kernels || g_separate_crop || !p || !crop || p->st[0].info.src != 0) return false;
+  if (g_generic_kernels || g_separate_crop == 1 || !p || !crop || p->st[0].info.src != 0) return false;
+  // Where composing PAYS (measured at full size, tools/crop_chain_bench.py, profiles/r03/crop_chain_bench.log): one-stage plans
+  // with an antialiased stage 0 and one gradient image per canvas - LLaVA 512 -> 336 70.3 vs 75.8 us (blur 9: 79.0 vs 85.1), Mllama
+  // 512 236-242 vs 244.  Qwen2-VL's canvas gradient is two temporal copies (the composed transposed gather reads both per tap: 183.5
+  // vs 179.0 us) and Phi-3.5 has a second stage and a two-tap up-sampling stage 0 (243.6 vs 240.6): those keep the two launches
+  // unless ADVX_TUNE_SEPARATE_CROP = 2 asks for composition wherever the tables fit (the tests do, to cover those geometries).
+  if (g_separate_crop != 2 &&
+      (p->info.n_stage != 1 || p->st[0].info.mode != ADVX_MODE_AA_BILINEAR || p->dplan.gcan_copies[0] != 1))
+    return false;
   const advx_stage_info& D = p->st[0].info;       // host geometry: valid before the plan is uploaded
   if (D.src_h != H || D.src_w != W) return false;
   for (int k = 1; k < p->info.n_stage; ++k)

@@ -32,6 +32,17 @@ class separate_crop:
         L.check(L.load().advx_set_tuning(L.TUNE_SEPARATE_CROP, 0), "advx_set_tuning")
 
 
+class compose_crop_everywhere:
+    """Context manager (tests): compose a crop window with the plan's stage 0 wherever the tables fit, also for the geometries where
+    the default keeps two launches because composing was measured slower (Qwen2-VL's two gradient copies, Phi-3.5's two stages)."""
+
+    def __enter__(self):
+        L.check(L.load().advx_set_tuning(L.TUNE_SEPARATE_CROP, 2), "advx_set_tuning")
+
+    def __exit__(self, *exc):
+        L.check(L.load().advx_set_tuning(L.TUNE_SEPARATE_CROP, 0), "advx_set_tuning")
+
+
 class full_tap_rows:
     """Context manager (tests): plans UPLOADED inside keep ATen's full tap rows on the device instead of the rows with the
     zero-weight end taps dropped.  Results must be bit-identical."""

@@ -120,9 +120,11 @@ const char* advx_last_error(void);
  * is what the tests use it for.  Process-wide, not thread-safe. */
 #define ADVX_TUNE_GENERIC_KERNELS 1
 #define ADVX_TUNE_PAIR_NT_LOADS 2   /* advx_fused_bwd reads grad_out with non-temporal loads (same results) */
-#define ADVX_TUNE_SEPARATE_CROP 4   /* never compose a crop window with a plan's stage 0 (advx_forward_multi): the window is resized
+#define ADVX_TUNE_SEPARATE_CROP 4   /* 1: never compose a crop window with a plan's stage 0 (advx_forward_multi) - the window is resized
                                      * into `argument` and the plan resamples that, two launches each way, bit-identical to the
-                                     * unfused kernels */
+                                     * unfused kernels; 2: compose wherever the tables fit, also where it does not pay (tests);
+                                     * 0 (default): compose where it was measured to pay - one-stage plans with an antialiased
+                                     * stage 0 and one gradient image per canvas (LLaVA, Llama-3.2-Vision) */
 #define ADVX_TUNE_FULL_TAP_ROWS 3   /* plans uploaded from now on keep ATen's full tap rows on the device; by default the
                                      * device copies drop the zero-weight taps at the ends of a row (same results) */
 int32_t advx_set_tuning(int32_t what, int32_t value);

@@ -52,7 +52,7 @@ def test_composed_crop_matches_the_two_launch_form_and_the_oracle(name, blur):
         for t, win in enumerate(windows):
             z = torch.randn(shape, generator=g2)
             g = torch.randn(shape, generator=g2) * 0.05
-            composes = ops.crop_composes(plan, H, W, win)
+            composes = ops.crop_composes(plan, H, W, win)          # under whatever switch the caller set
             pv = eng.forward(B, [z.to(DEV)], blur_sigma=0.8 + 0.4 * t if blur else None, crop=win)[0]
             eng.backward_update([g.to(DEV)])
             outs.append((pv.cpu().clone(), eng.grad.cpu().clone(), eng.p.cpu().clone(), composes))
@@ -60,27 +60,31 @@ def test_composed_crop_matches_the_two_launch_form_and_the_oracle(name, blur):
 
     with ops.separate_crop():
         ref, st_ref = run(True)
-    got, st_got = run(False)
+    # every geometry through the composed tables, also Qwen2-VL (two gradient copies) and Phi-3.5 (two stages), where the default
+    # keeps the two launches because composing was measured slower there
+    with ops.compose_crop_everywhere():
+        got, st_got = run(False)
     assert not any(r[3] for r in ref)                         # the switch really keeps the two launches
     assert sum(bool(r[3]) for r in got) >= (2 if name.startswith("phi3") else 3)      # and by default these windows compose
     for t, (a, b) in enumerate(zip(got, ref)):
         assert rel_err(a[0], b[0], elementwise=1e-5) < 2e-6, (t, "pixel_values")
         assert rel_err(a[1], b[1], elementwise=1e-5) < 2e-6, (t, "grad")
-    # against the oracle, one step from p = 0 with the first window that is not the whole image
-    plan = mk_plan()
-    eng = PixelPGD(x0.to(DEV), [plan], lr=1e-2, blur_kernel=blur, use_crop=True, allow_fused=False)
-    ora = PGDOracle(x0, [mk_oracle()], lr=1e-2, blur_kernel=blur)
-    shape = (B * plan.out_shape[0],) + plan.out_shape[1:]
-    for t in range(2):
-        z, g = torch.randn(shape, generator=gen), torch.randn(shape, generator=gen) * 0.05
-        win = windows[1 + t]
-        sig = 1.1 if blur else None
-        pv_ref = ora.forward(B, [z], blur_sigma=sig, crop=win)[0]
-        pv = eng.forward(B, [z.to(DEV)], blur_sigma=sig, crop=win)[0]
-        assert rel_err(pv.cpu(), pv_ref) < 1e-5
-        ref_b = ora.backward_update([g])
-        eng.backward_update([g.to(DEV)])
-        assert rel_err(eng.grad.cpu(), ref_b["grad"]) < 1e-4
+    # against the oracle, two steps with the windows that are not the whole image (composed wherever the tables fit)
+    with ops.compose_crop_everywhere():
+        plan = mk_plan()
+        eng = PixelPGD(x0.to(DEV), [plan], lr=1e-2, blur_kernel=blur, use_crop=True, allow_fused=False)
+        ora = PGDOracle(x0, [mk_oracle()], lr=1e-2, blur_kernel=blur)
+        shape = (B * plan.out_shape[0],) + plan.out_shape[1:]
+        for t in range(2):
+            z, g = torch.randn(shape, generator=gen), torch.randn(shape, generator=gen) * 0.05
+            win = windows[1 + t]
+            sig = 1.1 if blur else None
+            pv_ref = ora.forward(B, [z], blur_sigma=sig, crop=win)[0]
+            pv = eng.forward(B, [z.to(DEV)], blur_sigma=sig, crop=win)[0]
+            assert rel_err(pv.cpu(), pv_ref) < 1e-5
+            ref_b = ora.backward_update([g])
+            eng.backward_update([g.to(DEV)])
+            assert rel_err(eng.grad.cpu(), ref_b["grad"]) < 1e-4
 
 
 def test_composed_forward_and_backward_are_adjoint():

@@ -143,20 +143,26 @@ def test_get_loss_against_the_reference_method(k):
 
 
 def test_crop_composes_is_a_host_side_predicate():
-    """advx_crop_composes needs no GPU (plan geometry only): the trainers' windows (scale 0.6-1, ratio 3/4-4/3) compose with the
-    stage 0 of all four families; windows below ~1/4 of the image per axis do not (a window row would feed more than sixteen
-    canvas rows), nor does a window outside the image, nor anything while ADVX_TUNE_SEPARATE_CROP is set."""
+    """advx_crop_composes needs no GPU (plan geometry only).  By default a window composes where composing was measured to pay:
+    one-stage plans with an antialiased stage 0 and one gradient image per canvas - LLaVA and Llama-3.2-Vision - for the trainers'
+    windows (scale 0.6-1, ratio 3/4-4/3); Qwen2-VL (two temporal gradient copies) and Phi-3.5 (two stages, two-tap up-sampling)
+    keep the two launches unless composition is asked for everywhere (tests); windows below ~1/4 of the image per axis, windows
+    outside the image and anything under ADVX_TUNE_SEPARATE_CROP never compose."""
     from adversarialvlm_amd import ops
     from adversarialvlm_amd.plan import Plan
     H = W = 512
     plans = [Plan.llava(H, W), Plan.mllama(H, W), Plan.qwen2vl(H, W), Plan.phi3(H, W)]
-    for plan in plans:
-        assert ops.crop_composes(plan, H, W, (0, 0, H, W))
-        assert ops.crop_composes(plan, H, W, (40, 30, 400, 420))
-        assert ops.crop_composes(plan, H, W, (100, 30, 343, 458))          # 0.6 of the area at ratio 3/4
-        assert not ops.crop_composes(plan, H, W, (5, 5, 40, 40))
-        assert not ops.crop_composes(plan, H, W, (100, 60, 343, 458))      # reaches beyond the right edge
-        assert not ops.crop_composes(plan, H, W, None)
+    wins = [(0, 0, H, W), (40, 30, 400, 420), (100, 30, 343, 458)]          # the last: 0.6 of the area at ratio 3/4
+    for plan in plans[:2]:
+        assert all(ops.crop_composes(plan, H, W, w) for w in wins)
+    for plan in plans[2:]:
+        assert not any(ops.crop_composes(plan, H, W, w) for w in wins)
+    with ops.compose_crop_everywhere():
+        for plan in plans:
+            assert all(ops.crop_composes(plan, H, W, w) for w in wins)
+            assert not ops.crop_composes(plan, H, W, (5, 5, 40, 40))
+            assert not ops.crop_composes(plan, H, W, (100, 60, 343, 458))      # reaches beyond the right edge
+            assert not ops.crop_composes(plan, H, W, None)
     with ops.separate_crop():
         assert not any(ops.crop_composes(plan, H, W, (40, 30, 400, 420)) for plan in plans)
     assert ops.crop_composes(plans[0], H, W, (40, 30, 400, 420))
@@ -181,6 +187,8 @@ def test_composed_table_row_lengths_are_upper_bounds():
              (97, 130, Plan.llava(97, 130, 56, 72)), (60, 90, Plan.mllama(60, 90, tile=56, max_tiles=4)),
              (300, 200, Plan.phi3(300, 200)), (120, 150, Plan.qwen2vl(120, 150, min_pixels=56 * 56, max_pixels=28 * 28 * 64))]
     checked = 0
+    everywhere = ops.compose_crop_everywhere()
+    everywhere.__enter__()
     for H, W, plan in plans:
         windows = [(0, 0, H, W)]
         for _ in range(25):
@@ -212,4 +220,5 @@ def test_composed_table_row_lengths_are_upper_bounds():
                 need = int((last - first + 1).clip(min=0).max())
                 assert need <= tr_bound[axis], (H, W, win, axis, "transposed", need, tr_bound[axis])
                 checked += 1
+    everywhere.__exit__(None, None, None)
     assert checked > 300
