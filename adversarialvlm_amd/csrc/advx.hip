@@ -1337,13 +1337,15 @@ struct ComposeGeom {
 // transposed - a window row is read by <= tA intermediate rows, which spread over tA*out/mid canvas rows plus B's own reach.
 bool compose_geom(const advx_plan* p, int H, int W, const int32_t* crop, ComposeGeom* g) {
   if (g_generic_kernels || g_separate_crop == 1 || !p || !crop || p->st[0].info.src != 0) return false;
-  // Where composing PAYS (measured at full size, tools/crop_chain_bench.py, profiles/r03/crop_chain_bench.log): one-stage plans
-  // with an antialiased stage 0 and one gradient image per canvas - LLaVA 512 -> 336 70.3 vs 75.8 us (blur 9: 79.0 vs 85.1), Mllama
-  // 512 236-242 vs 244.  Qwen2-VL's canvas gradient is two temporal copies (the composed transposed gather reads both per tap: 183.5
-  // vs 179.0 us) and Phi-3.5 has a second stage and a two-tap up-sampling stage 0 (243.6 vs 240.6): those keep the two launches
-  // unless ADVX_TUNE_SEPARATE_CROP = 2 asks for composition wherever the tables fit (the tests do, to cover those geometries).
+  // Where composing PAYS (measured at full size, composed / two launches, tools/crop_chain_bench.py, profiles/r03/crop_chain_bench*.log):
+  // one-stage plans whose antialiased stage 0 does NOT up-sample and whose canvas has one gradient image - LLaVA 512 -> 336 69.3 / 74.7 us
+  // (blur 9: 77.9 / 83.8), LLaVA 336 58.8 / 61.1 (66.0 / 70.4).  A composed gather runs once per CANVAS element with more taps, so an
+  // up-sampling stage 0 loses (Llama-3.2-Vision 336 -> 560: 236 / 225; at 512 -> 1120 level: 233.5 / 235.2), so do Qwen2-VL's two temporal
+  // gradient copies, both read per tap (197 / 193), and Phi-3.5's second stage and two-tap up-sampling (241 / 238).  Those keep the two
+  // launches unless ADVX_TUNE_SEPARATE_CROP = 2 asks for composition wherever the tables fit (the tests do, to cover those geometries).
   if (g_separate_crop != 2 &&
-      (p->info.n_stage != 1 || p->st[0].info.mode != ADVX_MODE_AA_BILINEAR || p->dplan.gcan_copies[0] != 1))
+      (p->info.n_stage != 1 || p->st[0].info.mode != ADVX_MODE_AA_BILINEAR || p->dplan.gcan_copies[0] != 1 ||
+       p->st[0].info.res_h > H || p->st[0].info.res_w > W))
     return false;
   const advx_stage_info& D = p->st[0].info;       // host geometry: valid before the plan is uploaded
   if (D.src_h != H || D.src_w != W) return false;

@@ -123,8 +123,9 @@ const char* advx_last_error(void);
 #define ADVX_TUNE_SEPARATE_CROP 4   /* 1: never compose a crop window with a plan's stage 0 (advx_forward_multi) - the window is resized
                                      * into `argument` and the plan resamples that, two launches each way, bit-identical to the
                                      * unfused kernels; 2: compose wherever the tables fit, also where it does not pay (tests);
-                                     * 0 (default): compose where it was measured to pay - one-stage plans with an antialiased
-                                     * stage 0 and one gradient image per canvas (LLaVA, Llama-3.2-Vision) */
+                                     * 0 (default): compose where it was measured to pay - one-stage plans whose antialiased stage 0
+                                     * does not up-sample and whose canvas has one gradient image (LLaVA; Llama-3.2-Vision from
+                                     * images larger than its canvas) */
 #define ADVX_TUNE_FULL_TAP_ROWS 3   /* plans uploaded from now on keep ATen's full tap rows on the device; by default the
                                      * device copies drop the zero-weight taps at the ends of a row (same results) */
 int32_t advx_set_tuning(int32_t what, int32_t value);

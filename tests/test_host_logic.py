@@ -144,19 +144,21 @@ def test_get_loss_against_the_reference_method(k):
 
 def test_crop_composes_is_a_host_side_predicate():
     """advx_crop_composes needs no GPU (plan geometry only).  By default a window composes where composing was measured to pay:
-    one-stage plans with an antialiased stage 0 and one gradient image per canvas - LLaVA and Llama-3.2-Vision - for the trainers'
-    windows (scale 0.6-1, ratio 3/4-4/3); Qwen2-VL (two temporal gradient copies) and Phi-3.5 (two stages, two-tap up-sampling)
-    keep the two launches unless composition is asked for everywhere (tests); windows below ~1/4 of the image per axis, windows
-    outside the image and anything under ADVX_TUNE_SEPARATE_CROP never compose."""
+    one-stage plans whose antialiased stage 0 does not up-sample and whose canvas has one gradient image - LLaVA; Llama-3.2-Vision
+    only from an image larger than its canvas - for the trainers' windows (scale 0.6-1, ratio 3/4-4/3); Qwen2-VL (two temporal
+    gradient copies), Phi-3.5 (two stages, two-tap up-sampling) and up-sampling Mllama plans keep the two launches unless
+    composition is asked for everywhere (tests); windows below ~1/4 of the image per axis, windows outside the image and anything
+    under ADVX_TUNE_SEPARATE_CROP never compose."""
     from adversarialvlm_amd import ops
     from adversarialvlm_amd.plan import Plan
     H = W = 512
     plans = [Plan.llava(H, W), Plan.mllama(H, W), Plan.qwen2vl(H, W), Plan.phi3(H, W)]
     wins = [(0, 0, H, W), (40, 30, 400, 420), (100, 30, 343, 458)]          # the last: 0.6 of the area at ratio 3/4
-    for plan in plans[:2]:
-        assert all(ops.crop_composes(plan, H, W, w) for w in wins)
-    for plan in plans[2:]:
+    assert all(ops.crop_composes(plans[0], H, W, w) for w in wins)
+    for plan in plans[1:]:
         assert not any(ops.crop_composes(plan, H, W, w) for w in wins)
+    big = Plan.mllama(1352, 1988)                     # 1352 x 1988 -> 761 x 1120 inside a 1120 x 1120 canvas: down-sampling
+    assert ops.crop_composes(big, 1352, 1988, (100, 150, 1100, 1600))
     with ops.compose_crop_everywhere():
         for plan in plans:
             assert all(ops.crop_composes(plan, H, W, w) for w in wins)
