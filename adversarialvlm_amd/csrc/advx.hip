@@ -2590,7 +2590,6 @@ extern "C" int32_t advx_prepared_fwd(advx_plan* p, const float* pp, const float*
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   PreparedScratch f = carve_prepared(p, scratch);
-  const DStage& D = p->dstage[0];
   const long long n = 3LL * p->info.in_h * p->info.in_w;
   if (!prepared) {
     // first step, or p was changed elsewhere: s, its statistics partials and the canvas
@@ -2695,7 +2694,6 @@ static int32_t prepared_update_impl(advx_plan* p, float* pp, float* m, float* v,
   int32_t rc = check_opt(opt, m, v);
   if (rc) return rc;
   PreparedScratch f = carve_prepared(p, scratch);
-  const DStage& D = p->dstage[0];
   const long long n = 3LL * p->info.in_h * p->info.in_w;
   if (comm) {
     hipLaunchKernelGGL(k_plan_update<true>, dim3(f.tail_blocks), dim3(kBlock), 0, st, pp, m, v, grad_p, mask, x0, eps, n,

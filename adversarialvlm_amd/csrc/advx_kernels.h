@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(kBlock) k_blur(const float* __restrict__ in, i
   const int c = blockIdx.z;
   const int oy0 = blockIdx.y * kBlurTile, ox0 = blockIdx.x * kBlurTile;
   // weights: exp(-0.5 (t/sigma)^2) / sum  (torchvision _get_gaussian_kernel1d)
-  if (threadIdx.x < k) {
+  if ((int)threadIdx.x < k) {
     float t = (float)((int)threadIdx.x - r);
     float q = t / sigma;
     wgt[threadIdx.x] = expf(-0.5f * (q * q));
@@ -984,7 +984,6 @@ __device__ inline void emit_body(const DPlan& pl, const float* __restrict__ ws, 
   // zeroed once passes the columns the emits cover and [live_lo, live_hi) as their element
   // range: elements outside it inside a boundary column are written as exact zeros.
   const long long n = pl.out_numel;
-  const long long n4 = (n + 3) >> 2;
   const long long q = q_lo + (long long)block_x * blockDim.x + threadIdx.x;
   if (q >= q_hi) return;
   const long long i0 = q << 2;
