@@ -12,7 +12,10 @@ One step = fused forward (p -> 64 noisy pixel_values) -> [the VLM is not owned: 
 backward is replaced by a fixed synthetic upstream gradient g ~ N(0,1) resident in HBM]
 -> fused backward (sum over the batch, /std, image-fit term, tanh', mask, AdamW) ->
 quantise-error statistics.  With N > 1 every rank owns 64 prompts (weak scaling) and the
-shared image gradient (1.355 MB) is all-reduced once per step over RCCL.
+shared image gradient (1.355 MB) is all-reduced once per step - over the library's peer
+exchange (IPC segments over xGMI) when it passes its self-test and is not slower here, else
+over RCCL, said loudly (`config.exchange_report`, `config.exchange_fell_back`); a `strong`
+object (64 prompts in total on the same engine) is reported beside the weak `value`.
 
 `value` = prompts * steps / s over all ranks.  The VLM forward/backward (PyTorch-ROCm,
 ~1e15 FLOP per 64-prompt step) is NOT inside this number - see DESIGN.md "Measurement".
