@@ -61,6 +61,11 @@ MODEL_MAP = {
         "input_class": "AdvQwen2VLInputs",
         "processor_class": "DifferentiableQwen2VLImageProcessor",
     },
+    "synthetic/tiny-phi3v": {
+        "module": "adversarialvlm_amd.processors.synthetic_phi3v",
+        "input_class": "AdvPhiInputs",
+        "processor_class": "DifferentiablePhi3VImageProcessor",
+    },
     "synthetic/llava-1.5-7b": {
         "module": "adversarialvlm_amd.processors.synthetic",
         "input_class": "AdvLlavaInputs",

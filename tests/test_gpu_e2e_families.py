@@ -1,4 +1,5 @@
-"""GPU tier: a Llama-3.2-Vision and a Qwen2-VL ARCHITECTURE inside the loop (missing 2).
+"""GPU tier: a Llama-3.2-Vision and a Qwen2-VL ARCHITECTURE, and a twin of the Phi-3.5-Vision interface, inside the loop
+(missing 2).
 
 BASELINE configs[2..4] name Llama-3.2-11B-Vision, Qwen2-VL-7B and Phi-3.5-Vision.  No weights exist here, but the
 first two architectures ship with the installed transformers, so tiny random models of them
@@ -9,7 +10,10 @@ first two architectures ship with the installed transformers, so tiny random mod
 backward -> PixelPGD.  The oracle (oracle/pgd.py + MllamaOracle / Qwen2VLOracle) drives the SAME model on the CPU.
 Bars: loss <= 1e-4 relative, pixel gradient <= 1e-4 (L2 and elementwise).  Then one `crossattack_models.train()`
 over [tiny-llava, tiny-mllama, tiny-qwen2vl] with blur: configs[3]/[4] at the level the reference runs them
-(crossattack_models.py:352-384).  Phi-3.5-Vision's modelling code is remote code: no offline twin exists."""
+(crossattack_models.py:352-384).  Phi-3.5-Vision's processor and modelling code are remote code; `synthetic/tiny-phi3v`
+(processors/synthetic_phi3v.py) restates their INTERFACE - negative placeholder ids, `pixel_values [B, crops + 1, 3, 336, 336]`
+with the global view first, `image_sizes`, (h*w + 1)*144 + 1 + (h + 1)*12 image positions (phi3processor.py:88-95,239-302) -
+so the fourth plugin runs through the same tests, single and cross."""
 import os
 import random
 
@@ -20,7 +24,7 @@ from PIL import Image
 
 from conftest import rel_err
 from oracle.pgd import PGDOracle
-from oracle.processors import MllamaOracle, Qwen2VLOracle
+from oracle.processors import MllamaOracle, Phi3Oracle, Qwen2VLOracle
 
 pytestmark = pytest.mark.gpu
 
@@ -33,6 +37,9 @@ def _family(name, H, W):
     load, AdvInputs, DiffProc = load_components(name)
     if name.endswith("mllama"):
         oracle = MllamaOracle(tile=S.MLLAMA_TILE, max_tiles=S.MLLAMA_MAX_TILES)
+    elif name.endswith("phi3v"):
+        from adversarialvlm_amd.processors.synthetic_phi3v import PHI_NUM_CROPS
+        oracle = Phi3Oracle(num_crops=PHI_NUM_CROPS)
     else:
         oracle = Qwen2VLOracle(min_pixels=S.QWEN_MIN_PIXELS, max_pixels=S.QWEN_MAX_PIXELS)
     return load, AdvInputs, DiffProc, oracle
@@ -40,7 +47,8 @@ def _family(name, H, W):
 
 @pytest.mark.parametrize("name,size,batch", [("synthetic/tiny-mllama", (60, 90), 3), ("synthetic/tiny-mllama", (56, 56), 2),
                                              ("synthetic/tiny-mllama", (130, 40), 2), ("synthetic/tiny-qwen2vl", (60, 90), 3),
-                                             ("synthetic/tiny-qwen2vl", (84, 84), 2)])
+                                             ("synthetic/tiny-qwen2vl", (84, 84), 2), ("synthetic/tiny-phi3v", (60, 90), 2),
+                                             ("synthetic/tiny-phi3v", (130, 40), 2)])
 def test_two_pgd_steps_loss_and_grad_parity(name, size, batch):
     from adversarialvlm_amd.pgd import PixelPGD
     dev = torch.device("cuda:0")
@@ -102,7 +110,7 @@ def test_two_pgd_steps_loss_and_grad_parity(name, size, batch):
         assert rel_err(eng.p.cpu()[gmask], ora.p.detach()[gmask], elementwise=None) < 1e-3
 
 
-@pytest.mark.parametrize("name", ["synthetic/tiny-mllama", "synthetic/tiny-qwen2vl"])
+@pytest.mark.parametrize("name", ["synthetic/tiny-mllama", "synthetic/tiny-qwen2vl", "synthetic/tiny-phi3v"])
 def test_single_trainer_runs_the_family(tmp_path, name):
     """attack_model.train() end to end on the family's plugin: artefacts, finite losses, the target gets more likely,
     and the batched generation probe (it crashed for Mllama at the first save step)."""
@@ -125,10 +133,10 @@ def test_single_trainer_runs_the_family(tmp_path, name):
     assert np.all(raw[:, 40:, :] == np.float32(128 / 255)) and np.any(raw[:, :40, :40] != np.float32(128 / 255))   # the mask held
 
 
-def test_cross_trainer_three_families_with_blur(tmp_path):
+def test_cross_trainer_four_families_with_blur(tmp_path):
     """configs[3]/[4] at the reference's level: crossattack_models.train() over a LLaVA, a Mllama and a Qwen2-VL
-    architecture with Gaussian blur (sigma redrawn per step) and crop, weights, multi-answer - one engine, three
-    plans, three models' gradients summed (crossattack_models.py:352-391)."""
+    architecture and the Phi-3.5-Vision twin with Gaussian blur (sigma redrawn per step) and crop, weights, multi-answer - one engine, four
+    plans, four models' gradients summed (crossattack_models.py:352-391)."""
     import json
 
     from adversarialvlm_amd import crossattack_models
@@ -137,14 +145,14 @@ def test_cross_trainer_three_families_with_blur(tmp_path):
     Image.fromarray(np.full((70, 70, 3), 128, np.uint8)).save(path)
     ans = os.path.join(tmp, "answers.json")
     json.dump(["sure here it is", "of course the answer is"], open(ans, "w"))
-    names = ["synthetic/tiny-llava", "synthetic/tiny-mllama", "synthetic/tiny-qwen2vl"]
+    names = ["synthetic/tiny-llava", "synthetic/tiny-mllama", "synthetic/tiny-qwen2vl", "synthetic/tiny-phi3v"]
     eng, hist = crossattack_models.train(
         exp_name="cross3", img_orig=path, prompt="list", target_text="unused", model_names=names, lr=1e-2, num_iterations=3,
         save_steps=2, batch_size=2, grad_accum_steps=1, scheduler_step_size=100, scheduler_gamma=0.9, restart_num=0,
         mask_type=None, mask_size=None, clamp_method="tanh", epsilon=0.4, sigma=1e-3, start_from_white=False,
-        target_text_random=True, answers_file=ans, DPO_flag=False, model_weights=[0.5, 0.3, 0.2], use_gaussian_blur=True,
+        target_text_random=True, answers_file=ans, DPO_flag=False, model_weights=[0.4, 0.3, 0.2, 0.1], use_gaussian_blur=True,
         gblur_kernel_size=5, use_local_crop=True, base_path=tmp, return_engine=True, generation_probe=True, seed=2)
-    assert len(eng.plans) == 3 and eng.mode == "generic"
+    assert len(eng.plans) == 4 and eng.mode == "generic"
     assert len(hist) == 3 and all(np.isfinite(h["loss_per_iteration"]) for h in hist)
     for h in hist:
         per_model = [h[f"loss_{i}_{n.replace('/', '_')}"] for i, n in enumerate(names)]

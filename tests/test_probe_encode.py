@@ -62,3 +62,36 @@ def test_qwen2vl_batches_equal_one_processor_call(size):
     n_img = int((got["input_ids"][0] == proc.image_token_id).sum())
     t, gh, gw = got["image_grid_thw"][0].tolist()
     assert n_img == t * gh * gw // 4                      # one placeholder per merged 2x2 patch group
+
+
+@pytest.mark.parametrize("size", [(60, 90), (130, 40), (56, 56), (336, 336), (100, 400)])
+def test_phi3v_twin_batches_equal_the_reference_assembly(size):
+    """get_inputs_train() of the Phi-3.5 plugin (cached tokenisation, image_sizes from the PLAN) against what the
+    reference assembles per step - one processor call per prompt, pad_left, cat (phi3processor.py:275-311) - on the twin of
+    the remote processor (processors/synthetic_phi3v.py): key by key.  The number of negative placeholder ids equals the
+    plan's num_img_tokens, i.e. the HD geometry of the HIP path (C side) and of the twin's PIL path agree."""
+    from adversarialvlm_amd.processors.synthetic_phi3v import (AdvPhiInputs, DifferentiablePhi3VImageProcessor, phi3v_processor)
+    from adversarialvlm_amd.processors.phi3processor import pad_left
+    proc, _ = phi3v_processor()
+    H, W = size
+    img = _image(H, W)
+    adv = DifferentiablePhi3VImageProcessor(proc.image_processor, "cpu")
+    ip = AdvPhiInputs(questions=QUESTIONS, test_questions=["hi"], batch_size=4, original_image=img, processor=proc,
+                      device="cpu", target_text="sure here it is", rng=random.Random(4))
+    assert ip.shift == 1                                   # BOS is the "extra" token of phi3processor.py:61
+    ip.bind_geometry(adv, H, W)
+    for _ in range(2):
+        state = ip.rng.getstate()
+        got = ip.get_inputs_train()
+        ip.rng.setstate(state)
+        drawn = ip.rng.choices(QUESTIONS, k=4)
+        encs = [proc(ip._render_train(q, ip.target_text), [img], return_tensors="pt") for q in drawn]
+        ids = pad_left([e.input_ids[0] for e in encs], proc.tokenizer.pad_token_id)
+        want = {"input_ids": ids, "attention_mask": (ids != proc.tokenizer.pad_token_id).long(),
+                "image_sizes": torch.cat([e.image_sizes for e in encs], 0)}
+        assert set(got.keys()) == set(want.keys())
+        for k in want:
+            assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k]), k
+    info = adv.plan_for(H, W).info
+    assert int((got["input_ids"][0] < 0).sum()) == int(info.num_img_tokens)
+    assert tuple(encs[0].pixel_values.shape[1:]) == tuple(adv.plan_for(H, W).out_shape[1:])
