@@ -14,7 +14,7 @@ random-init Llama-3.2-Vision (mllama) and Qwen2-VL models small enough for a CPU
 These are what puts the wiring of `attack_model.py:314-328` with `llama32processor.py:119-147,360-405`
 (`pixel_values [B,1,4,3,T,T]`, `aspect_ratio_ids/mask`, `cross_attention_mask`) and
 `qwen2VLprocessor.py:68-96,211-272` (`[B*n_patches, 1176]` + `image_grid_thw`) in front of a model's `forward`
-without weights or a network (tests/test_gpu_e2e_families.py).  Phi-3.5-Vision is remote code: no offline twin.
+without weights or a network (tests/test_gpu_e2e_families.py).  Phi-3.5-Vision is remote code: its interface twin lives in synthetic_phi3v.py.
 """
 import torch
 
