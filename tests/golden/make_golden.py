@@ -413,18 +413,63 @@ def golden_index_tensors():
          mllama_aspect_ratio_mask=np.asarray(masks, np.int64), mllama_num_tiles=np.asarray(tiles, np.int64),
          qwen_geometry=np.asarray(QWEN_GEOMETRIES, np.int64), qwen_grid_thw_rows_cols=np.asarray(grids, np.int64))
 
+def golden_full_size(llava, qwen, phi3, mllama):
+    """Captures at BASELINE's two image sizes (336 x 336 synthetic, 512 x 512 `images/gray.png`) with the models' real
+    processor parameters, for every family: pixel_values and image.grad of the reference classes, stored as checksums and
+    sampled entries (inputs are rebuilt from their salts).  A file of its own, so the older fixtures regenerate bit for bit."""
+    def ns(**kw):
+        return SimpleNamespace(image_mean=CLIP_MEAN, image_std=CLIP_STD, do_convert_rgb=True, **kw)
+    makers = {
+        "llava": lambda: llava.DifferentiableLlavaImageProcessor(ns(crop_size={"height": 336, "width": 336}), "cpu"),
+        "qwen2vl": lambda: qwen.DifferentiableQwen2VLImageProcessor(
+            ns(patch_size=14, merge_size=2, temporal_patch_size=2, min_pixels=56 * 56, max_pixels=28 * 28 * 1280), "cpu"),
+        "phi3": lambda: phi3.DifferentiablePhi3VImageProcessor(ns(num_crops=6, num_img_tokens=144), "cpu"),
+        "mllama": lambda: mllama.DifferentiableMllamaImageProcessor(
+            ns(do_normalize=True, size={"height": 560, "width": 560}, max_image_tiles=4, rescale_factor=1 / 255), "cpu"),
+    }
+    arrays, salt = {}, 500
+    for fam, make in makers.items():
+        for (H, W) in ((336, 336), (512, 512), (400, 600)):
+            salt += 2
+            proc = make()
+            img = lcg_tensor((3, H, W), salt) + 0.5
+            img.requires_grad_(True)
+            out = proc.process(img)
+            pv = out["pixel_values"]
+            pv.backward(lcg_tensor(pv.shape, salt + 1))
+            idx = np.arange(0, pv.numel(), 4999)
+            gidx = np.arange(0, img.numel(), 499)
+            k = f"{fam}_{H}x{W}"
+            extra = [int(v) for key in ("num_tiles", "image_sizes", "num_img_tokens") if key in out and out[key] is not None
+                     for v in np.asarray(out[key]).reshape(-1)]
+            arrays.update({f"{k}_salt": np.array(salt), f"{k}_shape": np.array(pv.shape), f"{k}_ints": np.array(extra, dtype=np.int64),
+                           f"{k}_pv_sum": pv.detach().double().sum(), f"{k}_pv_sumsq": (pv.detach().double() ** 2).sum(),
+                           f"{k}_pv_idx": idx, f"{k}_pv_val": pv.detach().flatten()[idx],
+                           f"{k}_grad_sum": img.grad.double().sum(), f"{k}_grad_sumsq": (img.grad.double() ** 2).sum(),
+                           f"{k}_grad_idx": gidx, f"{k}_grad_val": img.grad.flatten()[gidx]})
+    save("full_size_reference.npz", **arrays)
+
 
 def main():
+    """python tests/golden/make_golden.py [--only full_size]   (--only: just that fixture file, the others stay untouched)"""
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present: fixtures can only be regenerated in the build container")
-    golden_index_tensors()        # before the torchvision stub of import_reference() exists
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    if only not in (None, "full_size"):
+        raise SystemExit("--only knows: full_size")
+    if only is None:
+        golden_index_tensors()        # before the torchvision stub of import_reference() exists
     llava, qwen, phi3 = import_reference()
+    mllama = import_reference_mllama()
+    golden_full_size(llava, qwen, phi3, mllama)
+    if only is not None:
+        return
     golden_llava(llava)
     golden_qwen(qwen)
     golden_phi3(phi3)
     golden_suffix_loss(llava)
     golden_mllama_helpers()
-    golden_mllama_reference(import_reference_mllama())
+    golden_mllama_reference(mllama)
     golden_trainer_helpers(import_reference_trainer())
     golden_closed_form()
     golden_mllama_restated()

@@ -387,3 +387,36 @@ def test_forward_multi_is_image_fwd_then_emit_multi(dev, blur, crop):
         for a, b in zip(*runs):
             assert torch.equal(a, b)
         assert float(runs[0][-1][L.STAT_SIGMA]) == pytest.approx(0.02)     # rotated from the previous QERR_STD
+
+
+@pytest.mark.parametrize("fam", ["llava", "qwen2vl", "phi3", "mllama"])
+@pytest.mark.parametrize("size", [(336, 336), (512, 512), (400, 600)])
+def test_full_size_reference_captures(dev, fam, size):
+    """The HIP processors at BASELINE's image sizes with the models' real parameters, DIRECTLY against captures from the
+    reference's own classes (full_size_reference.npz: checksums + sampled entries of pixel_values and image.grad) - not
+    through the oracle."""
+    from adversarialvlm_amd.plan import Plan
+    g = load_golden("full_size_reference.npz")
+    H, W = size
+    k = f"{fam}_{H}x{W}"
+    salt = int(g[f"{k}_salt"])
+    plan = {"llava": lambda: Plan.llava(H, W), "qwen2vl": lambda: Plan.qwen2vl(H, W), "phi3": lambda: Plan.phi3(H, W, num_crops=6),
+            "mllama": lambda: Plan.mllama(H, W, tile=560, max_tiles=4)}[fam]()
+    shape = tuple(int(v) for v in g[f"{k}_shape"])
+    assert tuple(plan.out_shape) == shape
+    pv, grad = _run(plan, lcg_tensor((3, H, W), salt) + 0.5, lcg_tensor(shape, salt + 1), dev)
+    d = pv.double()
+    assert abs(float(d.sum()) - float(g[f"{k}_pv_sum"])) <= 2e-6 * float(d.abs().sum())
+    assert abs(float((d * d).sum()) - float(g[f"{k}_pv_sumsq"])) <= 1e-5 * float(g[f"{k}_pv_sumsq"])
+    assert rel_err(pv.flatten()[g[f"{k}_pv_idx"]], g[f"{k}_pv_val"]) < TIGHT
+    gd = grad.double()
+    assert abs(float((gd * gd).sum()) - float(g[f"{k}_grad_sumsq"])) <= 1e-5 * float(g[f"{k}_grad_sumsq"])
+    assert rel_err(grad.flatten()[g[f"{k}_grad_idx"]], g[f"{k}_grad_val"]) < TIGHT
+    ints = [int(v) for v in g[f"{k}_ints"]]
+    i = plan.info
+    if fam == "phi3":
+        assert [int(i.image_h), int(i.image_w), int(i.num_img_tokens)] == ints
+    elif fam == "mllama":
+        assert [int(i.num_tiles)] == ints
+    elif fam == "qwen2vl":
+        assert [int(i.grid_h) * int(i.grid_w)] == ints

@@ -212,3 +212,43 @@ def test_create_mask_against_the_reference_function(k):
         assert float(m.double().sum()) == float(g[f"mask{k}_sum"])
         assert bool((m.flatten()[torch.tensor(g[f"mask{k}_idx"])] == 1).all())
         assert set(m.unique().tolist()) <= {0.0, 1.0}
+
+
+FULL_CASES = [(f, s) for f in ("llava", "qwen2vl", "phi3", "mllama") for s in ((336, 336), (512, 512), (400, 600))]
+
+
+def _full_oracle(fam):
+    return {"llava": LlavaOracle(336, 336), "qwen2vl": Qwen2VLOracle(), "phi3": Phi3Oracle(num_crops=6),
+            "mllama": MllamaOracle(tile=560, max_tiles=4)}[fam]
+
+
+def _ints(out):
+    vals = []
+    for key in ("num_tiles", "image_sizes", "num_img_tokens"):
+        if key in out and out[key] is not None:
+            vals += [int(v) for v in np.asarray(out[key]).reshape(-1)]
+    return vals
+
+
+@pytest.mark.parametrize("fam,size", FULL_CASES)
+def test_full_size_reference_captures(fam, size):
+    """BASELINE's image sizes (336 x 336, 512 x 512) and one non-square one through the reference's own processor classes
+    with the models' real parameters (tile 560 / 4 tiles, num_crops 6, 56^2..28^2*1280 pixels, crop 336): checksums, sampled
+    entries and the integer side outputs (full_size_reference.npz, make_golden.py: golden_full_size)."""
+    g = load_golden("full_size_reference.npz")
+    H, W = size
+    k = f"{fam}_{H}x{W}"
+    salt = int(g[f"{k}_salt"])
+    img = (lcg_tensor((3, H, W), salt) + 0.5).requires_grad_(True)
+    out = _full_oracle(fam).process(img)
+    pv = out["pixel_values"]
+    assert tuple(pv.shape) == tuple(int(v) for v in g[f"{k}_shape"])
+    assert _ints(out) == [int(v) for v in g[f"{k}_ints"]]
+    pv.backward(lcg_tensor(pv.shape, salt + 1))
+    d = pv.detach().double()
+    assert abs(float(d.sum()) - float(g[f"{k}_pv_sum"])) <= 1e-6 * float(d.abs().sum())
+    assert abs(float((d * d).sum()) - float(g[f"{k}_pv_sumsq"])) <= 1e-6 * float(g[f"{k}_pv_sumsq"])
+    assert rel_err(pv.detach().flatten()[g[f"{k}_pv_idx"]], g[f"{k}_pv_val"]) <= TOL
+    gd = img.grad.double()
+    assert abs(float((gd * gd).sum()) - float(g[f"{k}_grad_sumsq"])) <= 1e-6 * float(g[f"{k}_grad_sumsq"])
+    assert rel_err(img.grad.flatten()[g[f"{k}_grad_idx"]], g[f"{k}_grad_val"]) <= TOL
