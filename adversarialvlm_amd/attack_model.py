@@ -184,13 +184,15 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
           use_wandb=False, seed=0, base_path="./runs", components=None, return_engine=False,
           generation_probe=False, resume_from=None, pixel_io="float32", resaved_loss_every=0,
           noise_on_padding=True, suffix_only_ce=False, replica_check_every=None, exchange_transport="auto",
-          exchange_timeout_s=EXCHANGE_TIMEOUT_S):
+          exchange_timeout_s=EXCHANGE_TIMEOUT_S, unit_noise_fn=None):
     """pixel_io: "float32" hands the VLM fp32 pixel_values as the reference does; "model" lets
     the fused pair write them in model.dtype (the cast the vision tower's patch embedding applies
     first anyway) and read the half gradient directly - same numbers, half the traffic.
     replica_check_every (data parallelism): every so many iterations (default: save_steps) all ranks compare
     digests of (p, m, v) and the peer exchange's time-out word; on a mismatch every rank writes its state and
-    raises dp.ReplicaError."""
+    raises dp.ReplicaError.
+    unit_noise_fn (parity tests): callable(iteration, shape) -> N(0, 1) draws on the CPU that replace the in-kernel generator,
+    so that a run can be laid beside one of the reference's `train()` (tests/test_gpu_trainer_vs_reference_run.py)."""
     if pixel_io not in ("float32", "model"):
         raise ValueError("pixel_io must be 'float32' or 'model'")
     if clamp_method != "tanh":
@@ -288,7 +290,10 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
         crop = None
         if use_local_crop:
             crop = random_resized_crop_params(H, W, (crop_scale_min, crop_scale_max), (crop_ratio_min, crop_ratio_max))
-        pixel_values = engine.forward(local_batch, blur_sigma=float(gblur_sigma) if use_gaussian_blur else None,
+        given = None
+        if unit_noise_fn is not None:
+            given = [unit_noise_fn(iteration, (local_batch * plan.out_shape[0],) + tuple(plan.out_shape[1:])).to(device)]
+        pixel_values = engine.forward(local_batch, unit_noises=given, blur_sigma=float(gblur_sigma) if use_gaussian_blur else None,
                                       crop=crop)[0]                                         # :300-321 (HIP)
         pixel_values.requires_grad_(True)
         inputs["pixel_values"] = pixel_values
