@@ -49,9 +49,11 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
           questions_file=None, test_questions_file=None, answers_file=None, log_every=1, use_wandb=False, seed=0,
           base_path="./runs", return_engine=False, resaved_loss_every=0, noise_on_padding=True,
           suffix_only_ce=False, pixel_io="float32", components=None, generation_probe=False, resume_from=None,
-          replica_check_every=None, exchange_transport="auto", exchange_timeout_s=EXCHANGE_TIMEOUT_S):
+          replica_check_every=None, exchange_transport="auto", exchange_timeout_s=EXCHANGE_TIMEOUT_S, unit_noise_fn=None):
     """components: optional {model_name: (load_model_and_processor, AdvInputs, DiffProc)} overriding the registry
-    (tests).  generation_probe / resume_from / replica_check_every: as in attack_model.train."""
+    (tests).  generation_probe / resume_from / replica_check_every: as in attack_model.train.
+    unit_noise_fn (parity tests): callable(iteration, model index, shape) -> N(0, 1) draws on the CPU that replace the in-kernel
+    generator (tests/test_gpu_trainer_vs_reference_run.py lays a run beside one of the reference's `train()`)."""
     if clamp_method != "tanh":
         raise NotImplementedError("Clamping method except tanh are not implemented yet.")
     if mask_type == "random_square":
@@ -173,7 +175,11 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
         crop = None
         if use_local_crop:
             crop = random_resized_crop_params(H, W, (crop_scale_min, crop_scale_max), (crop_ratio_min, crop_ratio_max))
-        pvs = engine.forward(local_batch, blur_sigma=blur_sigma, crop=crop)                 # :329-362 (HIP)
+        given = None
+        if unit_noise_fn is not None:
+            given = [unit_noise_fn(iteration, i, (local_batch * pl.out_shape[0],) + tuple(pl.out_shape[1:])).to(device)
+                     for i, pl in zip(my_models, plans)]
+        pvs = engine.forward(local_batch, unit_noises=given, blur_sigma=blur_sigma, crop=crop)   # :329-362 (HIP)
         grads, losses, step_inputs = [], [], []
         for k, (model, ip, pv) in enumerate(zip(models, inputs_processors, pvs)):           # :352-384
             inputs = ip.get_inputs_train()

@@ -552,14 +552,118 @@ def golden_trainer_run(am, llava):
             shutil.rmtree(tmp, ignore_errors=True)
     save("trainer_run_reference.npz", **arrays)
 
+def golden_cross_trainer_run(llava, qwen, mllama):
+    """The reference's OWN `crossattack_models.train()` (crossattack_models.py:124-519) on the CPU: (x1) two tiny random
+    LLaVA models with weights 0.7 / 0.3, batch 2, gradient accumulation 2, StepLR decay, a corner mask; (x2) one model of each
+    family whose architecture ships with transformers - LLaVA, Llama-3.2-Vision, Qwen2-VL (adversarialvlm_amd/processors/
+    synthetic*.py) - behind the reference's own AdvLlavaInputs / AdvMllamaInputs / AdvQwen2VLInputs and Differentiable*Processor
+    classes, batch 1 (the reference hands the HF Mllama processor a flat image list, which transformers 5.x accepts for one
+    prompt only).  Stand-ins as in golden_trainer_run: loader, wandb recorder, neutral question pools, scratch directory.
+    Per iteration and model the loop draws `torch.randn_like(pixel_values_i)` from the global CPU generator, in model order,
+    after the models were built in model order - a test rebuilds the draws from that."""
+    import importlib
+    import random
+    import shutil
+    import tempfile
+
+    from PIL import Image
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from adversarialvlm_amd.processors import synthetic, synthetic_vlms
+
+    import_reference_trainer()                      # placeholders for wandb / torchvision names
+    cm = importlib.import_module("crossattack_models")
+
+    class Recorder(types.ModuleType):
+        def __init__(self):
+            super().__init__("wandb")
+            self.rows = []
+            self.Table = type("Table", (), {"__init__": lambda self, *a, **k: None, "add_data": lambda self, *a: None})
+            self.Image = lambda *a, **k: None
+
+        def init(self, **kw):
+            self.rows = []
+
+        def log(self, d):
+            self.rows.append({k: (float(v) if (torch.is_tensor(v) or isinstance(v, (int, float, np.floating))) and not isinstance(v, bool)
+                                  else None) for k, v in d.items()})
+
+        def finish(self):
+            pass
+
+    rec = Recorder()
+    sys.modules["wandb"] = rec
+    cm.wandb = rec
+    q, a = types.ModuleType("questions"), types.ModuleType("answers")
+    q.questions, q.not_safe_questions, q.not_safe_questions_test = ["describe this image"], ["what is shown here"], ["hi"]
+    a.answers, a.adv_answers = ["sure here it is"], ["of course"]
+    sys.modules["questions"], sys.modules["answers"] = q, a
+
+    def load_qwen(name, dev):
+        model, proc = synthetic_vlms.load_model_and_processor("synthetic/tiny-qwen2vl", dev, seed=3)
+        # transformers 4.51 (the reference's pin) kept the pixel bounds as attributes; 5.x keeps them in `size`
+        proc.image_processor.min_pixels, proc.image_processor.max_pixels = synthetic_vlms.QWEN_MIN_PIXELS, synthetic_vlms.QWEN_MAX_PIXELS
+        return model, proc
+
+    table = {
+        "tiny-llava-0": (lambda name, dev: synthetic.load_model_and_processor("synthetic/tiny-llava", dev, seed=0),
+                         llava.AdvLlavaInputs, llava.DifferentiableLlavaImageProcessor),
+        "tiny-llava-1": (lambda name, dev: synthetic.load_model_and_processor("synthetic/tiny-llava", dev, seed=1),
+                         llava.AdvLlavaInputs, llava.DifferentiableLlavaImageProcessor),
+        "tiny-mllama": (lambda name, dev: synthetic_vlms.load_model_and_processor("synthetic/tiny-mllama", dev, seed=2),
+                        mllama.AdvMllamaInputs, mllama.DifferentiableMllamaImageProcessor),
+        "tiny-qwen2vl": (load_qwen, qwen.AdvQwen2VLInputs, qwen.DifferentiableQwen2VLImageProcessor),
+    }
+    cm.load_components = lambda name: table[name]
+
+    runs = [("x1", ["tiny-llava-0", "tiny-llava-1"], dict(batch_size=2, grad_accum_steps=2, scheduler_step_size=1, scheduler_gamma=0.5,
+                                                         mask_type="corner", mask_size=30, model_weights=[0.7, 0.3]), (64, 48), 6, 21),
+            ("x2", ["tiny-llava-0", "tiny-mllama", "tiny-qwen2vl"],
+             dict(batch_size=1, grad_accum_steps=1, scheduler_step_size=100, scheduler_gamma=0.9, mask_type=None, mask_size=None,
+                  model_weights=None), (60, 90), 3, 22)]
+    arrays = {}
+    cwd = os.getcwd()
+    for name, names, kw, (H, W), iters, seed in runs:
+        tmp = tempfile.mkdtemp()
+        os.chdir(tmp)
+        try:
+            rng = np.random.default_rng(seed)
+            img = (rng.random((H, W, 3)) * 255).astype(np.uint8)
+            img[: H // 4, : W // 3] = 0
+            Image.fromarray(img).save("in.png")
+            random.seed(seed)
+            torch.manual_seed(seed)
+            cm.train(exp_name="run", img_orig="in.png", prompt="describe this image", target_text="sure here it is",
+                     model_names=names, lr=1e-2, num_iterations=iters, save_steps=2, restart_num=0, clamp_method="tanh", epsilon=0.4,
+                     sigma=1e-3, start_from_white=False, target_text_random=False, DPO_flag=False, attack_norm=0.4, **kw)
+            per_iter = [r for r in rec.rows if "loss_per_iteration" in r]
+            assert len(per_iter) == iters
+            keys = ["loss_per_iteration", "img_loss", "loss_resaved", "resave_error_mean", "resave_error_std", "resave_error_l1",
+                    "noise_std", "adversarial_mean", "adversarial_std", "lr", "grad_norm", "global_iteration"]
+            for k in keys:
+                arrays[f"{name}_{k}"] = np.array([r[k] for r in per_iter], dtype=np.float64)
+            arrays[f"{name}_model_losses"] = np.array([[r[f"loss_{i}_{mn}"] for i, mn in enumerate(names)] for r in per_iter])
+            arrays[f"{name}_names"] = np.array(names)
+            arrays[f"{name}_image"] = img
+            arrays[f"{name}_iters"], arrays[f"{name}_batch"], arrays[f"{name}_accum"] = np.array(iters), np.array(kw["batch_size"]), np.array(kw["grad_accum_steps"])
+            arrays[f"{name}_sched"] = np.array([kw["scheduler_step_size"], kw["scheduler_gamma"]], dtype=np.float64)
+            arrays[f"{name}_mask"] = np.array([{"corner": 0, "bottom_lines": 1, None: -1}[kw["mask_type"]], kw["mask_size"] or 0])
+            arrays[f"{name}_weights"] = np.array(kw["model_weights"] or [1.0] * len(names))
+            arrays[f"{name}_final"] = np.fromfile(os.path.join("runs", "run", "optimized_image_iter_final.bin"), dtype=np.float32)
+            arrays[f"{name}_files"] = np.array(sorted(os.listdir(os.path.join("runs", "run"))))
+        finally:
+            os.chdir(cwd)
+            shutil.rmtree(tmp, ignore_errors=True)
+    save("cross_trainer_run_reference.npz", **arrays)
+
 
 def main():
     """python tests/golden/make_golden.py [--only full_size]   (--only: just that fixture file, the others stay untouched)"""
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present: fixtures can only be regenerated in the build container")
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
-    if only not in (None, "full_size", "trainer_run"):
-        raise SystemExit("--only knows: full_size, trainer_run")
+    if only not in (None, "full_size", "trainer_run", "cross_trainer_run"):
+        raise SystemExit("--only knows: full_size, trainer_run, cross_trainer_run")
     if only is None:
         golden_index_tensors()        # before the torchvision stub of import_reference() exists
     llava, qwen, phi3 = import_reference()
@@ -568,6 +672,8 @@ def main():
         golden_full_size(llava, qwen, phi3, mllama)
     if only == "trainer_run":
         golden_trainer_run(import_reference_trainer(), llava)
+    if only == "cross_trainer_run":
+        golden_cross_trainer_run(llava, qwen, mllama)
     if only is not None:
         return
     golden_llava(llava)
@@ -579,7 +685,8 @@ def main():
     golden_trainer_helpers(import_reference_trainer())
     golden_closed_form()
     golden_mllama_restated()
-    golden_trainer_run(import_reference_trainer(), llava)      # last: it replaces the wandb placeholder by a recorder
+    golden_trainer_run(import_reference_trainer(), llava)      # last: these replace the wandb placeholder by a recorder
+    golden_cross_trainer_run(llava, qwen, mllama)
 
 
 if __name__ == "__main__":

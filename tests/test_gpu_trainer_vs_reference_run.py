@@ -80,3 +80,55 @@ def test_train_equals_the_reference_trainers_run(tmp_path, n):
     assert not extra, sorted(extra)                                                           # no checkpoint the reference did not write
     mask = torch.load(os.path.join(run, "mask.pt"))
     assert float(mask.sum()) == float(g[f"{n}_mask_sum"])
+
+
+@pytest.mark.parametrize("n", ["x1", "x2"])
+def test_cross_train_equals_the_reference_cross_trainers_run(tmp_path, n):
+    """`crossattack_models.train()` of this package beside the reference's own (cross_trainer_run_reference.npz): x1 two LLaVA
+    models with weights and gradient accumulation; x2 one model of each family whose architecture ships with transformers, the
+    reference side running its own AdvMllamaInputs / AdvQwen2VLInputs / Differentiable*Processor classes.  Per model
+    w_i CE_i + image loss (:369), their mean, `loss_resaved`, the quantise-error statistics, gradient norm, learning rate,
+    optimiser-step count, the final image and the checkpoint names."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_trainer_run import cross_setup
+
+    from adversarialvlm_amd import crossattack_models
+    g = load_golden("cross_trainer_run_reference.npz")
+    s = cross_setup(g, n)                                   # builds the models on the CPU in the run's order, then the draws
+    names, iters, accum = s["names"], s["iters"], s["opt"]["grad_accum_steps"]
+    kind, size = (int(v) for v in g[f"{n}_mask"])
+    tmp = str(tmp_path)
+    Image.fromarray(g[f"{n}_image"]).save(os.path.join(tmp, "in.png"))
+    components = {m: ((lambda name, device, m=m: s["fam"][m][0](device)), s["fam"][m][1], s["fam"][m][2]) for m in names}
+    eng, hist = crossattack_models.train(
+        exp_name="run", img_orig=os.path.join(tmp, "in.png"), prompt="describe this image", target_text="sure here it is",
+        model_names=names, lr=1e-2, num_iterations=iters, save_steps=2, batch_size=s["B"], grad_accum_steps=accum,
+        scheduler_step_size=s["opt"]["scheduler_step_size"], scheduler_gamma=s["opt"]["scheduler_gamma"], restart_num=0,
+        mask_type={0: "corner", 1: "bottom_lines", -1: None}[kind], mask_size=size if kind >= 0 else None, clamp_method="tanh",
+        epsilon=0.4, sigma=1e-3, start_from_white=False, target_text_random=False, DPO_flag=False, attack_norm=0.4,
+        model_weights=s["weights"], base_path=tmp, components=components, return_engine=True, resaved_loss_every=1, log_every=1,
+        unit_noise_fn=lambda it, i, shape: s["zs"][it][i].view(shape))
+    assert len(hist) == iters
+    npx = g[f"{n}_final"].size
+    for t, h in enumerate(hist):
+        where = (n, t)
+        for i, m in enumerate(names):
+            assert _close(h[f"loss_{i}_{m}"], g[f"{n}_model_losses"][t][i], 1e-4), (where, i)
+        assert _close(h["loss_per_iteration"], g[f"{n}_loss_per_iteration"][t], 1e-4), where
+        assert _close(h["img_loss"], g[f"{n}_img_loss"][t], 1e-4), where
+        assert _close(h["loss_resaved"], g[f"{n}_loss_resaved"][t], 1e-4), where
+        assert _close(h["grad_norm"], g[f"{n}_grad_norm"][t], 1e-3), where
+        assert _close(h["lr"], g[f"{n}_lr"][t], 1e-6) and int(h["global_iteration"]) == int(g[f"{n}_global_iteration"][t]), where
+        assert abs(h["resave_error_std"] - g[f"{n}_resave_error_std"][t]) <= 1e-4 * g[f"{n}_resave_error_std"][t] + 2 / (255 * (npx - 1) ** 0.5), where
+        assert _close(h["adversarial_mean"], g[f"{n}_adversarial_mean"][t], 1e-3, 1e-6), where
+        assert _close(h["adversarial_std"], g[f"{n}_adversarial_std"][t], 1e-3, 1e-6), where
+    run = os.path.join(tmp, "run")
+    final = np.fromfile(os.path.join(run, "optimized_image_iter_final.bin"), dtype=np.float32)
+    want = g[f"{n}_final"]
+    assert final.shape == want.shape
+    assert float(np.abs(final - want).max()) <= 2e-3 * 0.4 and rel_err(torch.tensor(final), torch.tensor(want), elementwise=None) < 1e-4
+    ours = set(os.listdir(run))
+    theirs = {str(f) for f in g[f"{n}_files"] if not str(f).startswith("test_results")}
+    assert theirs <= ours, sorted(theirs - ours)
+    assert not {f for f in ours - theirs if f.startswith("optimized_image")}

@@ -101,3 +101,90 @@ def test_oracle_loop_reproduces_the_reference_trainers_log(n):
         last_s = ref["s"]
     # the image written at the end is x_0 + x of the LAST iteration's forward, i.e. before that iteration's update (:473-477)
     assert rel_err(last_s.flatten(), g[f"{n}_final"]) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------ the cross-model trainer
+CROSS = ["x1", "x2"]
+
+
+def cross_setup(g, n, device="cpu"):
+    """Models built in the reference run's order (that is where its loop found the CPU generator), then its noise draws."""
+    from adversarialvlm_amd.processors import synthetic, synthetic_vlms as S
+    from oracle.processors import MllamaOracle, Qwen2VLOracle
+    fam = {"tiny-llava-0": (lambda d: synthetic.load_model_and_processor("synthetic/tiny-llava", d, seed=0), synthetic.AdvLlavaInputs,
+                            synthetic.DifferentiableLlavaImageProcessor, lambda: LlavaOracle(56, 56)),
+           "tiny-llava-1": (lambda d: synthetic.load_model_and_processor("synthetic/tiny-llava", d, seed=1), synthetic.AdvLlavaInputs,
+                            synthetic.DifferentiableLlavaImageProcessor, lambda: LlavaOracle(56, 56)),
+           "tiny-mllama": (lambda d: S.load_model_and_processor("synthetic/tiny-mllama", d, seed=2), S.AdvMllamaInputs,
+                           S.DifferentiableMllamaImageProcessor, lambda: MllamaOracle(tile=S.MLLAMA_TILE, max_tiles=S.MLLAMA_MAX_TILES)),
+           "tiny-qwen2vl": (lambda d: S.load_model_and_processor("synthetic/tiny-qwen2vl", d, seed=3), S.AdvQwen2VLInputs,
+                            S.DifferentiableQwen2VLImageProcessor,
+                            lambda: Qwen2VLOracle(min_pixels=S.QWEN_MIN_PIXELS, max_pixels=S.QWEN_MAX_PIXELS))}
+    names = [str(v) for v in g[f"{n}_names"]]
+    loaded = [fam[m][0]("cpu") for m in names]                     # always on the CPU first: the draws follow
+    img = g[f"{n}_image"]
+    x0 = torch.tensor(img.astype(np.float32) / 255).permute(2, 0, 1).contiguous()
+    oracles = [fam[m][3]() for m in names]
+    B, iters = int(g[f"{n}_batch"]), int(g[f"{n}_iters"])
+    shapes = []
+    for o in oracles:
+        pv = o.process(x0)["pixel_values"]
+        shapes.append((B * pv.shape[0],) + tuple(pv.shape[1:]))
+    zs = [[torch.randn(sh) for sh in shapes] for _ in range(iters)]
+    kind, size = (int(v) for v in g[f"{n}_mask"])
+    mask = P.create_mask({0: "corner", 1: "bottom_lines"}[kind], size, x0.shape) if kind >= 0 else (x0 != 0).float()
+    step, gamma = g[f"{n}_sched"]
+    return dict(names=names, fam=fam, loaded=loaded, x0=x0, oracles=oracles, B=B, iters=iters, zs=zs, mask=mask,
+                img=Image.fromarray(img), weights=[float(w) for w in g[f"{n}_weights"]],
+                opt=dict(lr=1e-2, epsilon=0.4, sigma0=1e-3, scheduler_step_size=int(step), scheduler_gamma=float(gamma),
+                         grad_accum_steps=int(g[f"{n}_accum"])))
+
+
+@pytest.mark.parametrize("n", CROSS)
+def test_oracle_loop_reproduces_the_reference_cross_trainers_log(n):
+    """oracle/pgd.py in cross mode against the reference's OWN `crossattack_models.train()` (cross_trainer_run_reference.npz):
+    x1 two LLaVA models, weights 0.7 / 0.3, accumulation 2 (which only changes the optimiser's cadence there, :349-350),
+    StepLR; x2 a LLaVA, a Llama-3.2-Vision and a Qwen2-VL architecture behind the reference's own plugin classes.  Logged per
+    model: w_i CE_i + image loss (:369); `loss_resaved` = mean of the models' CE on the re-saved image (:434-447)."""
+    g = load_golden("cross_trainer_run_reference.npz")
+    s = cross_setup(g, n)
+    models = [m for m, _ in s["loaded"]]
+    ips = [s["fam"][m][1](questions=["describe this image"], test_questions=["hi"], batch_size=s["B"], original_image=s["img"],
+                          processor=proc, device="cpu", target_text="sure here it is", rng=random.Random(0))
+           for m, (_, proc) in zip(s["names"], s["loaded"])]
+    ora = PGDOracle(s["x0"], s["oracles"], mask=s["mask"], model_weights=s["weights"], cross_mode=True, **s["opt"])
+    k = len(models)
+    for t in range(s["iters"]):
+        inputs = [ip.get_inputs_train() for ip in ips]
+        sigma = float(ora.sigma)
+        assert close((s["zs"][t][-1] * sigma).std(), g[f"{n}_noise_std"][t], 1e-5, 1e-12)      # `noise` of the last model is logged
+        ora.forward(s["B"], s["zs"][t])
+        ces = [None] * k
+
+        def make(i):
+            def loss_fn(pv):
+                out = models[i](**{kk: vv for kk, vv in inputs[i].items() if kk != "pixel_values"}, pixel_values=pv)
+                ces[i] = ips[i].get_loss(out.logits[:, :-1, :])
+                return ces[i]
+            return loss_fn
+        ref = ora.backward_update(loss_fns=[make(i) for i in range(k)])
+        per_model = [s["weights"][i] * float(ces[i].detach()) + ref["img_loss"] for i in range(k)]
+        for i in range(k):
+            assert close(per_model[i], g[f"{n}_model_losses"][t][i]), (t, i)
+        assert close(sum(per_model) / k, g[f"{n}_loss_per_iteration"][t])
+        assert close(ref["img_loss"], g[f"{n}_img_loss"][t])
+        assert close(ref["grad_norm"], g[f"{n}_grad_norm"][t], 1e-4)
+        assert close(ref["sigma_next"], g[f"{n}_resave_error_std"][t], 1e-5, 1e-9)
+        assert close(ref["qerr_mean"], g[f"{n}_resave_error_mean"][t], 1e-5, 1e-9) and close(ref["qerr_l1"], g[f"{n}_resave_error_l1"][t], 1e-5, 1e-6)
+        assert close(ora.current_lr(), g[f"{n}_lr"][t], 1e-12) and ora.opt_steps == int(g[f"{n}_global_iteration"][t])
+        with torch.no_grad():
+            q = P.quantise(ref["s"])
+            rs = []
+            for i in range(k):
+                pv1 = s["oracles"][i].process(q)["pixel_values"]
+                pv = pv1.repeat((s["B"],) + (1,) * (pv1.dim() - 1))
+                out = models[i](**{kk: vv for kk, vv in inputs[i].items() if kk != "pixel_values"}, pixel_values=pv)
+                rs.append(float(ips[i].get_loss(out.logits[:, :-1, :])))
+            assert close(sum(rs) / k, g[f"{n}_loss_resaved"][t])
+        last_s = ref["s"]
+    assert rel_err(last_s.flatten(), g[f"{n}_final"]) <= 1e-6
