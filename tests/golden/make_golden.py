@@ -449,7 +449,7 @@ def golden_full_size(llava, qwen, phi3, mllama):
                            f"{k}_grad_idx": gidx, f"{k}_grad_val": img.grad.flatten()[gidx]})
     save("full_size_reference.npz", **arrays)
 
-def golden_trainer_run(am, llava):
+def golden_trainer_run(am, llava, qwen=None, mllama=None):
     """The reference's OWN `attack_model.train()` (attack_model.py:108-478), run here on the CPU for a few iterations around a
     tiny random LLaVA-architecture model: what it logs every iteration (loss, image loss, re-saved loss, quantise-error
     mean / std / L1, noise std, gradient norm, learning rate) and the images it writes.  This is the trainer loop itself -
@@ -497,20 +497,46 @@ def golden_trainer_run(am, llava):
     a.answers, a.adv_answers = ["sure here it is"], ["of course"]
     sys.modules["questions"], sys.modules["answers"] = q, a
 
+    from adversarialvlm_amd.processors import synthetic_vlms
+
     def loader(model_name, device):
         model, proc = synthetic.load_model_and_processor("synthetic/tiny-llava", device, seed=0)
         return model, proc
-    am.load_components = lambda name: (loader, llava.AdvLlavaInputs, llava.DifferentiableLlavaImageProcessor)
+
+    def load_mllama(model_name, device):
+        return synthetic_vlms.load_model_and_processor("synthetic/tiny-mllama", device, seed=2)
+
+    def load_qwen(model_name, device):
+        model, proc = synthetic_vlms.load_model_and_processor("synthetic/tiny-qwen2vl", device, seed=3)
+        # transformers 4.51 (the reference's pin) kept the pixel bounds as attributes; 5.x keeps them in `size`
+        proc.image_processor.min_pixels, proc.image_processor.max_pixels = synthetic_vlms.QWEN_MIN_PIXELS, synthetic_vlms.QWEN_MAX_PIXELS
+        return model, proc
+    table = {"tiny": (loader, llava.AdvLlavaInputs, llava.DifferentiableLlavaImageProcessor)}
+    if mllama is not None:
+        table["tiny-mllama"] = (load_mllama, mllama.AdvMllamaInputs, mllama.DifferentiableMllamaImageProcessor)
+    if qwen is not None:
+        table["tiny-qwen2vl"] = (load_qwen, qwen.AdvQwen2VLInputs, qwen.DifferentiableQwen2VLImageProcessor)
+    am.load_components = lambda name: table[name]
 
     runs = [("a", dict(grad_accum_steps=1, mask_type="corner", mask_size=30, scheduler_step_size=2, scheduler_gamma=0.5,
                        start_from_white=False), (3, 64, 48), 5, 11),
             ("b", dict(grad_accum_steps=2, mask_type=None, mask_size=None, scheduler_step_size=100, scheduler_gamma=1.0,
                        start_from_white=False), (3, 56, 56), 6, 12),
             ("c", dict(grad_accum_steps=1, mask_type="bottom_lines", mask_size=20, scheduler_step_size=100, scheduler_gamma=1.0,
-                       start_from_white=True), (3, 40, 70), 3, 13)]
+                       start_from_white=True), (3, 40, 70), 3, 13),
+            # BASELINE configs[2] at the reference's level: a Llama-3.2-Vision architecture, tanh + localized patch (corner mask);
+            # batch 1 (the reference hands the HF Mllama processor a flat image list: transformers 5.x takes it for one prompt)
+            ("d", dict(grad_accum_steps=1, mask_type="corner", mask_size=40, scheduler_step_size=100, scheduler_gamma=1.0,
+                       start_from_white=False, model_name="tiny-mllama", batch_size=1), (3, 60, 90), 4, 14),
+            ("e", dict(grad_accum_steps=2, mask_type=None, mask_size=None, scheduler_step_size=100, scheduler_gamma=1.0,
+                       start_from_white=False, model_name="tiny-qwen2vl", batch_size=1), (3, 60, 90), 4, 15)]
     arrays = {}
     cwd = os.getcwd()
     for name, kw, ishape, iters, seed in runs:
+        kw = dict(kw)
+        model_name, batch = kw.pop("model_name", "tiny"), kw.pop("batch_size", 2)
+        if model_name not in table:
+            continue
         tmp = tempfile.mkdtemp()
         os.chdir(tmp)
         try:
@@ -521,7 +547,7 @@ def golden_trainer_run(am, llava):
             random.seed(seed)
             torch.manual_seed(seed)
             am.train(exp_name="run", img_orig="in.png", prompt="describe this image", target_text="sure here it is",
-                     model_name="tiny", lr=1e-2, num_iterations=iters, save_steps=2, batch_size=2, restart_num=0,
+                     model_name=model_name, lr=1e-2, num_iterations=iters, save_steps=2, batch_size=batch, restart_num=0,
                      clamp_method="tanh", epsilon=0.5, sigma=1e-3, target_text_random=False, **kw)
             per_iter = [r for r in rec.rows if "loss_resaved" in r]
             assert len(per_iter) == iters
@@ -531,6 +557,7 @@ def golden_trainer_run(am, llava):
                 arrays[f"{name}_{k.replace(' ', '_')}"] = np.array([r[k] for r in per_iter], dtype=np.float64)
             arrays[f"{name}_image"] = img
             arrays[f"{name}_seed"] = np.array(seed)
+            arrays[f"{name}_model"], arrays[f"{name}_batch"] = np.array(model_name), np.array(batch)
             arrays[f"{name}_iters"] = np.array(iters)
             arrays[f"{name}_accum"] = np.array(kw["grad_accum_steps"])
             arrays[f"{name}_sched"] = np.array([kw["scheduler_step_size"], kw["scheduler_gamma"]], dtype=np.float64)
@@ -540,12 +567,14 @@ def golden_trainer_run(am, llava):
             arrays[f"{name}_mask_sum"] = np.array(float(torch.load(os.path.join("runs", "run", "mask.pt")).sum()))
             arrays[f"{name}_files"] = np.array(sorted(f for f in os.listdir(os.path.join("runs", "run"))))
             # the batch the reference's AdvLlavaInputs assembles for this prompt (llavaprocessor.py:80-108), for the id layout
-            _, proc = loader("tiny", "cpu")
-            ip = llava.AdvLlavaInputs(questions=["describe this image"], test_questions=["hi"], batch_size=2,
-                                      original_image=Image.fromarray(img), processor=proc, device="cpu",
-                                      target_text="sure here it is")
+            load_fn, AdvCls, _ = table[model_name]
+            _, proc = load_fn(model_name, "cpu")
+            ip = AdvCls(questions=["describe this image"], test_questions=["hi"], batch_size=batch,
+                        original_image=Image.fromarray(img), processor=proc, device="cpu", target_text="sure here it is")
             enc = ip.get_inputs_train()
-            arrays[f"{name}_input_ids"], arrays[f"{name}_attention_mask"] = enc["input_ids"], enc["attention_mask"]
+            for key in enc.keys():
+                if key != "pixel_values":
+                    arrays[f"{name}_in_{key}"] = enc[key]
             arrays[f"{name}_suffix"] = np.array([ip.suffix_length, ip.shift])
         finally:
             os.chdir(cwd)
@@ -671,7 +700,7 @@ def main():
     if only in (None, "full_size"):
         golden_full_size(llava, qwen, phi3, mllama)
     if only == "trainer_run":
-        golden_trainer_run(import_reference_trainer(), llava)
+        golden_trainer_run(import_reference_trainer(), llava, qwen, mllama)
     if only == "cross_trainer_run":
         golden_cross_trainer_run(llava, qwen, mllama)
     if only is not None:
@@ -685,7 +714,7 @@ def main():
     golden_trainer_helpers(import_reference_trainer())
     golden_closed_form()
     golden_mllama_restated()
-    golden_trainer_run(import_reference_trainer(), llava)      # last: these replace the wandb placeholder by a recorder
+    golden_trainer_run(import_reference_trainer(), llava, qwen, mllama)      # last: these replace the wandb placeholder by a recorder
     golden_cross_trainer_run(llava, qwen, mllama)
 
 

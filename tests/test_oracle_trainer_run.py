@@ -19,33 +19,51 @@ from oracle import pixel_ops as P
 from oracle.pgd import PGDOracle
 from oracle.processors import LlavaOracle
 
-RUNS = ["a", "b", "c"]
+RUNS = ["a", "b", "c", "d", "e"]
 TOL = 2e-5        # same torch ops on both sides; the model's GEMMs may take another code path on another CPU
 
 
+def families():
+    """name in the captures -> (loader(device), AdvInputs, DifferentiableProcessor, oracle processor factory)"""
+    from adversarialvlm_amd.processors import synthetic, synthetic_vlms as S
+    from oracle.processors import MllamaOracle, Qwen2VLOracle
+    llava0 = (lambda d: synthetic.load_model_and_processor("synthetic/tiny-llava", d, seed=0), synthetic.AdvLlavaInputs,
+              synthetic.DifferentiableLlavaImageProcessor, lambda: LlavaOracle(56, 56))
+    return {"tiny": llava0, "tiny-llava-0": llava0,
+            "tiny-llava-1": (lambda d: synthetic.load_model_and_processor("synthetic/tiny-llava", d, seed=1), synthetic.AdvLlavaInputs,
+                             synthetic.DifferentiableLlavaImageProcessor, lambda: LlavaOracle(56, 56)),
+            "tiny-mllama": (lambda d: S.load_model_and_processor("synthetic/tiny-mllama", d, seed=2), S.AdvMllamaInputs,
+                            S.DifferentiableMllamaImageProcessor, lambda: MllamaOracle(tile=S.MLLAMA_TILE, max_tiles=S.MLLAMA_MAX_TILES)),
+            "tiny-qwen2vl": (lambda d: S.load_model_and_processor("synthetic/tiny-qwen2vl", d, seed=3), S.AdvQwen2VLInputs,
+                             S.DifferentiableQwen2VLImageProcessor,
+                             lambda: Qwen2VLOracle(min_pixels=S.QWEN_MIN_PIXELS, max_pixels=S.QWEN_MAX_PIXELS))}
+
+
 def run_setup(g, n):
-    """-> dict(x0, mask, kwargs of the optimiser, iterations, noise draws, model, processor) of run n"""
-    from adversarialvlm_amd.processors import synthetic
-    model, proc = synthetic.load_model_and_processor("synthetic/tiny-llava", "cpu", seed=0)     # leaves the generator where
-    iters = int(g[f"{n}_iters"])                                                                # the reference's loop found it
-    zs = [torch.randn(2, 3, 56, 56) for _ in range(iters)]
+    """-> dict(x0, mask, kwargs of the optimiser, iterations, noise draws, model, processor, ...) of run n"""
+    fam = families()[str(g[f"{n}_model"])]
+    model, proc = fam[0]("cpu")                       # leaves the CPU generator where the reference's loop found it
+    iters, B = int(g[f"{n}_iters"]), int(g[f"{n}_batch"])
     img = g[f"{n}_image"]
     x0 = torch.tensor(img.astype(np.float32) / 255).permute(2, 0, 1).contiguous()
     if int(g[f"{n}_white"]):
         x0 = torch.ones_like(x0)
+    oracle = fam[3]()
+    pv = oracle.process(x0)["pixel_values"]
+    shape = (B * pv.shape[0],) + tuple(pv.shape[1:])
+    zs = [torch.randn(shape) for _ in range(iters)]
     kind, size = (int(v) for v in g[f"{n}_mask"])
     mask = P.create_mask({0: "corner", 1: "bottom_lines"}[kind], size, x0.shape) if kind >= 0 else (x0 != 0).float()
     assert float(mask.sum()) == float(g[f"{n}_mask_sum"])
     step, gamma = g[f"{n}_sched"]
-    return dict(x0=x0, mask=mask, iters=iters, zs=zs, model=model, proc=proc, img=Image.fromarray(img),
+    return dict(x0=x0, mask=mask, iters=iters, B=B, zs=zs, model=model, proc=proc, img=Image.fromarray(img), fam=fam, oracle=oracle,
                 opt=dict(lr=1e-2, epsilon=0.5, sigma0=1e-3, scheduler_step_size=int(step), scheduler_gamma=float(gamma),
                          grad_accum_steps=int(g[f"{n}_accum"])))
 
 
 def make_inputs(setup, device="cpu"):
-    from adversarialvlm_amd.processors.synthetic import AdvLlavaInputs
-    return AdvLlavaInputs(questions=["describe this image"], test_questions=["hi"], batch_size=2, original_image=setup["img"],
-                          processor=setup["proc"], device=device, target_text="sure here it is", rng=random.Random(0))
+    return setup["fam"][1](questions=["describe this image"], test_questions=["hi"], batch_size=setup["B"], original_image=setup["img"],
+                           processor=setup["proc"], device=device, target_text="sure here it is", rng=random.Random(0))
 
 
 def close(a, b, tol=TOL, floor=0.0):
@@ -57,10 +75,19 @@ def test_plugin_batches_equal_the_reference_plugins(n):
     """get_inputs_train() of this package's AdvLlavaInputs (cached tokenisation) against the batch the reference's class
     assembled for the same prompt (llavaprocessor.py:80-108): ids, mask, suffix length and shift."""
     g = load_golden("trainer_run_reference.npz")
-    ip = make_inputs(run_setup(g, n))
-    enc = ip.get_inputs_train()
-    assert torch.equal(enc["input_ids"], torch.tensor(g[f"{n}_input_ids"]))
-    assert torch.equal(enc["attention_mask"], torch.tensor(g[f"{n}_attention_mask"]))
+    s = run_setup(g, n)
+    ip = make_inputs(s)
+    keys = sorted(k[len(n) + 4:] for k in g.files if k.startswith(f"{n}_in_"))
+    for bound in (False, True):
+        if bound:
+            # index tensors from the PLAN geometry (what the trainers use) instead of the HF pass over the original image
+            H, W = s["x0"].shape[1:]
+            ip.bind_geometry(s["fam"][2](s["proc"].image_processor, "cpu"), H, W)
+        enc = ip.get_inputs_train()
+        assert sorted(enc.keys()) == keys
+        for k in keys:
+            want = torch.tensor(g[f"{n}_in_{k}"])
+            assert enc[k].dtype == want.dtype and torch.equal(enc[k], want), (k, bound)
     assert [ip.suffix_length, ip.shift] == [int(v) for v in g[f"{n}_suffix"]]
 
 
@@ -70,18 +97,21 @@ def test_oracle_loop_reproduces_the_reference_trainers_log(n):
     s = run_setup(g, n)
     model, ip = s["model"], make_inputs(s)
     accum = s["opt"]["grad_accum_steps"]
-    ora = PGDOracle(s["x0"], [LlavaOracle(56, 56)], mask=s["mask"], **s["opt"])
+    ora = PGDOracle(s["x0"], [s["oracle"]], mask=s["mask"], **s["opt"])
     last_s = None
+
+    def side(inputs):
+        return {k: v for k, v in inputs.items() if k != "pixel_values"}
     for t in range(s["iters"]):
         inputs = ip.get_inputs_train()
         sigma = float(ora.sigma)
         noise = s["zs"][t] * sigma
         assert close(noise.std(), g[f"{n}_noise_std"][t], 1e-5, 1e-12) and abs(float(noise.mean()) - g[f"{n}_noise_mean"][t]) < 1e-9
-        ora.forward(2, [s["zs"][t]])
+        ora.forward(s["B"], [s["zs"][t]])
         ce = {}
 
         def loss_fn(pv):
-            out = model(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"], pixel_values=pv)
+            out = model(**side(inputs), pixel_values=pv)
             ce["v"] = ip.get_loss(out.logits[:, :-1, :])
             return ce["v"]
         ref = ora.backward_update(loss_fns=[loss_fn])
@@ -95,8 +125,8 @@ def test_oracle_loop_reproduces_the_reference_trainers_log(n):
         assert close(ora.current_lr(), g[f"{n}_lr"][t], 1e-12)                                      # scheduler.get_last_lr() after the step
         assert ora.opt_steps == int(g[f"{n}_global_iteration"][t])
         with torch.no_grad():                                                                       # :375-379 the re-saved forward
-            pv = LlavaOracle(56, 56).process(P.quantise(ref["s"]))["pixel_values"].repeat(2, 1, 1, 1)
-            out = model(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"], pixel_values=pv)
+            pv1 = s["oracle"].process(P.quantise(ref["s"]))["pixel_values"]
+            out = model(**side(inputs), pixel_values=pv1.repeat((s["B"],) + (1,) * (pv1.dim() - 1)))
             assert close(ip.get_loss(out.logits[:, :-1, :]), g[f"{n}_loss_resaved"][t])
         last_s = ref["s"]
     # the image written at the end is x_0 + x of the LAST iteration's forward, i.e. before that iteration's update (:473-477)
@@ -109,17 +139,7 @@ CROSS = ["x1", "x2"]
 
 def cross_setup(g, n, device="cpu"):
     """Models built in the reference run's order (that is where its loop found the CPU generator), then its noise draws."""
-    from adversarialvlm_amd.processors import synthetic, synthetic_vlms as S
-    from oracle.processors import MllamaOracle, Qwen2VLOracle
-    fam = {"tiny-llava-0": (lambda d: synthetic.load_model_and_processor("synthetic/tiny-llava", d, seed=0), synthetic.AdvLlavaInputs,
-                            synthetic.DifferentiableLlavaImageProcessor, lambda: LlavaOracle(56, 56)),
-           "tiny-llava-1": (lambda d: synthetic.load_model_and_processor("synthetic/tiny-llava", d, seed=1), synthetic.AdvLlavaInputs,
-                            synthetic.DifferentiableLlavaImageProcessor, lambda: LlavaOracle(56, 56)),
-           "tiny-mllama": (lambda d: S.load_model_and_processor("synthetic/tiny-mllama", d, seed=2), S.AdvMllamaInputs,
-                           S.DifferentiableMllamaImageProcessor, lambda: MllamaOracle(tile=S.MLLAMA_TILE, max_tiles=S.MLLAMA_MAX_TILES)),
-           "tiny-qwen2vl": (lambda d: S.load_model_and_processor("synthetic/tiny-qwen2vl", d, seed=3), S.AdvQwen2VLInputs,
-                            S.DifferentiableQwen2VLImageProcessor,
-                            lambda: Qwen2VLOracle(min_pixels=S.QWEN_MIN_PIXELS, max_pixels=S.QWEN_MAX_PIXELS))}
+    fam = families()
     names = [str(v) for v in g[f"{n}_names"]]
     loaded = [fam[m][0]("cpu") for m in names]                     # always on the CPU first: the draws follow
     img = g[f"{n}_image"]
