@@ -576,6 +576,10 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None):
                 if key != "pixel_values":
                     arrays[f"{name}_in_{key}"] = enc[key]
             arrays[f"{name}_suffix"] = np.array([ip.suffix_length, ip.shift])
+            inf = ip.get_inputs_inference(Image.fromarray(img), question="what is in this picture")     # :110-133 of the plugins
+            for key in inf.keys():
+                if key != "pixel_values":
+                    arrays[f"{name}_inf_{key}"] = inf[key]
         finally:
             os.chdir(cwd)
             shutil.rmtree(tmp, ignore_errors=True)

@@ -89,6 +89,12 @@ def test_plugin_batches_equal_the_reference_plugins(n):
             want = torch.tensor(g[f"{n}_in_{k}"])
             assert enc[k].dtype == want.dtype and torch.equal(enc[k], want), (k, bound)
     assert [ip.suffix_length, ip.shift] == [int(v) for v in g[f"{n}_suffix"]]
+    # ... and the inference prompt of the generation probe (get_inputs_inference of the reference's plugins)
+    inf = ip.get_inputs_inference(s["img"], question="what is in this picture")
+    keys = sorted(k[len(n) + 5:] for k in g.files if k.startswith(f"{n}_inf_"))
+    assert sorted(k for k in inf.keys() if k != "pixel_values") == keys
+    for k in keys:
+        assert torch.equal(inf[k], torch.tensor(g[f"{n}_inf_{k}"])), k
 
 
 @pytest.mark.parametrize("n", RUNS)
