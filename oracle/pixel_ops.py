@@ -104,8 +104,8 @@ def create_mask(mask_type, mask_size, shape):
 def quantise(s):
     """tensor2pil + pil_to_tensor round trip (llavaprocessor.py:151-161): PNG is lossless
     so the round trip equals uint8 TRUNCATION of clamp(s,0,1)*255, divided by 255 (Q1)."""
-    q = (s.detach().clamp(0, 1) * 255).numpy().astype(np.uint8)
-    return torch.tensor(q.astype(np.float32) / 255)
+    q = (s.detach().clamp(0, 1) * 255).cpu().numpy().astype(np.uint8)     # tensor2pil moves to the CPU too (:153)
+    return torch.tensor(q.astype(np.float32) / 255).to(s.device)
 
 
 def quantise_error_stats(s):

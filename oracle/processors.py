@@ -33,8 +33,8 @@ def _aa(img, h, w):
 
 
 def _norm(img, mean, std):
-    m = torch.tensor(mean, dtype=img.dtype).view(-1, 1, 1)
-    s = torch.tensor(std, dtype=img.dtype).view(-1, 1, 1)
+    m = torch.tensor(mean, dtype=img.dtype, device=img.device).view(-1, 1, 1)
+    s = torch.tensor(std, dtype=img.dtype, device=img.device).view(-1, 1, 1)
     return (img - m) / s
 
 
@@ -69,7 +69,7 @@ class MllamaOracle:
         C = img.shape[0]
         tiles = img.reshape(C, th, self.tile, tw, self.tile).permute(1, 3, 0, 2, 4)
         tiles = tiles.reshape(th * tw, C, self.tile, self.tile)                # :326-332
-        out = torch.zeros(1, 1, self.max_tiles, C, self.tile, self.tile, dtype=img.dtype)
+        out = torch.zeros(1, 1, self.max_tiles, C, self.tile, self.tile, dtype=img.dtype, device=img.device)
         out[0, 0, :th * tw] = tiles                                            # :344-355
         return {"pixel_values": out, "aspect_ratio_ids": None, "num_tiles": th * tw}
 
@@ -98,7 +98,7 @@ class Phi3Oracle:
         local = local.reshape(-1, 3, 336, 336)                                     # :227
         tiles = torch.cat([glob, local], dim=0)                                    # :229
         if tiles.shape[0] < self.num_crops + 1:                                    # :232-235
-            pad = torch.zeros(self.num_crops + 1 - tiles.shape[0], 3, 336, 336, dtype=tiles.dtype)
+            pad = torch.zeros(self.num_crops + 1 - tiles.shape[0], 3, 336, 336, dtype=tiles.dtype, device=tiles.device)
             tiles = torch.cat([tiles, pad], dim=0)
         return {"pixel_values": tiles.unsqueeze(0), "image_sizes": [[h, w]],
                 "num_img_tokens": [G.phi3_num_img_tokens(h, w)]}                   # :244-249
