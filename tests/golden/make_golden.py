@@ -493,8 +493,10 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None):
     sys.modules["wandb"] = rec
     am.wandb = rec
     q, a = types.ModuleType("questions"), types.ModuleType("answers")
-    q.questions, q.not_safe_questions, q.not_safe_questions_test = ["describe this image"], ["what is shown here"], ["hi", "what is in this picture"]
-    a.answers, a.adv_answers = ["sure here it is"], ["of course"]
+    q.not_safe_questions = ["what is shown here", "describe the scene please", "list the items in this picture"]
+    q.questions = ["describe this image", "what is in this picture", "hi", "what is shown in region 3 of the image"]
+    q.not_safe_questions_test = ["hi", "what is in this picture"]
+    a.answers, a.adv_answers = ["sure here it is", "of course the answer is"], ["yes here is the list"]
     sys.modules["questions"], sys.modules["answers"] = q, a
 
     from adversarialvlm_amd.processors import synthetic_vlms
@@ -529,12 +531,17 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None):
             ("d", dict(grad_accum_steps=1, mask_type="corner", mask_size=40, scheduler_step_size=100, scheduler_gamma=1.0,
                        start_from_white=False, model_name="tiny-mllama", batch_size=1), (3, 60, 90), 4, 14),
             ("e", dict(grad_accum_steps=2, mask_type=None, mask_size=None, scheduler_step_size=100, scheduler_gamma=1.0,
-                       start_from_white=False, model_name="tiny-qwen2vl", batch_size=1), (3, 60, 90), 4, 15)]
+                       start_from_white=False, model_name="tiny-qwen2vl", batch_size=1), (3, 60, 90), 4, 15),
+            # the draws of the loop: prompts sampled with replacement from the pool (--prompt list) and a target drawn per
+            # iteration (--target_text_random: multi-answer supervision), both from the global `random` stream (:283-292)
+            ("f", dict(grad_accum_steps=1, mask_type=None, mask_size=None, scheduler_step_size=100, scheduler_gamma=1.0,
+                       start_from_white=False, batch_size=3, prompt="list", target_text_random=True), (3, 56, 56), 5, 16)]
     arrays = {}
     cwd = os.getcwd()
     for name, kw, ishape, iters, seed in runs:
         kw = dict(kw)
         model_name, batch = kw.pop("model_name", "tiny"), kw.pop("batch_size", 2)
+        prompt, ttr = kw.pop("prompt", "describe this image"), kw.pop("target_text_random", False)
         if model_name not in table:
             continue
         tmp = tempfile.mkdtemp()
@@ -546,9 +553,9 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None):
             Image.fromarray(img).save("in.png")
             random.seed(seed)
             torch.manual_seed(seed)
-            am.train(exp_name="run", img_orig="in.png", prompt="describe this image", target_text="sure here it is",
+            am.train(exp_name="run", img_orig="in.png", prompt=prompt, target_text="sure here it is",
                      model_name=model_name, lr=1e-2, num_iterations=iters, save_steps=2, batch_size=batch, restart_num=0,
-                     clamp_method="tanh", epsilon=0.5, sigma=1e-3, target_text_random=False, **kw)
+                     clamp_method="tanh", epsilon=0.5, sigma=1e-3, target_text_random=ttr, **kw)
             per_iter = [r for r in rec.rows if "loss_resaved" in r]
             assert len(per_iter) == iters
             keys = ["loss", "image_loss", "loss_resaved", "resave_error_mean", "resave_error_std", "resave_error_l1", "noise_mean",
@@ -558,6 +565,9 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None):
             arrays[f"{name}_image"] = img
             arrays[f"{name}_seed"] = np.array(seed)
             arrays[f"{name}_model"], arrays[f"{name}_batch"] = np.array(model_name), np.array(batch)
+            arrays[f"{name}_prompt"], arrays[f"{name}_target_random"] = np.array(prompt), np.array(int(ttr))
+            arrays[f"{name}_questions"] = np.array(q.not_safe_questions + q.questions)        # the pool as train() forms it (:144)
+            arrays[f"{name}_answers"] = np.array(a.answers + a.adv_answers)                   # (:147-148)
             arrays[f"{name}_iters"] = np.array(iters)
             arrays[f"{name}_accum"] = np.array(kw["grad_accum_steps"])
             arrays[f"{name}_sched"] = np.array([kw["scheduler_step_size"], kw["scheduler_gamma"]], dtype=np.float64)
@@ -571,6 +581,7 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None):
             _, proc = load_fn(model_name, "cpu")
             ip = AdvCls(questions=["describe this image"], test_questions=["hi"], batch_size=batch,
                         original_image=Image.fromarray(img), processor=proc, device="cpu", target_text="sure here it is")
+            random.seed(1234)
             enc = ip.get_inputs_train()
             for key in enc.keys():
                 if key != "pixel_values":
@@ -628,8 +639,10 @@ def golden_cross_trainer_run(llava, qwen, mllama):
     sys.modules["wandb"] = rec
     cm.wandb = rec
     q, a = types.ModuleType("questions"), types.ModuleType("answers")
-    q.questions, q.not_safe_questions, q.not_safe_questions_test = ["describe this image"], ["what is shown here"], ["hi"]
-    a.answers, a.adv_answers = ["sure here it is"], ["of course"]
+    q.not_safe_questions = ["what is shown here", "describe the scene please", "list the items in this picture"]
+    q.questions = ["describe this image", "what is in this picture", "hi", "what is shown in region 3 of the image"]
+    q.not_safe_questions_test = ["hi"]
+    a.answers, a.adv_answers = ["sure here it is", "of course the answer is"], ["yes here is the list"]
     sys.modules["questions"], sys.modules["answers"] = q, a
 
     def load_qwen(name, dev):
@@ -653,10 +666,18 @@ def golden_cross_trainer_run(llava, qwen, mllama):
                                                          mask_type="corner", mask_size=30, model_weights=[0.7, 0.3]), (64, 48), 6, 21),
             ("x2", ["tiny-llava-0", "tiny-mllama", "tiny-qwen2vl"],
              dict(batch_size=1, grad_accum_steps=1, scheduler_step_size=100, scheduler_gamma=0.9, mask_type=None, mask_size=None,
-                  model_weights=None), (60, 90), 3, 22)]
+                  model_weights=None), (60, 90), 3, 22),
+            # the draws of the cross loop (:303-321): a coin per iteration, a refusal per model below refuse_prob, else ONE target
+            # for all models; prompts sampled from the pool
+            ("x3", ["tiny-llava-0", "tiny-llava-1"],
+             dict(batch_size=2, grad_accum_steps=1, scheduler_step_size=100, scheduler_gamma=0.9, mask_type=None, mask_size=None,
+                  model_weights=[1.0, 0.5], prompt="list", target_text_random=True, DPO_flag=True, refuse_prob=0.5), (56, 56), 6, 23)]
     arrays = {}
     cwd = os.getcwd()
     for name, names, kw, (H, W), iters, seed in runs:
+        kw = dict(kw)
+        prompt, ttr = kw.pop("prompt", "describe this image"), kw.pop("target_text_random", False)
+        dpo, refuse_prob = kw.pop("DPO_flag", False), kw.pop("refuse_prob", 0.1)
         tmp = tempfile.mkdtemp()
         os.chdir(tmp)
         try:
@@ -666,9 +687,10 @@ def golden_cross_trainer_run(llava, qwen, mllama):
             Image.fromarray(img).save("in.png")
             random.seed(seed)
             torch.manual_seed(seed)
-            cm.train(exp_name="run", img_orig="in.png", prompt="describe this image", target_text="sure here it is",
+            cm.train(exp_name="run", img_orig="in.png", prompt=prompt, target_text="sure here it is",
                      model_names=names, lr=1e-2, num_iterations=iters, save_steps=2, restart_num=0, clamp_method="tanh", epsilon=0.4,
-                     sigma=1e-3, start_from_white=False, target_text_random=False, DPO_flag=False, attack_norm=0.4, **kw)
+                     sigma=1e-3, start_from_white=False, target_text_random=ttr, DPO_flag=dpo, refuse_prob=refuse_prob,
+                     attack_norm=0.4, **kw)
             per_iter = [r for r in rec.rows if "loss_per_iteration" in r]
             assert len(per_iter) == iters
             keys = ["loss_per_iteration", "img_loss", "loss_resaved", "resave_error_mean", "resave_error_std", "resave_error_l1",
@@ -677,6 +699,11 @@ def golden_cross_trainer_run(llava, qwen, mllama):
                 arrays[f"{name}_{k}"] = np.array([r[k] for r in per_iter], dtype=np.float64)
             arrays[f"{name}_model_losses"] = np.array([[r[f"loss_{i}_{mn}"] for i, mn in enumerate(names)] for r in per_iter])
             arrays[f"{name}_names"] = np.array(names)
+            arrays[f"{name}_prompt"], arrays[f"{name}_target_random"] = np.array(prompt), np.array(int(ttr))
+            arrays[f"{name}_dpo"] = np.array([float(dpo), refuse_prob])
+            arrays[f"{name}_seed"] = np.array(seed)
+            arrays[f"{name}_questions"] = np.array(q.not_safe_questions + q.questions)
+            arrays[f"{name}_answers"] = np.array(a.answers + a.adv_answers)
             arrays[f"{name}_image"] = img
             arrays[f"{name}_iters"], arrays[f"{name}_batch"], arrays[f"{name}_accum"] = np.array(iters), np.array(kw["batch_size"]), np.array(kw["grad_accum_steps"])
             arrays[f"{name}_sched"] = np.array([kw["scheduler_step_size"], kw["scheduler_gamma"]], dtype=np.float64)

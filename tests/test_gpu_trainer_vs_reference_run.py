@@ -19,7 +19,16 @@ from PIL import Image
 from conftest import load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
-RUNS = ["a", "b", "c", "d", "e"]        # d: Llama-3.2-Vision architecture + localized patch (configs[2]); e: Qwen2-VL
+RUNS = ["a", "b", "c", "d", "e", "f"]   # d: Llama-3.2-Vision architecture + localized patch (configs[2]); e: Qwen2-VL;
+                                         # f: prompts sampled from the pool + a target drawn per iteration (the global `random` stream)
+
+
+def _pools(tmp, s):
+    import json
+    qf, af = os.path.join(tmp, "questions.json"), os.path.join(tmp, "answers.json")
+    json.dump(s["pool"], open(qf, "w"))
+    json.dump(s["answers"], open(af, "w"))
+    return dict(questions_file=qf, answers_file=af, seed=s["seed"])
 
 
 def _close(a, b, tol, floor=0.0):
@@ -45,12 +54,12 @@ def test_train_equals_the_reference_trainers_run(tmp_path, n):
 
     components = ((lambda model_name, device: fam[0](device)), fam[1], fam[2])
     eng, hist = attack_model.train(
-        exp_name="run", img_orig=os.path.join(tmp, "in.png"), prompt="describe this image", target_text="sure here it is",
+        exp_name="run", img_orig=os.path.join(tmp, "in.png"), prompt=s["prompt"], target_text="sure here it is",
         model_name=str(g[f"{n}_model"]), lr=1e-2, num_iterations=iters, save_steps=2, batch_size=s["B"], grad_accum_steps=accum,
         scheduler_step_size=int(step), scheduler_gamma=float(gamma), restart_num=0,
         mask_type={0: "corner", 1: "bottom_lines", -1: None}[kind], mask_size=size if kind >= 0 else None, clamp_method="tanh",
-        epsilon=0.5, sigma=1e-3, start_from_white=bool(int(g[f"{n}_white"])), target_text_random=False, base_path=tmp,
-        components=components, return_engine=True, resaved_loss_every=1, log_every=1, unit_noise_fn=lambda it, shape: zs[it].view(shape))
+        epsilon=0.5, sigma=1e-3, start_from_white=bool(int(g[f"{n}_white"])), target_text_random=s["target_random"], base_path=tmp,
+        components=components, **_pools(tmp, s), return_engine=True, resaved_loss_every=1, log_every=1, unit_noise_fn=lambda it, shape: zs[it].view(shape))
     assert len(hist) == iters
     for t, h in enumerate(hist):
         where = (n, t)
@@ -83,7 +92,7 @@ def test_train_equals_the_reference_trainers_run(tmp_path, n):
     assert float(mask.sum()) == float(g[f"{n}_mask_sum"])
 
 
-@pytest.mark.parametrize("n", ["x1", "x2"])
+@pytest.mark.parametrize("n", ["x1", "x2", "x3"])      # x3: the coin, a refusal per model or one target for all, sampled prompts
 def test_cross_train_equals_the_reference_cross_trainers_run(tmp_path, n):
     """`crossattack_models.train()` of this package beside the reference's own (cross_trainer_run_reference.npz): x1 two LLaVA
     models with weights and gradient accumulation; x2 one model of each family whose architecture ships with transformers, the
@@ -103,12 +112,12 @@ def test_cross_train_equals_the_reference_cross_trainers_run(tmp_path, n):
     Image.fromarray(g[f"{n}_image"]).save(os.path.join(tmp, "in.png"))
     components = {m: ((lambda name, device, m=m: s["fam"][m][0](device)), s["fam"][m][1], s["fam"][m][2]) for m in names}
     eng, hist = crossattack_models.train(
-        exp_name="run", img_orig=os.path.join(tmp, "in.png"), prompt="describe this image", target_text="sure here it is",
+        exp_name="run", img_orig=os.path.join(tmp, "in.png"), prompt=s["prompt"], target_text="sure here it is",
         model_names=names, lr=1e-2, num_iterations=iters, save_steps=2, batch_size=s["B"], grad_accum_steps=accum,
         scheduler_step_size=s["opt"]["scheduler_step_size"], scheduler_gamma=s["opt"]["scheduler_gamma"], restart_num=0,
         mask_type={0: "corner", 1: "bottom_lines", -1: None}[kind], mask_size=size if kind >= 0 else None, clamp_method="tanh",
-        epsilon=0.4, sigma=1e-3, start_from_white=False, target_text_random=False, DPO_flag=False, attack_norm=0.4,
-        model_weights=s["weights"], base_path=tmp, components=components, return_engine=True, resaved_loss_every=1, log_every=1,
+        epsilon=0.4, sigma=1e-3, start_from_white=False, target_text_random=s["target_random"], DPO_flag=s["dpo"],
+        refuse_prob=s["refuse_prob"], attack_norm=0.4, model_weights=s["weights"], base_path=tmp, components=components, **_pools(tmp, s), return_engine=True, resaved_loss_every=1, log_every=1,
         unit_noise_fn=lambda it, i, shape: s["zs"][it][i].view(shape))
     assert len(hist) == iters
     npx = g[f"{n}_final"].size

@@ -19,7 +19,7 @@ from oracle import pixel_ops as P
 from oracle.pgd import PGDOracle
 from oracle.processors import LlavaOracle
 
-RUNS = ["a", "b", "c", "d", "e"]
+RUNS = ["a", "b", "c", "d", "e", "f"]
 TOL = 2e-5        # same torch ops on both sides; the model's GEMMs may take another code path on another CPU
 
 
@@ -56,14 +56,27 @@ def run_setup(g, n):
     mask = P.create_mask({0: "corner", 1: "bottom_lines"}[kind], size, x0.shape) if kind >= 0 else (x0 != 0).float()
     assert float(mask.sum()) == float(g[f"{n}_mask_sum"])
     step, gamma = g[f"{n}_sched"]
+    prompt, pool = str(g[f"{n}_prompt"]), [str(v) for v in g[f"{n}_questions"]]
+    answers = [str(v) for v in g[f"{n}_answers"]]
     return dict(x0=x0, mask=mask, iters=iters, B=B, zs=zs, model=model, proc=proc, img=Image.fromarray(img), fam=fam, oracle=oracle,
+                seed=int(g[f"{n}_seed"]), questions=pool if prompt == "list" else [prompt], pool=pool, answers=answers, prompt=prompt,
+                target_random=bool(int(g[f"{n}_target_random"])),
                 opt=dict(lr=1e-2, epsilon=0.5, sigma0=1e-3, scheduler_step_size=int(step), scheduler_gamma=float(gamma),
                          grad_accum_steps=int(g[f"{n}_accum"])))
 
 
 def make_inputs(setup, device="cpu"):
+    """The plugin as train() builds it (attack_model.py:263-270): the pool or the one prompt, the answer list under
+    --target_text_random; prompts are drawn from the GLOBAL `random` stream, as in the reference."""
+    return setup["fam"][1](questions=setup["questions"], test_questions=["hi"], batch_size=setup["B"], original_image=setup["img"],
+                           processor=setup["proc"], device=device,
+                           target_text=setup["answers"] if setup["target_random"] else "sure here it is")
+
+
+def probe_inputs(setup):
+    """The plugin the capture script asked for one batch after each run: one prompt, one target."""
     return setup["fam"][1](questions=["describe this image"], test_questions=["hi"], batch_size=setup["B"], original_image=setup["img"],
-                           processor=setup["proc"], device=device, target_text="sure here it is", rng=random.Random(0))
+                           processor=setup["proc"], device="cpu", target_text="sure here it is")
 
 
 def close(a, b, tol=TOL, floor=0.0):
@@ -76,9 +89,10 @@ def test_plugin_batches_equal_the_reference_plugins(n):
     assembled for the same prompt (llavaprocessor.py:80-108): ids, mask, suffix length and shift."""
     g = load_golden("trainer_run_reference.npz")
     s = run_setup(g, n)
-    ip = make_inputs(s)
+    ip = probe_inputs(s)
     keys = sorted(k[len(n) + 4:] for k in g.files if k.startswith(f"{n}_in_"))
     for bound in (False, True):
+        random.seed(1234)
         if bound:
             # index tensors from the PLAN geometry (what the trainers use) instead of the HF pass over the original image
             H, W = s["x0"].shape[1:]
@@ -105,11 +119,14 @@ def test_oracle_loop_reproduces_the_reference_trainers_log(n):
     accum = s["opt"]["grad_accum_steps"]
     ora = PGDOracle(s["x0"], [s["oracle"]], mask=s["mask"], **s["opt"])
     last_s = None
+    random.seed(s["seed"])                  # the capture seeded the global stream right before train()
 
     def side(inputs):
         return {k: v for k, v in inputs.items() if k != "pixel_values"}
     for t in range(s["iters"]):
-        inputs = ip.get_inputs_train()
+        if s["target_random"]:
+            ip.set_target_text(random.choice(ip.target_texts))                                     # :283-290
+        inputs = ip.get_inputs_train()                                                             # :292 random.choices(pool, k=B)
         sigma = float(ora.sigma)
         noise = s["zs"][t] * sigma
         assert close(noise.std(), g[f"{n}_noise_std"][t], 1e-5, 1e-12) and abs(float(noise.mean()) - g[f"{n}_noise_mean"][t]) < 1e-9
@@ -140,7 +157,7 @@ def test_oracle_loop_reproduces_the_reference_trainers_log(n):
 
 
 # ------------------------------------------------------------------------------------------ the cross-model trainer
-CROSS = ["x1", "x2"]
+CROSS = ["x1", "x2", "x3"]
 
 
 def cross_setup(g, n, device="cpu"):
@@ -160,8 +177,11 @@ def cross_setup(g, n, device="cpu"):
     kind, size = (int(v) for v in g[f"{n}_mask"])
     mask = P.create_mask({0: "corner", 1: "bottom_lines"}[kind], size, x0.shape) if kind >= 0 else (x0 != 0).float()
     step, gamma = g[f"{n}_sched"]
+    prompt, pool = str(g[f"{n}_prompt"]), [str(v) for v in g[f"{n}_questions"]]
     return dict(names=names, fam=fam, loaded=loaded, x0=x0, oracles=oracles, B=B, iters=iters, zs=zs, mask=mask,
-                img=Image.fromarray(img), weights=[float(w) for w in g[f"{n}_weights"]],
+                img=Image.fromarray(img), weights=[float(w) for w in g[f"{n}_weights"]], seed=int(g[f"{n}_seed"]),
+                questions=pool if prompt == "list" else [prompt], pool=pool, answers=[str(v) for v in g[f"{n}_answers"]], prompt=prompt,
+                target_random=bool(int(g[f"{n}_target_random"])), dpo=bool(g[f"{n}_dpo"][0]), refuse_prob=float(g[f"{n}_dpo"][1]),
                 opt=dict(lr=1e-2, epsilon=0.4, sigma0=1e-3, scheduler_step_size=int(step), scheduler_gamma=float(gamma),
                          grad_accum_steps=int(g[f"{n}_accum"])))
 
@@ -175,12 +195,22 @@ def test_oracle_loop_reproduces_the_reference_cross_trainers_log(n):
     g = load_golden("cross_trainer_run_reference.npz")
     s = cross_setup(g, n)
     models = [m for m, _ in s["loaded"]]
-    ips = [s["fam"][m][1](questions=["describe this image"], test_questions=["hi"], batch_size=s["B"], original_image=s["img"],
-                          processor=proc, device="cpu", target_text="sure here it is", rng=random.Random(0))
+    ips = [s["fam"][m][1](questions=s["questions"], test_questions=["hi"], batch_size=s["B"], original_image=s["img"],
+                          processor=proc, device="cpu", target_text=s["answers"] if s["target_random"] else "sure here it is")
            for m, (_, proc) in zip(s["names"], s["loaded"])]
+    random.seed(s["seed"])
     ora = PGDOracle(s["x0"], s["oracles"], mask=s["mask"], model_weights=s["weights"], cross_mode=True, **s["opt"])
     k = len(models)
     for t in range(s["iters"]):
+        if s["dpo"] or s["target_random"]:                                                         # crossattack_models.py:303-321
+            coin = random.random()
+            if s["dpo"] and coin < s["refuse_prob"]:
+                for ip in ips:
+                    ip.set_target_text(random.choice(ip.refuses))
+            elif s["target_random"]:
+                text = random.choice(ips[-1].target_texts)
+                for ip in ips:
+                    ip.set_target_text(text)
         inputs = [ip.get_inputs_train() for ip in ips]
         sigma = float(ora.sigma)
         assert close((s["zs"][t][-1] * sigma).std(), g[f"{n}_noise_std"][t], 1e-5, 1e-12)      # `noise` of the last model is logged
