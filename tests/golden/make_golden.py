@@ -576,6 +576,12 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None):
             arrays[f"{name}_final"] = np.fromfile(os.path.join("runs", "run", "optimized_image_iter_final.bin"), dtype=np.float32)
             arrays[f"{name}_mask_sum"] = np.array(float(torch.load(os.path.join("runs", "run", "mask.pt")).sum()))
             arrays[f"{name}_files"] = np.array(sorted(f for f in os.listdir(os.path.join("runs", "run"))))
+            import csv
+            with open(os.path.join("runs", "run", "test_results_iter_0.csv"), newline="", encoding="utf-8") as fcsv:
+                arrays[f"{name}_probe0"] = np.array([row for row in csv.reader(fcsv)])     # the generation probe at iteration 0 (train_test.py)
+            arrays[f"{name}_probe0_stats"] = np.array([[r.get(k) for k in ("test_target_first_word_acc", "test_target_acc", "test_refuse_count",
+                                                                           "test_total_questions")]
+                                                       for r in rec.rows if "test_target_acc" in r][0], dtype=np.float64)
             # the batch the reference's AdvLlavaInputs assembles for this prompt (llavaprocessor.py:80-108), for the id layout
             load_fn, AdvCls, _ = table[model_name]
             _, proc = load_fn(model_name, "cpu")

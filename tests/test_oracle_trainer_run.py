@@ -244,3 +244,28 @@ def test_oracle_loop_reproduces_the_reference_cross_trainers_log(n):
             assert close(sum(rs) / k, g[f"{n}_loss_resaved"][t])
         last_s = ref["s"]
     assert rel_err(last_s.flatten(), g[f"{n}_final"]) <= 1e-6
+
+
+@pytest.mark.parametrize("n,batched", [("d", True), ("d", False), ("e", True), ("e", False)])
+def test_generation_probe_equals_the_reference_probes_csv(tmp_path, n, batched):
+    """`train_test.run_model_test` of this package (one left-padded `generate` per chunk of questions, or the reference's serial
+    form) against the CSV and the statistics the reference's own `run_model_test` (train_test.py:6-86) produced at iteration 0 of
+    its runs d (Llama-3.2-Vision architecture) and e (Qwen2-VL architecture): same header, same questions, same generated text,
+    same four rates.  On the CPU: these two processors make their own pixel_values from the PNG, the HIP path is not involved."""
+    import csv
+
+    from adversarialvlm_amd.train_test import run_model_test
+    g = load_golden("trainer_run_reference.npz")
+    s = run_setup(g, n)
+    ip = make_inputs(s)
+    name = str(g[f"{n}_model"])
+    want = [[str(c) for c in row] for row in g[f"{n}_probe0"]]
+    questions = [row[0] for row in want[1:]]
+    first, log = run_model_test([s["model"]], [s["proc"]], [ip], [name], questions, ip.target_texts[0], str(tmp_path), 0, s["img"],
+                                batched=batched)
+    with open(tmp_path / "test_results_iter_0.csv", newline="", encoding="utf-8") as f:
+        got = [row for row in csv.reader(f)]
+    assert got == want
+    assert first == want[1]
+    stats = [log[k] for k in ("test_target_first_word_acc", "test_target_acc", "test_refuse_count", "test_total_questions")]
+    assert stats == [float(v) for v in g[f"{n}_probe0_stats"]]
