@@ -37,8 +37,6 @@ def _close(a, b, tol, floor=0.0):
 
 @pytest.mark.parametrize("n", RUNS)
 def test_train_equals_the_reference_trainers_run(tmp_path, n):
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_oracle_trainer_run import run_setup
 
     from adversarialvlm_amd import attack_model
@@ -99,8 +97,6 @@ def test_cross_train_equals_the_reference_cross_trainers_run(tmp_path, n):
     reference side running its own AdvMllamaInputs / AdvQwen2VLInputs / Differentiable*Processor classes.  Per model
     w_i CE_i + image loss (:369), their mean, `loss_resaved`, the quantise-error statistics, gradient norm, learning rate,
     optimiser-step count, the final image and the checkpoint names."""
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_oracle_trainer_run import cross_setup
 
     from adversarialvlm_amd import crossattack_models
