@@ -535,7 +535,10 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None):
             # the draws of the loop: prompts sampled with replacement from the pool (--prompt list) and a target drawn per
             # iteration (--target_text_random: multi-answer supervision), both from the global `random` stream (:283-292)
             ("f", dict(grad_accum_steps=1, mask_type=None, mask_size=None, scheduler_step_size=100, scheduler_gamma=1.0,
-                       start_from_white=False, batch_size=3, prompt="list", target_text_random=True), (3, 56, 56), 5, 16)]
+                       start_from_white=False, batch_size=3, prompt="list", target_text_random=True), (3, 56, 56), 5, 16),
+            # BASELINE configs[0] as written: tanh-clamp attack, 1 prompt, 2 PGD steps, on the CPU - the reference's own run of it
+            ("g", dict(grad_accum_steps=1, mask_type=None, mask_size=None, scheduler_step_size=100, scheduler_gamma=1.0,
+                       start_from_white=False, batch_size=1), (3, 56, 56), 2, 17)]
     arrays = {}
     cwd = os.getcwd()
     for name, kw, ishape, iters, seed in runs:

@@ -19,7 +19,7 @@ from oracle import pixel_ops as P
 from oracle.pgd import PGDOracle
 from oracle.processors import LlavaOracle
 
-RUNS = ["a", "b", "c", "d", "e", "f"]
+RUNS = ["a", "b", "c", "d", "e", "f", "g"]        # g = BASELINE configs[0]: 1 prompt, 2 PGD steps
 TOL = 2e-5        # same torch ops on both sides; the model's GEMMs may take another code path on another CPU
 
 
