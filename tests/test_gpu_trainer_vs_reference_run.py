@@ -138,3 +138,143 @@ def test_cross_train_equals_the_reference_cross_trainers_run(tmp_path, n):
     theirs = {str(f) for f in g[f"{n}_files"] if not str(f).startswith("test_results")}
     assert theirs <= ours, sorted(theirs - ours)
     assert not {f for f in ours - theirs if f.startswith("optimized_image")}
+
+
+# ------------------------------------------------------------------------------ data parallelism against the reference run
+def _dp_rank(rank, world, port, tmp, n, transport, out):
+    """One rank of a two-rank run of `attack_model.train()`: the reference run's batch of 2 is sharded, rank r takes sample r
+    of every noise draw; the image gradient is all-reduced (peer segments or the host library, gloo here)."""
+    import torch.distributed as dist
+    from test_oracle_trainer_run import run_setup
+
+    from adversarialvlm_amd import attack_model
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    g = load_golden("trainer_run_reference.npz")
+    s = run_setup(g, n)
+    assert s["B"] == world
+    fam = s["fam"]
+    kind, size = (int(v) for v in g[f"{n}_mask"])
+    step, gamma = g[f"{n}_sched"]
+    eng, hist = attack_model.train(
+        exp_name=f"dp_{transport}", img_orig=os.path.join(tmp, "in.png"), prompt=s["prompt"], target_text="sure here it is",
+        model_name=str(g[f"{n}_model"]), lr=1e-2, num_iterations=s["iters"], save_steps=2, batch_size=s["B"],
+        grad_accum_steps=int(g[f"{n}_accum"]), scheduler_step_size=int(step), scheduler_gamma=float(gamma), restart_num=0,
+        mask_type={0: "corner", 1: "bottom_lines", -1: None}[kind], mask_size=size if kind >= 0 else None, clamp_method="tanh",
+        epsilon=0.5, sigma=1e-3, start_from_white=bool(int(g[f"{n}_white"])), target_text_random=False, base_path=tmp,
+        components=((lambda model_name, device: fam[0](device)), fam[1], fam[2]), return_engine=True, log_every=1,
+        exchange_transport=transport, seed=s["seed"],
+        unit_noise_fn=lambda it, shape: s["zs"][it][rank:rank + 1].reshape(shape))
+    out[rank] = (eng.p.cpu(), hist, eng.exchange_report)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("n,transport", [("a", "peer"), ("a", "rccl"), ("b", "peer")])
+def test_two_ranks_reproduce_the_reference_trainers_batch_of_two(tmp_path, n, transport):
+    """SURVEY 8(e) against the reference itself: the reference has no data parallelism - its run with batch 2 in ONE process is
+    the truth - and two ranks of this package's trainer with one prompt each, the image gradient summed over the exchange and
+    every loss pre-scaled by 1/world, must arrive where it arrived: same image loss, learning rate, optimiser-step count and
+    quantise-error statistics every iteration (rank 0's log; its CE is the local sample's), same final image; replicas bit-identical."""
+    import socket
+
+    import torch.multiprocessing as mp
+    g = load_golden("trainer_run_reference.npz")
+    tmp = str(tmp_path)
+    Image.fromarray(g[f"{n}_image"]).save(os.path.join(tmp, "in.png"))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_dp_rank, args=(2, port, tmp, n, transport, out), nprocs=2, join=True)
+    (p0, hist, report), (p1, _, _) = out[0], out[1]
+    assert torch.equal(p0, p1)
+    assert report["chosen"] == ("peer" if transport == "peer" else "host"), report
+    npx = g[f"{n}_final"].size
+    for t, h in enumerate(hist):
+        assert _close(h["image_loss"], g[f"{n}_image_loss"][t], 1e-4), t
+        assert _close(h["lr"], g[f"{n}_lr"][t], 1e-6) and int(h["global_iteration"]) == int(g[f"{n}_global_iteration"][t]), t
+        # a gradient-accumulation window is exchanged ONCE, at its end (the reduction is linear): inside the window the logged
+        # norm is the rank's own share; at the window's end it is the norm of the summed gradient, the reference's number
+        if (t + 1) % int(g[f"{n}_accum"]) == 0:
+            assert _close(h["grad norm"], g[f"{n}_grad_norm"][t], 1e-3), t
+        assert abs(h["resave_error_std"] - g[f"{n}_resave_error_std"][t]) <= 1e-4 * g[f"{n}_resave_error_std"][t] + 2 / (255 * (npx - 1) ** 0.5), t
+    final = np.fromfile(os.path.join(tmp, f"dp_{transport}", "optimized_image_iter_final.bin"), dtype=np.float32)
+    want = g[f"{n}_final"]
+    assert float(np.abs(final - want).max()) <= 2e-3 * 0.5 and rel_err(torch.tensor(final), torch.tensor(want), elementwise=None) < 1e-4
+
+
+def _dp_cross_rank(rank, world, port, tmp, n, transport, out):
+    """One rank of `crossattack_models.train()` under data parallelism: rank r holds model r % n_models (one model per rank
+    group, BASELINE configs[3]) and, inside its group, shard r // n_models of the reference run's batch."""
+    import torch.distributed as dist
+    from test_oracle_trainer_run import cross_setup
+
+    from adversarialvlm_amd import crossattack_models
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    g = load_golden("cross_trainer_run_reference.npz")
+    s = cross_setup(g, n)
+    names = s["names"]
+    group, shard = world // len(names), rank // len(names)
+    local = s["B"] // group
+    kind, size = (int(v) for v in g[f"{n}_mask"])
+    components = {m: ((lambda name, device, m=m: s["fam"][m][0](device)), s["fam"][m][1], s["fam"][m][2]) for m in names}
+    eng, hist = crossattack_models.train(
+        exp_name=f"dpx_{world}_{transport}", img_orig=os.path.join(tmp, "in.png"), prompt=s["prompt"], target_text="sure here it is",
+        model_names=names, lr=1e-2, num_iterations=s["iters"], save_steps=2, batch_size=s["B"], grad_accum_steps=s["opt"]["grad_accum_steps"],
+        scheduler_step_size=s["opt"]["scheduler_step_size"], scheduler_gamma=s["opt"]["scheduler_gamma"], restart_num=0,
+        mask_type={0: "corner", 1: "bottom_lines", -1: None}[kind], mask_size=size if kind >= 0 else None, clamp_method="tanh",
+        epsilon=0.4, sigma=1e-3, start_from_white=False, target_text_random=False, DPO_flag=False, attack_norm=0.4,
+        model_weights=s["weights"], base_path=tmp, components=components, return_engine=True, log_every=1, seed=s["seed"],
+        exchange_transport=transport,
+        unit_noise_fn=lambda it, i, shape: s["zs"][it][i][shard * local:(shard + 1) * local].reshape(shape))
+    out[rank] = (eng.p.cpu(), hist)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,transport", [(2, "peer"), (4, "peer"), (4, "rccl")])
+def test_model_groups_reproduce_the_reference_cross_trainers_run(tmp_path, world, transport):
+    """BASELINE configs[3] against the reference itself: the reference runs its models one after the other in ONE process
+    (crossattack_models.py:352-391) - run x1, two models with weights 0.7 / 0.3, batch 2 - and this package runs one model per rank
+    group, 2 ranks (one per model) or 4 (two per model, one prompt each), the image gradient averaged inside a group and SUMMED
+    across groups by the one exchange: same image loss, learning rate, optimiser-step count and quantise-error statistics every
+    iteration, rank 0's own model loss where its batch is the whole one, the same final image; replicas bit-identical."""
+    import socket
+
+    import torch.multiprocessing as mp
+    n = "x1"
+    g = load_golden("cross_trainer_run_reference.npz")
+    tmp = str(tmp_path)
+    Image.fromarray(g[f"{n}_image"]).save(os.path.join(tmp, "in.png"))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_dp_cross_rank, args=(world, port, tmp, n, transport, out), nprocs=world, join=True)
+    for r in range(1, world):
+        assert torch.equal(out[0][0], out[r][0]), r
+    hist = out[0][1]
+    names = [str(v) for v in g[f"{n}_names"]]
+    accum = int(g[f"{n}_accum"])
+    npx = g[f"{n}_final"].size
+    for t, h in enumerate(hist):
+        assert _close(h["img_loss"], g[f"{n}_img_loss"][t], 1e-4), t
+        assert _close(h["lr"], g[f"{n}_lr"][t], 1e-6) and int(h["global_iteration"]) == int(g[f"{n}_global_iteration"][t]), t
+        if world == len(names):                                  # rank 0 sees its model's whole batch
+            assert _close(h[f"loss_0_{names[0]}"], g[f"{n}_model_losses"][t][0], 1e-4), t
+        if (t + 1) % accum == 0:                                 # the exchange happens where the optimiser steps
+            assert _close(h["grad_norm"], g[f"{n}_grad_norm"][t], 1e-3), t
+        assert abs(h["resave_error_std"] - g[f"{n}_resave_error_std"][t]) <= 1e-4 * g[f"{n}_resave_error_std"][t] + 2 / (255 * (npx - 1) ** 0.5), t
+    final = np.fromfile(os.path.join(tmp, f"dpx_{world}_{transport}", "optimized_image_iter_final.bin"), dtype=np.float32)
+    want = g[f"{n}_final"]
+    assert float(np.abs(final - want).max()) <= 2e-3 * 0.4 and rel_err(torch.tensor(final), torch.tensor(want), elementwise=None) < 1e-4
