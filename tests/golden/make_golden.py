@@ -449,7 +449,7 @@ def golden_full_size(llava, qwen, phi3, mllama):
                            f"{k}_grad_idx": gidx, f"{k}_grad_val": img.grad.flatten()[gidx]})
     save("full_size_reference.npz", **arrays)
 
-def golden_trainer_run(am, llava, qwen=None, mllama=None):
+def golden_trainer_run(am, llava, qwen=None, mllama=None, phi3=None):
     """The reference's OWN `attack_model.train()` (attack_model.py:108-478), run here on the CPU for a few iterations around a
     tiny random LLaVA-architecture model: what it logs every iteration (loss, image loss, re-saved loss, quantise-error
     mean / std / L1, noise std, gradient norm, learning rate) and the images it writes.  This is the trainer loop itself -
@@ -514,6 +514,15 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None):
         proc.image_processor.min_pixels, proc.image_processor.max_pixels = synthetic_vlms.QWEN_MIN_PIXELS, synthetic_vlms.QWEN_MAX_PIXELS
         return model, proc
     table = {"tiny": (loader, llava.AdvLlavaInputs, llava.DifferentiableLlavaImageProcessor)}
+    if phi3 is not None:
+        # Phi-3.5-Vision's processor and model are remote code: the reference's OWN plugin pair (AdvPhiInputs with its
+        # batch_processing / pad_left, DifferentiablePhi3VImageProcessor) runs here around the interface twin of
+        # adversarialvlm_amd/processors/synthetic_phi3v.py.  The plugin moves every batch `.to("cuda:0")` (phi3processor.py:284,
+        # :302): in this container without a GPU that move is made the identity it would be on a one-device host.
+        from adversarialvlm_amd.processors import synthetic_phi3v
+        _cuda_moves_are_identity_without_a_gpu()
+        table["tiny-phi3v"] = ((lambda name, dev: synthetic_phi3v.load_model_and_processor("synthetic/tiny-phi3v", dev, seed=4)),
+                               phi3.AdvPhiInputs, phi3.DifferentiablePhi3VImageProcessor)
     if mllama is not None:
         table["tiny-mllama"] = (load_mllama, mllama.AdvMllamaInputs, mllama.DifferentiableMllamaImageProcessor)
     if qwen is not None:
@@ -536,6 +545,8 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None):
             # iteration (--target_text_random: multi-answer supervision), both from the global `random` stream (:283-292)
             ("f", dict(grad_accum_steps=1, mask_type=None, mask_size=None, scheduler_step_size=100, scheduler_gamma=1.0,
                        start_from_white=False, batch_size=3, prompt="list", target_text_random=True), (3, 56, 56), 5, 16),
+            ("h", dict(grad_accum_steps=1, mask_type="corner", mask_size=40, scheduler_step_size=100, scheduler_gamma=1.0,
+                       start_from_white=False, model_name="tiny-phi3v", batch_size=2), (3, 60, 90), 3, 18),
             # BASELINE configs[0] as written: tanh-clamp attack, 1 prompt, 2 PGD steps, on the CPU - the reference's own run of it
             ("g", dict(grad_accum_steps=1, mask_type=None, mask_size=None, scheduler_step_size=100, scheduler_gamma=1.0,
                        start_from_white=False, batch_size=1), (3, 56, 56), 2, 17)]
@@ -605,7 +616,21 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None):
             shutil.rmtree(tmp, ignore_errors=True)
     save("trainer_run_reference.npz", **arrays)
 
-def golden_cross_trainer_run(llava, qwen, mllama):
+def _cuda_moves_are_identity_without_a_gpu():
+    """The Phi-3.5 plugin moves every batch `.to("cuda:0")` (phi3processor.py:284,:302): in this container without a GPU that move
+    is made the identity it would be on a one-device host."""
+    from transformers.feature_extraction_utils import BatchFeature
+    if not torch.cuda.is_available() and not getattr(BatchFeature.to, "_cpu_only_container", False):
+        plain_to = BatchFeature.to
+
+        def to(self, *args, **kwargs):
+            args = tuple("cpu" if (isinstance(a, str) and a.startswith("cuda")) else a for a in args)
+            return plain_to(self, *args, **kwargs)
+        to._cpu_only_container = True
+        BatchFeature.to = to
+
+
+def golden_cross_trainer_run(llava, qwen, mllama, phi3=None):
     """The reference's OWN `crossattack_models.train()` (crossattack_models.py:124-519) on the CPU: (x1) two tiny random
     LLaVA models with weights 0.7 / 0.3, batch 2, gradient accumulation 2, StepLR decay, a corner mask; (x2) one model of each
     family whose architecture ships with transformers - LLaVA, Llama-3.2-Vision, Qwen2-VL (adversarialvlm_amd/processors/
@@ -669,6 +694,11 @@ def golden_cross_trainer_run(llava, qwen, mllama):
                         mllama.AdvMllamaInputs, mllama.DifferentiableMllamaImageProcessor),
         "tiny-qwen2vl": (load_qwen, qwen.AdvQwen2VLInputs, qwen.DifferentiableQwen2VLImageProcessor),
     }
+    if phi3 is not None:
+        from adversarialvlm_amd.processors import synthetic_phi3v
+        _cuda_moves_are_identity_without_a_gpu()
+        table["tiny-phi3v"] = ((lambda name, dev: synthetic_phi3v.load_model_and_processor("synthetic/tiny-phi3v", dev, seed=4)),
+                               phi3.AdvPhiInputs, phi3.DifferentiablePhi3VImageProcessor)
     cm.load_components = lambda name: table[name]
 
     runs = [("x1", ["tiny-llava-0", "tiny-llava-1"], dict(batch_size=2, grad_accum_steps=2, scheduler_step_size=1, scheduler_gamma=0.5,
@@ -680,10 +710,16 @@ def golden_cross_trainer_run(llava, qwen, mllama):
             # for all models; prompts sampled from the pool
             ("x3", ["tiny-llava-0", "tiny-llava-1"],
              dict(batch_size=2, grad_accum_steps=1, scheduler_step_size=100, scheduler_gamma=0.9, mask_type=None, mask_size=None,
-                  model_weights=[1.0, 0.5], prompt="list", target_text_random=True, DPO_flag=True, refuse_prob=0.5), (56, 56), 6, 23)]
+                  model_weights=[1.0, 0.5], prompt="list", target_text_random=True, DPO_flag=True, refuse_prob=0.5), (56, 56), 6, 23),
+            # BASELINE configs[3] by name: Phi-3.5-Vision + Qwen2-VL + Llama-3.2-Vision, the weights of scripts/attacks/attack_cross.sh
+            ("x4", ["tiny-phi3v", "tiny-qwen2vl", "tiny-mllama"],
+             dict(batch_size=1, grad_accum_steps=1, scheduler_step_size=100, scheduler_gamma=0.9, mask_type=None, mask_size=None,
+                  model_weights=[0.2, 0.8, 1.6]), (60, 90), 3, 24)]
     arrays = {}
     cwd = os.getcwd()
     for name, names, kw, (H, W), iters, seed in runs:
+        if any(m not in table for m in names):
+            continue
         kw = dict(kw)
         prompt, ttr = kw.pop("prompt", "describe this image"), kw.pop("target_text_random", False)
         dpo, refuse_prob = kw.pop("DPO_flag", False), kw.pop("refuse_prob", 0.1)
@@ -740,9 +776,9 @@ def main():
     if only in (None, "full_size"):
         golden_full_size(llava, qwen, phi3, mllama)
     if only == "trainer_run":
-        golden_trainer_run(import_reference_trainer(), llava, qwen, mllama)
+        golden_trainer_run(import_reference_trainer(), llava, qwen, mllama, phi3)
     if only == "cross_trainer_run":
-        golden_cross_trainer_run(llava, qwen, mllama)
+        golden_cross_trainer_run(llava, qwen, mllama, phi3)
     if only is not None:
         return
     golden_llava(llava)
@@ -754,8 +790,8 @@ def main():
     golden_trainer_helpers(import_reference_trainer())
     golden_closed_form()
     golden_mllama_restated()
-    golden_trainer_run(import_reference_trainer(), llava, qwen, mllama)      # last: these replace the wandb placeholder by a recorder
-    golden_cross_trainer_run(llava, qwen, mllama)
+    golden_trainer_run(import_reference_trainer(), llava, qwen, mllama, phi3)      # last: these replace the wandb placeholder by a recorder
+    golden_cross_trainer_run(llava, qwen, mllama, phi3)
 
 
 if __name__ == "__main__":

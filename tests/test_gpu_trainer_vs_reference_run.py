@@ -19,7 +19,7 @@ from PIL import Image
 from conftest import load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
-RUNS = ["a", "b", "c", "d", "e", "f", "g"]   # g: BASELINE configs[0] (1 prompt, 2 PGD steps); d: Llama-3.2-Vision architecture + localized patch (configs[2]); e: Qwen2-VL;
+RUNS = ["a", "b", "c", "d", "e", "f", "g", "h"]   # h: the reference's Phi-3.5 plugin pair around the interface twin; g: BASELINE configs[0] (1 prompt, 2 PGD steps); d: Llama-3.2-Vision architecture + localized patch (configs[2]); e: Qwen2-VL;
                                          # f: prompts sampled from the pool + a target drawn per iteration (the global `random` stream)
 
 
@@ -90,7 +90,7 @@ def test_train_equals_the_reference_trainers_run(tmp_path, n):
     assert float(mask.sum()) == float(g[f"{n}_mask_sum"])
 
 
-@pytest.mark.parametrize("n", ["x1", "x2", "x3"])      # x3: the coin, a refusal per model or one target for all, sampled prompts
+@pytest.mark.parametrize("n", ["x1", "x2", "x3", "x4"])      # x4: Phi-3.5 + Qwen2-VL + Llama-3.2-Vision (configs[3]); x3: the coin, a refusal per model or one target for all, sampled prompts
 def test_cross_train_equals_the_reference_cross_trainers_run(tmp_path, n):
     """`crossattack_models.train()` of this package beside the reference's own (cross_trainer_run_reference.npz): x1 two LLaVA
     models with weights and gradient accumulation; x2 one model of each family whose architecture ships with transformers, the

@@ -19,14 +19,14 @@ from oracle import pixel_ops as P
 from oracle.pgd import PGDOracle
 from oracle.processors import LlavaOracle
 
-RUNS = ["a", "b", "c", "d", "e", "f", "g"]        # g = BASELINE configs[0]: 1 prompt, 2 PGD steps
+RUNS = ["a", "b", "c", "d", "e", "f", "g", "h"]   # g = BASELINE configs[0]: 1 prompt, 2 PGD steps; h = the Phi-3.5 plugin pair
 TOL = 2e-5        # same torch ops on both sides; the model's GEMMs may take another code path on another CPU
 
 
 def families():
     """name in the captures -> (loader(device), AdvInputs, DifferentiableProcessor, oracle processor factory)"""
-    from adversarialvlm_amd.processors import synthetic, synthetic_vlms as S
-    from oracle.processors import MllamaOracle, Qwen2VLOracle
+    from adversarialvlm_amd.processors import synthetic, synthetic_phi3v as F3, synthetic_vlms as S
+    from oracle.processors import MllamaOracle, Phi3Oracle, Qwen2VLOracle
     llava0 = (lambda d: synthetic.load_model_and_processor("synthetic/tiny-llava", d, seed=0), synthetic.AdvLlavaInputs,
               synthetic.DifferentiableLlavaImageProcessor, lambda: LlavaOracle(56, 56))
     return {"tiny": llava0, "tiny-llava-0": llava0,
@@ -34,6 +34,8 @@ def families():
                              synthetic.DifferentiableLlavaImageProcessor, lambda: LlavaOracle(56, 56)),
             "tiny-mllama": (lambda d: S.load_model_and_processor("synthetic/tiny-mllama", d, seed=2), S.AdvMllamaInputs,
                             S.DifferentiableMllamaImageProcessor, lambda: MllamaOracle(tile=S.MLLAMA_TILE, max_tiles=S.MLLAMA_MAX_TILES)),
+            "tiny-phi3v": (lambda d: F3.load_model_and_processor("synthetic/tiny-phi3v", d, seed=4), F3.AdvPhiInputs,
+                           F3.DifferentiablePhi3VImageProcessor, lambda: Phi3Oracle(num_crops=F3.PHI_NUM_CROPS)),
             "tiny-qwen2vl": (lambda d: S.load_model_and_processor("synthetic/tiny-qwen2vl", d, seed=3), S.AdvQwen2VLInputs,
                              S.DifferentiableQwen2VLImageProcessor,
                              lambda: Qwen2VLOracle(min_pixels=S.QWEN_MIN_PIXELS, max_pixels=S.QWEN_MAX_PIXELS))}
@@ -157,7 +159,7 @@ def test_oracle_loop_reproduces_the_reference_trainers_log(n):
 
 
 # ------------------------------------------------------------------------------------------ the cross-model trainer
-CROSS = ["x1", "x2", "x3"]
+CROSS = ["x1", "x2", "x3", "x4"]          # x4 = BASELINE configs[3] by name: Phi-3.5 + Qwen2-VL + Llama-3.2-Vision
 
 
 def cross_setup(g, n, device="cpu"):
@@ -246,7 +248,7 @@ def test_oracle_loop_reproduces_the_reference_cross_trainers_log(n):
     assert rel_err(last_s.flatten(), g[f"{n}_final"]) <= 1e-6
 
 
-@pytest.mark.parametrize("n,batched", [("d", True), ("d", False), ("e", True), ("e", False)])
+@pytest.mark.parametrize("n,batched", [("d", True), ("d", False), ("e", True), ("e", False), ("h", True), ("h", False)])
 def test_generation_probe_equals_the_reference_probes_csv(tmp_path, n, batched):
     """`train_test.run_model_test` of this package (one left-padded `generate` per chunk of questions, or the reference's serial
     form) against the CSV and the statistics the reference's own `run_model_test` (train_test.py:6-86) produced at iteration 0 of
