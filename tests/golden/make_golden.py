@@ -547,6 +547,10 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None, phi3=None):
                        start_from_white=False, batch_size=3, prompt="list", target_text_random=True), (3, 56, 56), 5, 16),
             ("h", dict(grad_accum_steps=1, mask_type="corner", mask_size=40, scheduler_step_size=100, scheduler_gamma=1.0,
                        start_from_white=False, model_name="tiny-phi3v", batch_size=2), (3, 60, 90), 3, 18),
+            # --restart_num: the reference clamps and re-quantises a LOCAL x every restart_num iterations (:447-457), which the next
+            # iteration overwrites from p - a no-op on the trajectory (Q5); run i is run a with restart_num 2
+            ("i", dict(grad_accum_steps=1, mask_type="corner", mask_size=30, scheduler_step_size=2, scheduler_gamma=0.5,
+                       start_from_white=False, restart_num=2), (3, 64, 48), 5, 11),
             # BASELINE configs[0] as written: tanh-clamp attack, 1 prompt, 2 PGD steps, on the CPU - the reference's own run of it
             ("g", dict(grad_accum_steps=1, mask_type=None, mask_size=None, scheduler_step_size=100, scheduler_gamma=1.0,
                        start_from_white=False, batch_size=1), (3, 56, 56), 2, 17)]
@@ -556,6 +560,7 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None, phi3=None):
         kw = dict(kw)
         model_name, batch = kw.pop("model_name", "tiny"), kw.pop("batch_size", 2)
         prompt, ttr = kw.pop("prompt", "describe this image"), kw.pop("target_text_random", False)
+        restart = kw.pop("restart_num", 0)
         if model_name not in table:
             continue
         tmp = tempfile.mkdtemp()
@@ -568,7 +573,7 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None, phi3=None):
             random.seed(seed)
             torch.manual_seed(seed)
             am.train(exp_name="run", img_orig="in.png", prompt=prompt, target_text="sure here it is",
-                     model_name=model_name, lr=1e-2, num_iterations=iters, save_steps=2, batch_size=batch, restart_num=0,
+                     model_name=model_name, lr=1e-2, num_iterations=iters, save_steps=2, batch_size=batch, restart_num=restart,
                      clamp_method="tanh", epsilon=0.5, sigma=1e-3, target_text_random=ttr, **kw)
             per_iter = [r for r in rec.rows if "loss_resaved" in r]
             assert len(per_iter) == iters
@@ -580,6 +585,7 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None, phi3=None):
             arrays[f"{name}_seed"] = np.array(seed)
             arrays[f"{name}_model"], arrays[f"{name}_batch"] = np.array(model_name), np.array(batch)
             arrays[f"{name}_prompt"], arrays[f"{name}_target_random"] = np.array(prompt), np.array(int(ttr))
+            arrays[f"{name}_restart"] = np.array(restart)
             arrays[f"{name}_questions"] = np.array(q.not_safe_questions + q.questions)        # the pool as train() forms it (:144)
             arrays[f"{name}_answers"] = np.array(a.answers + a.adv_answers)                   # (:147-148)
             arrays[f"{name}_iters"] = np.array(iters)

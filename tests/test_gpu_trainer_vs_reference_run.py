@@ -19,7 +19,7 @@ from PIL import Image
 from conftest import load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
-RUNS = ["a", "b", "c", "d", "e", "f", "g", "h"]   # h: the reference's Phi-3.5 plugin pair around the interface twin; g: BASELINE configs[0] (1 prompt, 2 PGD steps); d: Llama-3.2-Vision architecture + localized patch (configs[2]); e: Qwen2-VL;
+RUNS = ["a", "b", "c", "d", "e", "f", "g", "h", "i"]   # i: run a with --restart_num 2; h: the reference's Phi-3.5 plugin pair around the interface twin; g: BASELINE configs[0] (1 prompt, 2 PGD steps); d: Llama-3.2-Vision architecture + localized patch (configs[2]); e: Qwen2-VL;
                                          # f: prompts sampled from the pool + a target drawn per iteration (the global `random` stream)
 
 
@@ -54,7 +54,7 @@ def test_train_equals_the_reference_trainers_run(tmp_path, n):
     eng, hist = attack_model.train(
         exp_name="run", img_orig=os.path.join(tmp, "in.png"), prompt=s["prompt"], target_text="sure here it is",
         model_name=str(g[f"{n}_model"]), lr=1e-2, num_iterations=iters, save_steps=2, batch_size=s["B"], grad_accum_steps=accum,
-        scheduler_step_size=int(step), scheduler_gamma=float(gamma), restart_num=0,
+        scheduler_step_size=int(step), scheduler_gamma=float(gamma), restart_num=int(g[f"{n}_restart"]),
         mask_type={0: "corner", 1: "bottom_lines", -1: None}[kind], mask_size=size if kind >= 0 else None, clamp_method="tanh",
         epsilon=0.5, sigma=1e-3, start_from_white=bool(int(g[f"{n}_white"])), target_text_random=s["target_random"], base_path=tmp,
         components=components, **_pools(tmp, s), return_engine=True, resaved_loss_every=1, log_every=1, unit_noise_fn=lambda it, shape: zs[it].view(shape))

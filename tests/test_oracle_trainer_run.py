@@ -19,7 +19,7 @@ from oracle import pixel_ops as P
 from oracle.pgd import PGDOracle
 from oracle.processors import LlavaOracle
 
-RUNS = ["a", "b", "c", "d", "e", "f", "g", "h"]   # g = BASELINE configs[0]: 1 prompt, 2 PGD steps; h = the Phi-3.5 plugin pair
+RUNS = ["a", "b", "c", "d", "e", "f", "g", "h", "i"]   # i = run a with --restart_num 2 (a no-op, Q5); g = BASELINE configs[0]: 1 prompt, 2 PGD steps; h = the Phi-3.5 plugin pair
 TOL = 2e-5        # same torch ops on both sides; the model's GEMMs may take another code path on another CPU
 
 
@@ -156,6 +156,15 @@ def test_oracle_loop_reproduces_the_reference_trainers_log(n):
         last_s = ref["s"]
     # the image written at the end is x_0 + x of the LAST iteration's forward, i.e. before that iteration's update (:473-477)
     assert rel_err(last_s.flatten(), g[f"{n}_final"]) <= 1e-6
+
+
+def test_restart_num_is_a_no_op_in_the_reference():
+    """Q5, from the reference's own runs: with --restart_num 2 its train() logs the same numbers and writes the same image as
+    without (the clamp-and-requantise of :447-457 rebinds a local the next iteration overwrites)."""
+    g = load_golden("trainer_run_reference.npz")
+    assert int(g["i_restart"]) == 2 and int(g["a_restart"]) == 0
+    for k in ("loss", "image_loss", "loss_resaved", "resave_error_std", "grad_norm", "lr", "final"):
+        assert np.array_equal(g[f"a_{k}"], g[f"i_{k}"]), k
 
 
 # ------------------------------------------------------------------------------------------ the cross-model trainer
