@@ -739,9 +739,11 @@ def golden_cross_trainer_run(llava, qwen, mllama, phi3=None):
             random.seed(seed)
             torch.manual_seed(seed)
             cm.train(exp_name="run", img_orig="in.png", prompt=prompt, target_text="sure here it is",
-                     model_names=names, lr=1e-2, num_iterations=iters, save_steps=2, restart_num=0, clamp_method="tanh", epsilon=0.4,
-                     sigma=1e-3, start_from_white=False, target_text_random=ttr, DPO_flag=dpo, refuse_prob=refuse_prob,
-                     attack_norm=0.4, **kw)
+                     model_names=names, lr=1e-2, num_iterations=iters, save_steps=2, restart_num=0, clamp_method="tanh",
+                     # Q3: the amplitude of the perturbation is `attack_norm`, --epsilon only reaches the log (:277, :329);
+                     # --sigma is not used either, the first noise level is a literal 0.001 (:299): both set to values that would show
+                     epsilon=0.3, sigma=5e-3, attack_norm=0.4,
+                     start_from_white=False, target_text_random=ttr, DPO_flag=dpo, refuse_prob=refuse_prob, **kw)
             per_iter = [r for r in rec.rows if "loss_per_iteration" in r]
             assert len(per_iter) == iters
             keys = ["loss_per_iteration", "img_loss", "loss_resaved", "resave_error_mean", "resave_error_std", "resave_error_l1",

@@ -112,7 +112,7 @@ def test_cross_train_equals_the_reference_cross_trainers_run(tmp_path, n):
         model_names=names, lr=1e-2, num_iterations=iters, save_steps=2, batch_size=s["B"], grad_accum_steps=accum,
         scheduler_step_size=s["opt"]["scheduler_step_size"], scheduler_gamma=s["opt"]["scheduler_gamma"], restart_num=0,
         mask_type={0: "corner", 1: "bottom_lines", -1: None}[kind], mask_size=size if kind >= 0 else None, clamp_method="tanh",
-        epsilon=0.4, sigma=1e-3, start_from_white=False, target_text_random=s["target_random"], DPO_flag=s["dpo"],
+        epsilon=0.3, sigma=5e-3, start_from_white=False, target_text_random=s["target_random"], DPO_flag=s["dpo"],   # Q3: neither is used
         refuse_prob=s["refuse_prob"], attack_norm=0.4, model_weights=s["weights"], base_path=tmp, components=components, **_pools(tmp, s), return_engine=True, resaved_loss_every=1, log_every=1,
         unit_noise_fn=lambda it, i, shape: s["zs"][it][i].view(shape))
     assert len(hist) == iters
@@ -231,7 +231,7 @@ def _dp_cross_rank(rank, world, port, tmp, n, transport, out):
         model_names=names, lr=1e-2, num_iterations=s["iters"], save_steps=2, batch_size=s["B"], grad_accum_steps=s["opt"]["grad_accum_steps"],
         scheduler_step_size=s["opt"]["scheduler_step_size"], scheduler_gamma=s["opt"]["scheduler_gamma"], restart_num=0,
         mask_type={0: "corner", 1: "bottom_lines", -1: None}[kind], mask_size=size if kind >= 0 else None, clamp_method="tanh",
-        epsilon=0.4, sigma=1e-3, start_from_white=False, target_text_random=False, DPO_flag=False, attack_norm=0.4,
+        epsilon=0.3, sigma=5e-3, start_from_white=False, target_text_random=False, DPO_flag=False, attack_norm=0.4,
         model_weights=s["weights"], base_path=tmp, components=components, return_engine=True, log_every=1, seed=s["seed"],
         exchange_transport=transport,
         unit_noise_fn=lambda it, i, shape: s["zs"][it][i][shard * local:(shard + 1) * local].reshape(shape))
