@@ -23,7 +23,6 @@ from types import SimpleNamespace
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference/src"
