@@ -546,6 +546,10 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None, phi3=None):
                        start_from_white=False, batch_size=3, prompt="list", target_text_random=True), (3, 56, 56), 5, 16),
             ("h", dict(grad_accum_steps=1, mask_type="corner", mask_size=40, scheduler_step_size=100, scheduler_gamma=1.0,
                        start_from_white=False, model_name="tiny-phi3v", batch_size=2), (3, 60, 90), 3, 18),
+            # Qwen2-VL with prompts of different lengths in one batch: the REAL fast tokenizer's left padding, `mm_token_type_ids`
+            # padded with it, three images in one processor call (qwen2VLprocessor.py:68-96)
+            ("j", dict(grad_accum_steps=1, mask_type=None, mask_size=None, scheduler_step_size=100, scheduler_gamma=1.0,
+                       start_from_white=False, model_name="tiny-qwen2vl", batch_size=3, prompt="list"), (3, 60, 90), 3, 19),
             # --restart_num: the reference clamps and re-quantises a LOCAL x every restart_num iterations (:447-457), which the next
             # iteration overwrites from p - a no-op on the trajectory (Q5); run i is run a with restart_num 2
             ("i", dict(grad_accum_steps=1, mask_type="corner", mask_size=30, scheduler_step_size=2, scheduler_gamma=0.5,

@@ -19,7 +19,7 @@ from PIL import Image
 from conftest import load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
-RUNS = ["a", "b", "c", "d", "e", "f", "g", "h", "i"]   # i: run a with --restart_num 2; h: the reference's Phi-3.5 plugin pair around the interface twin; g: BASELINE configs[0] (1 prompt, 2 PGD steps); d: Llama-3.2-Vision architecture + localized patch (configs[2]); e: Qwen2-VL;
+RUNS = ["a", "b", "c", "d", "e", "f", "g", "h", "i", "j"]   # j: Qwen2-VL, ragged prompts in one batch; i: run a with --restart_num 2; h: the reference's Phi-3.5 plugin pair around the interface twin; g: BASELINE configs[0] (1 prompt, 2 PGD steps); d: Llama-3.2-Vision architecture + localized patch (configs[2]); e: Qwen2-VL;
                                          # f: prompts sampled from the pool + a target drawn per iteration (the global `random` stream)
 
 

@@ -19,7 +19,7 @@ from oracle import pixel_ops as P
 from oracle.pgd import PGDOracle
 from oracle.processors import LlavaOracle
 
-RUNS = ["a", "b", "c", "d", "e", "f", "g", "h", "i"]   # i = run a with --restart_num 2 (a no-op, Q5); g = BASELINE configs[0]: 1 prompt, 2 PGD steps; h = the Phi-3.5 plugin pair
+RUNS = ["a", "b", "c", "d", "e", "f", "g", "h", "i", "j"]   # j = Qwen2-VL, ragged prompts in one batch; i = run a with --restart_num 2 (a no-op, Q5); g = BASELINE configs[0]: 1 prompt, 2 PGD steps; h = the Phi-3.5 plugin pair
 TOL = 2e-5        # same torch ops on both sides; the model's GEMMs may take another code path on another CPU
 
 
