@@ -274,7 +274,7 @@ def build_parser():
     p.add_argument("--start_from_white", action="store_true")
     p.add_argument("--target_text_random", action="store_true")
     p.add_argument("--DPO_flag", action="store_true")
-    p.add_argument("--refuse_prob", type=float, default=0.1)
+    p.add_argument("--refuse_prob", type=float, default=0.0)      # crossattack_models.py:551 (the function default, 0.1, is never reached from the CLI)
     p.add_argument("--epsilon", type=float, default=0.4, help="logged only by the reference (Q3); use --attack_norm")
     p.add_argument("--attack_norm", type=float, default=0.5)
     p.add_argument("--sigma", type=float, default=0.001)

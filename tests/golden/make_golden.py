@@ -772,14 +772,54 @@ def golden_cross_trainer_run(llava, qwen, mllama, phi3=None):
             shutil.rmtree(tmp, ignore_errors=True)
     save("cross_trainer_run_reference.npz", **arrays)
 
+def golden_cli_flags(am):
+    """The command lines of the two trainers as the reference's OWN `main()` functions build them (attack_model.py:482-519,
+    crossattack_models.py:527-575): every option with its type, default, choices and action, read off the parser object at the
+    moment `parse_args` is called.  The free-text defaults of --exp_name / --img_orig / --prompt / --target_text are research
+    content and are not stored (this package's defaults for them are neutral on purpose)."""
+    import argparse
+    import importlib
+    import json
+    cm = importlib.import_module("crossattack_models")
+
+    class Caught(Exception):
+        pass
+
+    def grab(module):
+        plain = argparse.ArgumentParser.parse_args
+
+        def parse_args(self, *a, **k):
+            raise Caught(self)
+        argparse.ArgumentParser.parse_args = parse_args
+        try:
+            module.main()
+        except Caught as c:
+            parser = c.args[0]
+        finally:
+            argparse.ArgumentParser.parse_args = plain
+        rows = []
+        for act in parser._actions:
+            if not act.option_strings or act.dest == "help":
+                continue
+            free_text = act.dest in ("exp_name", "img_orig", "prompt", "target_text")
+            rows.append(dict(flag=act.option_strings[0], dest=act.dest, action=type(act).__name__,
+                             type=getattr(act.type, "__name__", None) if act.type is not None else None,
+                             default=None if free_text else act.default, default_stored=not free_text,
+                             choices=list(act.choices) if act.choices else None, nargs=act.nargs))
+        return rows
+    data = {"attack_model": grab(am), "crossattack_models": grab(cm), "meta": meta()}
+    with open(os.path.join(HERE, "cli_flags_reference.json"), "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+    print("wrote cli_flags_reference.json", {k: len(v) for k, v in data.items() if k != "meta"})
+
 
 def main():
     """python tests/golden/make_golden.py [--only full_size]   (--only: just that fixture file, the others stay untouched)"""
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present: fixtures can only be regenerated in the build container")
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
-    if only not in (None, "full_size", "trainer_run", "cross_trainer_run"):
-        raise SystemExit("--only knows: full_size, trainer_run, cross_trainer_run")
+    if only not in (None, "full_size", "trainer_run", "cross_trainer_run", "cli_flags"):
+        raise SystemExit("--only knows: full_size, trainer_run, cross_trainer_run, cli_flags")
     if only is None:
         golden_index_tensors()        # before the torchvision stub of import_reference() exists
     llava, qwen, phi3 = import_reference()
@@ -790,6 +830,8 @@ def main():
         golden_trainer_run(import_reference_trainer(), llava, qwen, mllama, phi3)
     if only == "cross_trainer_run":
         golden_cross_trainer_run(llava, qwen, mllama, phi3)
+    if only == "cli_flags":
+        golden_cli_flags(import_reference_trainer())
     if only is not None:
         return
     golden_llava(llava)
@@ -801,6 +843,7 @@ def main():
     golden_trainer_helpers(import_reference_trainer())
     golden_closed_form()
     golden_mllama_restated()
+    golden_cli_flags(import_reference_trainer())
     golden_trainer_run(import_reference_trainer(), llava, qwen, mllama, phi3)      # last: these replace the wandb placeholder by a recorder
     golden_cross_trainer_run(llava, qwen, mllama, phi3)
 

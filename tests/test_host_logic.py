@@ -224,3 +224,28 @@ def test_composed_table_row_lengths_are_upper_bounds():
                 checked += 1
     everywhere.__exit__(None, None, None)
     assert checked > 300
+
+
+@pytest.mark.parametrize("which", ["attack_model", "crossattack_models"])
+def test_every_reference_flag_exists_with_the_reference_default(which):
+    """SURVEY App. C from the reference itself: tests/golden/cli_flags_reference.json is read off the parser objects the
+    reference's own `main()` functions build (make_golden.py --only cli_flags).  Every one of its options exists here under the
+    same name, with the same type, action, choices, nargs and default - so the reference's launch scripts run unchanged.  The
+    free-text defaults (--exp_name / --img_orig / --prompt / --target_text) are deliberately different (neutral) and are not in
+    the fixture; the cross trainer's --model_names default differs in the same spirit (the three models of BASELINE configs[3]
+    instead of one)."""
+    import importlib
+    import json
+    import os
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cli_flags_reference.json")))[which]
+    parser = importlib.import_module(f"adversarialvlm_amd.{which}").build_parser()
+    ours = {a.option_strings[0]: a for a in parser._actions if a.option_strings and a.dest != "help"}
+    assert len(ref) == 30
+    for r in ref:
+        a = ours.get(r["flag"])
+        assert a is not None, r["flag"]
+        assert a.dest == r["dest"] and type(a).__name__ == r["action"], r["flag"]
+        assert (getattr(a.type, "__name__", None) if a.type is not None else None) == r["type"], r["flag"]
+        assert (list(a.choices) if a.choices else None) == r["choices"] and a.nargs == r["nargs"], r["flag"]
+        if r["default_stored"] and r["flag"] != "--model_names":
+            assert a.default == r["default"], (r["flag"], a.default, r["default"])
