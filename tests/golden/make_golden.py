@@ -807,7 +807,24 @@ def golden_cli_flags(am):
                              default=None if free_text else act.default, default_stored=not free_text,
                              choices=list(act.choices) if act.choices else None, nargs=act.nargs))
         return rows
-    data = {"attack_model": grab(am), "crossattack_models": grab(cm), "meta": meta()}
+    import inspect
+
+    def signature(fn):
+        return [[n, None if prm.default is inspect.Parameter.empty else prm.default, prm.default is not inspect.Parameter.empty]
+                for n, prm in inspect.signature(fn).parameters.items()]
+    from processors import llavaprocessor, llama32processor, phi3processor, qwen2VLprocessor
+    classes = {}
+    for mod, adv, diff in ((llavaprocessor, "AdvLlavaInputs", "DifferentiableLlavaImageProcessor"),
+                           (llama32processor, "AdvMllamaInputs", "DifferentiableMllamaImageProcessor"),
+                           (phi3processor, "AdvPhiInputs", "DifferentiablePhi3VImageProcessor"),
+                           (qwen2VLprocessor, "AdvQwen2VLInputs", "DifferentiableQwen2VLImageProcessor")):
+        for cname in (adv, diff):
+            cls = getattr(mod, cname)
+            classes[cname] = {"init": signature(cls.__init__),
+                              "methods": sorted(n for n, v in vars(cls).items() if callable(v) and not n.startswith("_"))}
+    data = {"attack_model": grab(am), "crossattack_models": grab(cm), "meta": meta(),
+            "train_signatures": {"attack_model": signature(am.train), "crossattack_models": signature(cm.train)},
+            "plugin_classes": classes}
     with open(os.path.join(HERE, "cli_flags_reference.json"), "w") as f:
         json.dump(data, f, indent=1, sort_keys=True)
     print("wrote cli_flags_reference.json", {k: len(v) for k, v in data.items() if k != "meta"})

@@ -249,3 +249,41 @@ def test_every_reference_flag_exists_with_the_reference_default(which):
         assert (list(a.choices) if a.choices else None) == r["choices"] and a.nargs == r["nargs"], r["flag"]
         if r["default_stored"] and r["flag"] != "--model_names":
             assert a.default == r["default"], (r["flag"], a.default, r["default"])
+
+
+def test_train_signatures_and_plugin_surfaces_follow_the_reference():
+    """The reference's own `train()` signatures and plugin classes, read with `inspect` (cli_flags_reference.json): this package's
+    trainers take the same parameters, in the same order, with the same defaults (a caller of `train(**kwargs)` or of the
+    positional form does not notice the swap; this package's additions come after them), and the plugin classes keep the
+    constructor signatures and every method the trainers and the generation probe call."""
+    import importlib
+    import inspect
+    import json
+    import os
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cli_flags_reference.json")))
+    for which, want in ref["train_signatures"].items():
+        got = list(inspect.signature(importlib.import_module(f"adversarialvlm_amd.{which}").train).parameters.items())
+        assert len(got) >= len(want)
+        for (name, prm), (rname, rdefault, has_default) in zip(got, want):
+            assert name == rname, (which, name, rname)
+            assert (prm.default is not inspect.Parameter.empty) == has_default, (which, name)
+            if has_default:
+                assert prm.default == rdefault, (which, name, prm.default, rdefault)
+    where = {"AdvLlavaInputs": "llavaprocessor", "DifferentiableLlavaImageProcessor": "llavaprocessor",
+             "AdvMllamaInputs": "llama32processor", "DifferentiableMllamaImageProcessor": "llama32processor",
+             "AdvPhiInputs": "phi3processor", "DifferentiablePhi3VImageProcessor": "phi3processor",
+             "AdvQwen2VLInputs": "qwen2VLprocessor", "DifferentiableQwen2VLImageProcessor": "qwen2VLprocessor"}
+    called = {"Adv": {"get_inputs_train", "get_loss", "get_inputs_inference", "set_target_text", "update_target_tokens"},
+              "Dif": {"process", "pil_to_tensor", "tensor2pil"}}
+    for cname, desc in ref["plugin_classes"].items():
+        cls = getattr(importlib.import_module(f"adversarialvlm_amd.processors.{where[cname]}"), cname)
+        got = list(inspect.signature(cls.__init__).parameters.items())
+        for (name, prm), (rname, rdefault, has_default) in zip(got, desc["init"]):
+            assert name == rname, (cname, name, rname)
+            if has_default:
+                assert prm.default == rdefault, (cname, name)
+        assert called[cname[:3]] <= set(desc["methods"])                      # what is called IS part of the reference's surface
+        for m in called[cname[:3]]:
+            assert callable(getattr(cls, m, None)), (cname, m)
+        if cname.startswith("Adv"):
+            assert isinstance(cls.refuses, list) and cls.refuses
