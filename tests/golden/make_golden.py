@@ -822,9 +822,14 @@ def golden_cli_flags(am):
             cls = getattr(mod, cname)
             classes[cname] = {"init": signature(cls.__init__),
                               "methods": sorted(n for n, v in vars(cls).items() if callable(v) and not n.startswith("_"))}
+            if hasattr(cls, "refuses"):      # the refusal prefixes are part of the plugin contract: count and digest, not the text
+                import hashlib
+                classes[cname]["refuses"] = [len(cls.refuses), hashlib.sha256("\n".join(cls.refuses).encode()).hexdigest()]
+    import processors as ref_registry
+    model_map = {k: [v["module"].split(".")[-1], v["input_class"], v["processor_class"]] for k, v in ref_registry.MODEL_MAP.items()}
     data = {"attack_model": grab(am), "crossattack_models": grab(cm), "meta": meta(),
             "train_signatures": {"attack_model": signature(am.train), "crossattack_models": signature(cm.train)},
-            "plugin_classes": classes}
+            "plugin_classes": classes, "model_map": model_map}
     with open(os.path.join(HERE, "cli_flags_reference.json"), "w") as f:
         json.dump(data, f, indent=1, sort_keys=True)
     print("wrote cli_flags_reference.json", {k: len(v) for k, v in data.items() if k != "meta"})

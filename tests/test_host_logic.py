@@ -287,3 +287,28 @@ def test_train_signatures_and_plugin_surfaces_follow_the_reference():
             assert callable(getattr(cls, m, None)), (cname, m)
         if cname.startswith("Adv"):
             assert isinstance(cls.refuses, list) and cls.refuses
+
+
+def test_registry_and_refusal_lists_follow_the_reference():
+    """`MODEL_MAP` of the reference's plugin registry (processors/__init__.py:5-47) and the refusal prefixes of its four input
+    classes (count + sha256, not the text): every model name of the reference resolves here to the same class names in the
+    module of the same name - the evaluation-only judge entry `google/gemma-3-12b-it` excepted, out of scope - and the `refuses`
+    lists the cross trainer draws from (crossattack_models.py:307-309) are the reference's, element for element."""
+    import hashlib
+    import json
+    import os
+
+    from adversarialvlm_amd.processors import MODEL_MAP, load_components
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cli_flags_reference.json")))
+    for name, (module, adv, diff) in ref["model_map"].items():
+        if name == "google/gemma-3-12b-it":
+            assert name not in MODEL_MAP
+            continue
+        info = MODEL_MAP[name]
+        assert [info["module"].split(".")[-1], info["input_class"], info["processor_class"]] == [module, adv, diff], name
+        _, AdvInputs, DiffProc = load_components(name)
+        assert AdvInputs.__name__ == adv and DiffProc.__name__ == diff
+        count, digest = ref["plugin_classes"][adv]["refuses"]
+        assert len(AdvInputs.refuses) == count and hashlib.sha256("\n".join(AdvInputs.refuses).encode()).hexdigest() == digest, adv
+    with pytest.raises(ValueError):
+        load_components("no/such-model")
