@@ -827,7 +827,22 @@ def golden_cli_flags(am):
                 classes[cname]["refuses"] = [len(cls.refuses), hashlib.sha256("\n".join(cls.refuses).encode()).hexdigest()]
     import processors as ref_registry
     model_map = {k: [v["module"].split(".")[-1], v["input_class"], v["processor_class"]] for k, v in ref_registry.MODEL_MAP.items()}
-    data = {"attack_model": grab(am), "crossattack_models": grab(cm), "meta": meta(),
+    # the launch scripts: which trainer each one starts and which options it passes (names only; the values are run settings
+    # and free text).  Lines that are commented out do not count.
+    import re
+    scripts = {}
+    sdir = os.path.join(os.path.dirname(REF), "scripts", "attacks")
+    for fn in sorted(os.listdir(sdir)):
+        if not fn.endswith(".sh"):
+            continue
+        live = [ln for ln in open(os.path.join(sdir, fn)).read().splitlines() if not ln.lstrip().startswith("#")]
+        text = "\n".join(ln.split(" #")[0] for ln in live)
+        entry = re.findall(r"src/([\w-]+)\.py", text)
+        flags = re.findall(r"(?<![\w-])(--[A-Za-z_]\w*)", text)
+        if entry:
+            scripts[fn] = {"entry": entry[0], "flags": sorted(set(flags)),
+                           "entry_in_tree": os.path.exists(os.path.join(REF, entry[0] + ".py"))}
+    data = {"attack_model": grab(am), "crossattack_models": grab(cm), "meta": meta(), "launch_scripts": scripts,
             "train_signatures": {"attack_model": signature(am.train), "crossattack_models": signature(cm.train)},
             "plugin_classes": classes, "model_map": model_map}
     with open(os.path.join(HERE, "cli_flags_reference.json"), "w") as f:

@@ -312,3 +312,27 @@ def test_registry_and_refusal_lists_follow_the_reference():
         assert len(AdvInputs.refuses) == count and hashlib.sha256("\n".join(AdvInputs.refuses).encode()).hexdigest() == digest, adv
     with pytest.raises(ValueError):
         load_components("no/such-model")
+
+
+def test_reference_launch_scripts_find_their_options_here():
+    """scripts/attacks/*.sh of the reference: which trainer each one starts and which options it passes (names only,
+    cli_flags_reference.json).  Every option a script passes to `attack_model.py` / `crossattack_models.py` - or to their
+    `*_M-fork.py` variants, which the reference tree does not contain - is an option of this package's trainer of that name,
+    exactly or as the unambiguous prefix argparse accepts (`--model_name` for the cross trainer's `--model_names`)."""
+    import importlib
+    import json
+    import os
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cli_flags_reference.json")))["launch_scripts"]
+    assert len(ref) >= 15
+    seen = 0
+    for script, d in ref.items():
+        base = d["entry"].replace("_M-fork", "")
+        if base not in ("attack_model", "crossattack_models"):
+            continue                                                  # another experiment's script (e.g. the guard-model attack)
+        seen += 1
+        parser = importlib.import_module(f"adversarialvlm_amd.{base}").build_parser()
+        options = [o for a in parser._actions for o in a.option_strings if o.startswith("--")]
+        for flag in d["flags"]:
+            hits = [o for o in options if o == flag] or [o for o in options if o.startswith(flag)]
+            assert len(hits) == 1, (script, flag, hits)
+    assert seen >= 14
