@@ -597,6 +597,7 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None, phi3=None):
             arrays[f"{name}_mask"] = np.array([{"corner": 0, "bottom_lines": 1, None: -1}[kw["mask_type"]], kw["mask_size"] or 0])
             arrays[f"{name}_white"] = np.array(int(kw["start_from_white"]))
             arrays[f"{name}_final"] = np.fromfile(os.path.join("runs", "run", "optimized_image_iter_final.bin"), dtype=np.float32)
+            arrays[f"{name}_final_png"] = np.asarray(Image.open(os.path.join("runs", "run", "optimized_image_iter_final.png")).convert("RGB"))
             arrays[f"{name}_mask_sum"] = np.array(float(torch.load(os.path.join("runs", "run", "mask.pt")).sum()))
             arrays[f"{name}_files"] = np.array(sorted(f for f in os.listdir(os.path.join("runs", "run"))))
             import csv

@@ -88,6 +88,11 @@ def test_train_equals_the_reference_trainers_run(tmp_path, n):
     assert not extra, sorted(extra)                                                           # no checkpoint the reference did not write
     mask = torch.load(os.path.join(run, "mask.pt"))
     assert float(mask.sum()) == float(g[f"{n}_mask_sum"])
+    # the PNG the evaluation side reads (SafeBench_universal.py:34): the reference's, but for a uint8 level here and there where
+    # the two devices' gradients put s on either side of a level
+    png = np.asarray(Image.open(os.path.join(run, "optimized_image_iter_final.png")).convert("RGB")).astype(np.int32)
+    d = np.abs(png - g[f"{n}_final_png"].astype(np.int32))
+    assert d.max() <= 1 and int((d > 0).sum()) <= max(3, d.size // 2000), (int(d.max()), int((d > 0).sum()))
 
 
 @pytest.mark.parametrize("n", ["x1", "x2", "x3", "x4"])      # x4: Phi-3.5 + Qwen2-VL + Llama-3.2-Vision (configs[3]); x3: the coin, a refusal per model or one target for all, sampled prompts

@@ -156,6 +156,9 @@ def test_oracle_loop_reproduces_the_reference_trainers_log(n):
         last_s = ref["s"]
     # the image written at the end is x_0 + x of the LAST iteration's forward, i.e. before that iteration's update (:473-477)
     assert rel_err(last_s.flatten(), g[f"{n}_final"]) <= 1e-6
+    # ... and its PNG: uint8 TRUNCATION of clamp(s, 0, 1) * 255 (tensor2pil, llavaprocessor.py:151-155; Q1), level for level
+    png = (P.quantise(last_s) * 255).round().to(torch.uint8).permute(1, 2, 0).numpy()
+    assert np.array_equal(png, g[f"{n}_final_png"])
 
 
 def test_restart_num_is_a_no_op_in_the_reference():
