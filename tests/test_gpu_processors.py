@@ -420,3 +420,27 @@ def test_full_size_reference_captures(dev, fam, size):
         assert [int(i.num_tiles)] == ints
     elif fam == "qwen2vl":
         assert [int(i.grid_h) * int(i.grid_w)] == ints
+
+
+@pytest.mark.slow
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("fam,size", [("llava", (2160, 3840)), ("llava", (3000, 17)), ("qwen2vl", (2000, 3000)), ("qwen2vl", (31, 2600)),
+                                      ("mllama", (1352, 1988)), ("mllama", (4000, 700)), ("phi3", (1988, 1352)), ("phi3", (200, 3000))])
+def test_very_large_and_very_oblong_images_against_the_oracle(dev, fam, size):
+    """Sizes far beyond BASELINE's 336 / 512: a 4K frame into LLaVA's 336 crop (35-tap antialiased rows, 8.3 M pixels per channel),
+    images that are almost lines, the largest canvases the processors' own limits allow (Qwen2-VL's max_pixels, four Mllama tiles,
+    Phi-3.5's sixteen-crop budget is 6 here).  Forward and gradient against the oracle at the processors' usual bar - index
+    arithmetic (32-bit per sample, 64-bit across the batch), tap-table row lengths and launch grids are what this exercises."""
+    from adversarialvlm_amd.plan import Plan
+    H, W = size
+    plan, oracle = {"llava": lambda: (Plan.llava(H, W), LlavaOracle()), "qwen2vl": lambda: (Plan.qwen2vl(H, W), Qwen2VLOracle()),
+                    "mllama": lambda: (Plan.mllama(H, W), MllamaOracle()), "phi3": lambda: (Plan.phi3(H, W), Phi3Oracle())}[fam]()
+    img = lcg_tensor((3, H, W), 900 + H % 97) + 0.5
+    x = img.clone().requires_grad_(True)
+    pv_ref = oracle.process(x)["pixel_values"]
+    up = lcg_tensor(tuple(pv_ref.shape), 901)
+    pv_ref.backward(up)
+    pv, grad = _run(plan, img, up, dev)
+    assert tuple(pv.shape) == tuple(pv_ref.shape)
+    assert rel_err(pv, pv_ref.detach()) < TIGHT
+    assert rel_err(grad, x.grad) < 2 * TIGHT
