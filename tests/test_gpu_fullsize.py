@@ -90,3 +90,32 @@ def test_llava_512_blur9_crop_batch64_full_size_composed(dev):
     worst = T._trajectory(dev, x0, [LlavaOracle()], [plan], [64], 3, blur_kernel=9, blur_sigma_fn=lambda t: sig[t],
                           crop_fn=lambda t: windows[t], fused=False, max_ill=12)
     assert worst["grad"] < 1e-5 and worst["pixel_values"] < 1e-5, worst
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("case", ["llava-4k-prepared", "qwen-6mp-blur-crop", "mllama-oblong-cross"])
+def test_trajectories_on_very_large_images(dev, case):
+    """The step itself far beyond BASELINE's sizes: a 4K frame behind LLaVA's processor in the prepared chain (24.9 M optimised
+    values, 35-tap rows), a 2000 x 3000 image behind Qwen2-VL with blur 9 and a crop window per step (generic chain), and a
+    4000 x 700 strip shared by Llama-3.2-Vision and LLaVA in cross mode - two steps each under the trajectory bar.  The vetting budget of p
+    scales with the pixel count here, and says why: a resize that shrinks 11 x spreads every canvas gradient over ~130 image
+    pixels, so at 4K the typical first gradient is 1e-4 and N P(|g| < a few adam_eps) is no longer a handful - measured on the
+    4K case: 1117 of 24.9 M pixels (4.5e-5 of them) sit at |g| ~ 1.7e-8 = adam_eps, where the two implementations' gradients
+    agree to 2e-11 absolute and AdamW's g / (|g| + eps) turns that into 5e-4 of a step.  Budget: 1e-4 of the optimised values;
+    the rule itself (gradient agrees elementwise, every gradient seen <= max(1e3 adam_eps, 1e-3 max|g|)) is unchanged."""
+    from adversarialvlm_amd.plan import Plan
+    from oracle.processors import LlavaOracle
+    g = torch.Generator().manual_seed(46)
+    if case == "llava-4k-prepared":
+        x0 = torch.rand(3, 2160, 3840, generator=g)
+        worst = T._trajectory(dev, x0, [LlavaOracle()], [Plan.llava(2160, 3840)], [2], 2, fused_mode="prepared", max_ill=x0.numel() // 10000)
+    elif case == "qwen-6mp-blur-crop":
+        x0 = torch.rand(3, 2000, 3000, generator=g)
+        wins = [(100, 200, 1500, 2400), (0, 0, 2000, 3000)]
+        worst = T._trajectory(dev, x0, [Qwen2VLOracle()], [Plan.qwen2vl(2000, 3000)], [2], 2, blur_kernel=9, blur_sigma_fn=lambda t: [3.0, 0.7][t],
+                              crop_fn=lambda t: wins[t], fused=False, max_ill=x0.numel() // 10000)
+    else:
+        x0 = torch.rand(3, 4000, 700, generator=g)
+        worst = T._trajectory(dev, x0, [MllamaOracle(), LlavaOracle()], [Plan.mllama(4000, 700), Plan.llava(4000, 700)], [2, 3], 2,
+                              weights=[0.6, 1.4], cross=True, gamma=0.9, max_ill=x0.numel() // 10000)
+    assert worst["grad"] < 1e-5 and worst["pixel_values"] < 1e-5, worst

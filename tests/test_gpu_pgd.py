@@ -46,6 +46,7 @@ ADAM_EPS = 1e-8
 DET_MAX_ILL = 2             # pixels of p a deterministic test's trajectory may have vetted, in total over its steps
 FUZZ_MAX_ILL = 8            # the same for a RANDOM trajectory (tools/fuzz_pgd.py, test_random_trajectories)
 ILL_CONDITIONED = []        # (step, flat pixel index, p engine, p oracle, g engine, g oracle, max|g|) of accepted pixels
+ILL_LARGE = []              # the same for images of more than 2 M optimised values (test_gpu_fullsize's 4K / 6 MP cases), counted apart
 QUANTISER_FLIPS = [0]       # pixels whose uint8 level differed between the implementations (allowed for by a derived bound)
 
 
@@ -64,13 +65,18 @@ def _check_p(step, p_eng, p_ref, g_eng, g_ref, always_tiny, excluded, budget, op
             f"vs {float(p_ref.flatten()[first]):.9g}, g {float(ge[first]):.3e} vs {float(gr[first]):.3e} (max|g| {gmax:.3e})")
     assert optimizer == "adamw", f"{what} - the sign step has no ill-conditioned pixels"
     assert off.numel() <= budget, f"{what}; this trajectory may vet {budget} more"
+    large = p_ref.numel() > 2_000_000
     for k in off.tolist():
         rec = (step, k, float(p_eng.flatten()[k]), float(p_ref.flatten()[k]), float(ge[k]), float(gr[k]), gmax)
         assert abs(ge[k] - gr[k]) <= ELEMENTWISE_BAR * gmax, f"p AND its gradient differ at a pixel: {rec}"
         assert bool(always_tiny[k]), f"p misses the elementwise bar at a pixel that has seen a gradient above max(1e3 adam_eps, 1e-3 max|g|): {rec}"
-        ILL_CONDITIONED.append(rec)
-        print(f"ill-conditioned pixel accepted: step {step}, index {k}, p {rec[2]:.9g} vs {rec[3]:.9g}, "
-              f"g {rec[4]:.3e} vs {rec[5]:.3e} (max|g| {gmax:.3e})")
+        (ILL_LARGE if large else ILL_CONDITIONED).append(rec)
+        if not large:
+            print(f"ill-conditioned pixel accepted: step {step}, index {k}, p {rec[2]:.9g} vs {rec[3]:.9g}, "
+                  f"g {rec[4]:.3e} vs {rec[5]:.3e} (max|g| {gmax:.3e})")
+    if large:
+        worst_g = max(abs(float(gr[k])) for k in off.tolist())
+        print(f"ill-conditioned pixels accepted: step {step}, {off.numel()} of {p_ref.numel()} (largest |g| among them {worst_g:.3e}, max|g| {gmax:.3e})")
     excluded[off] = True
     return int(off.numel())
 
@@ -152,7 +158,11 @@ def _trajectory(dev, x0, oracles, plans, batches, steps, blur_kernel=None, crop_
         q_std_slack = flips ** 0.5 / (255.0 * (s_ref.numel() - 1) ** 0.5)
         upd("sigma", max(0.0, abs(st["sigma_next"] - ref["sigma_next"]) - q_std_slack) / max(ref["sigma_next"], 1e-12))
         upd("imgfit", abs(st["img_loss"] - ref["img_loss"]) / max(ref["img_loss"], 1e-12))
-        upd("grad_norm", abs(st["grad_norm"] - ref["grad_norm"]) / max(ref["grad_norm"], 1e-12))
+        # ||g||: the engine accumulates it in double.  The oracle's `p.grad.norm()` is torch's float32 reduction, which on the CPU
+        # drifts with the element count (1.2e-3 low at 25 M elements, 2e-7 at 1 M: test_gpu_fullsize's 4K case found it) - so the
+        # exact norm of the oracle's own gradient counts as well
+        gn = [ref["grad_norm"], float(ref["grad"].double().norm())]
+        upd("grad_norm", min(abs(st["grad_norm"] - v) / max(v, 1e-12) for v in gn))
         upd("qerr_mean", max(0.0, abs(st["qerr_mean"] - ref["qerr_mean"]) - q_mean_slack) / max(ref["qerr_mean"], 1e-12))
         upd("x_std", abs(st["x_std"] - ref["x_std"]) / max(ref["x_std"], 1e-12) if ref["x_std"] > 0 else 0.0)
         assert eng.current_lr() == pytest.approx(ora.current_lr(), rel=1e-12)
