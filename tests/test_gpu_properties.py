@@ -108,3 +108,61 @@ def test_masked_pixels_never_move(dev):
             eng.backward_update([g])
         assert torch.count_nonzero(eng.p[:, 100:, :]) == 0 and torch.count_nonzero(eng.p[:, :, 100:]) == 0
         assert torch.count_nonzero(eng.p[:, :100, :100]) > 0
+
+
+@pytest.mark.slow
+@pytest.mark.timeout(900)
+def test_tensors_beyond_two_to_the_32_elements(dev):
+    """64-bit addressing across the batch: pixel_values and their gradient with more than 2^32 elements (18 GB in float32 - a
+    fraction of the 288 GB this part has; BASELINE's 64 prompts are 87 MB).  Llama-3.2-Vision's layout with 1200 prompts through
+    emit / collect, and LLaVA's fused pair with 13 000 prompts: every sample is written, the last one like the first; the in-kernel
+    noise of the last rows is N(0, sigma^2) and differs from row to row; a gradient that is zero but for the LAST sample gives, bit
+    for bit, what that sample alone gives."""
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.pgd import PixelPGD
+    from adversarialvlm_amd.plan import Plan
+    gen = torch.Generator().manual_seed(7)
+    # ---- plan-based emit / collect
+    plan = Plan.mllama(336, 336)
+    n, B = plan.out_numel, 1200
+    assert B * n > 2 ** 32
+    img = torch.rand(3, 336, 336, generator=gen).to(dev)
+    one = ops.emit(plan, img, 1)
+    big = ops.emit(plan, img, B)
+    for b in (0, 1, B // 2, B - 2, B - 1):
+        assert torch.equal(big[b], one[0]), b
+    sigma = torch.tensor([0.25], device=dev)
+    noisy = ops.emit(plan, img, B, sigma_dev=sigma, philox=(5, 0), out=big)
+    live = slice(0, 3 * 560 * 560)                       # the first tile holds the image
+    for b in (B - 1, B - 2):
+        z = (noisy[b, live] - one[0, live]) / 0.25
+        assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3, b
+    assert not torch.equal(noisy[B - 1], noisy[B - 2])
+    del noisy
+    big.zero_()
+    row = (torch.randn(n, generator=gen) * 0.01).to(dev)
+    big[B - 1].copy_(row)
+    g_big = ops.collect(plan, big, B)
+    g_one = ops.collect(plan, row.view(1, n), 1)
+    assert torch.equal(g_big, g_one)
+    del big
+    torch.cuda.empty_cache()
+    # ---- the fused pair
+    B = 13000
+    x0 = torch.rand(3, 336, 336, generator=gen).to(dev)
+    engines = [PixelPGD(x0, [Plan.llava(336, 336)], lr=1e-2, fused_mode="pair", seed=3) for _ in range(2)]
+    pv = engines[0].forward(B)[0]
+    assert pv.numel() > 2 ** 32 and tuple(pv.shape) == (B, 3, 336, 336)
+    pv1 = engines[1].forward(1)[0]
+    sig = 1e-3                                           # sigma0: the first step's noise level (attack_model.py:261)
+    for b in (B - 1, B - 2, B // 2):
+        z = (pv[b] - pv[0]) / (sig * 2 ** 0.5)          # difference of two independent draws around the same canvas
+        assert abs(float(z.mean())) < 1e-2 and abs(float(z.std()) - 1.0) < 1e-2, b
+    assert float((pv[0] - pv1[0]).abs().max()) < 10 * sig
+    row = (torch.randn(3, 336, 336, generator=gen) * 0.01).to(dev)
+    g = torch.zeros_like(pv)
+    del pv
+    g[B - 1].copy_(row)
+    engines[0].backward_update([g])
+    engines[1].backward_update([row[None]])
+    assert torch.equal(engines[0].grad, engines[1].grad) and torch.equal(engines[0].p, engines[1].p)
