@@ -323,7 +323,13 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
                    "image_loss": st["img_loss"], "grad norm": st["grad_norm"], "lr": engine.current_lr(),
                    "resave_error_std": st["sigma_next"], "resave_error_mean": st["qerr_mean"],
                    "resave_error_l1": st["qerr_l1"], "adversarial_mean": st["x_mean"], "adversarial_std": st["x_std"],
-                   "noise_sigma": st["sigma"], "sigma": sigma}
+                   "noise_sigma": st["sigma"], "sigma": sigma,
+                   # the reference logs the sample mean / std of the noise tensor it drew (:398-399); the noise here is drawn
+                   # inside the kernel, so these are the generator's parameters - what those statistics estimate
+                   "noise_mean": 0.0, "noise_std": st["sigma"]}
+            if stepped:
+                rec["accumulated_loss"] = accumulated_loss                                  # :349-352, once per optimiser step
+                accumulated_loss = 0.0
             if resaved_loss_every > 0 and iteration % resaved_loss_every == 0:
                 # :375-379 - the loss of the image as a PNG of it would be seen (no noise); a whole
                 # extra VLM forward, so periodic here instead of every step

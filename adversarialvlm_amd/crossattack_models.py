@@ -156,6 +156,7 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
     check_every = int(replica_check_every) if replica_check_every else int(save_steps)
     if world > 1:
         torch.distributed.barrier()          # model loading skews the ranks by far more than a step
+    accumulated_loss = 0.0
     for iteration in range(start_iteration, num_iterations):
         if world > 1:
             reseed_prompt_stream(inputs_processors, seed, rank, iteration)
@@ -205,10 +206,18 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
             st = engine.stats_dict()
             rec = {"iteration": iteration, "global_iteration": global_iteration, "img_loss": st["img_loss"],
                    "grad_norm": st["grad_norm"], "lr": engine.current_lr(), "resave_error_std": st["sigma_next"],
-                   "adversarial_mean": st["x_mean"], "adversarial_std": st["x_std"]}
+                   "resave_error_mean": st["qerr_mean"], "resave_error_l1": st["qerr_l1"],
+                   "adversarial_mean": st["x_mean"], "adversarial_std": st["x_std"],
+                   # the generator's parameters where the reference logs the sample statistics of its draw (:457-458)
+                   "noise_mean": 0.0, "noise_std": st["sigma"],
+                   "use_gaussian_blur": bool(use_gaussian_blur), "gblur_kernel_size": gblur_kernel_size}
             for k, i in enumerate(my_models):
                 rec[f"loss_{i}_{model_names[i].replace('/', '_')}"] = float(losses[k]) * model_weights[i] + st["img_loss"]
             rec["loss_per_iteration"] = float(np.mean([v for kk, v in rec.items() if kk.startswith("loss_")]))
+            accumulated_loss += float(sum(v for kk, v in rec.items() if kk.startswith("loss_") and kk != "loss_per_iteration"))
+            if stepped:
+                rec["accumulated_loss"] = accumulated_loss                                  # :400-404, once per optimiser step
+                accumulated_loss = 0.0
             if resaved_loss_every > 0 and iteration % resaved_loss_every == 0:
                 # :434-445 - every model's loss on the image as its PNG would be read back (no noise),
                 # averaged; one extra forward per model, so periodic here

@@ -580,6 +580,8 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None, phi3=None):
                      clamp_method="tanh", epsilon=0.5, sigma=1e-3, target_text_random=ttr, **kw)
             per_iter = [r for r in rec.rows if "loss_resaved" in r]
             assert len(per_iter) == iters
+            arrays[f"{name}_log_keys"] = np.array(sorted({k for r in rec.rows for k in r}))      # every key the run handed to wandb.log
+            arrays[f"{name}_accumulated_loss"] = np.array([r["accumulated_loss"] for r in rec.rows if "accumulated_loss" in r])
             keys = ["loss", "image_loss", "loss_resaved", "resave_error_mean", "resave_error_std", "resave_error_l1", "noise_mean",
                     "noise_std", "adversarial_mean", "adversarial_std", "lr", "grad norm", "global_iteration"]
             for k in keys:
@@ -750,6 +752,8 @@ def golden_cross_trainer_run(llava, qwen, mllama, phi3=None):
                      start_from_white=False, target_text_random=ttr, DPO_flag=dpo, refuse_prob=refuse_prob, **kw)
             per_iter = [r for r in rec.rows if "loss_per_iteration" in r]
             assert len(per_iter) == iters
+            arrays[f"{name}_log_keys"] = np.array(sorted({k for r in rec.rows for k in r}))
+            arrays[f"{name}_accumulated_loss"] = np.array([r["accumulated_loss"] for r in rec.rows if "accumulated_loss" in r])
             keys = ["loss_per_iteration", "img_loss", "loss_resaved", "resave_error_mean", "resave_error_std", "resave_error_l1",
                     "noise_std", "adversarial_mean", "adversarial_std", "lr", "grad_norm", "global_iteration"]
             for k in keys:

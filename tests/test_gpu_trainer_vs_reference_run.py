@@ -74,6 +74,15 @@ def test_train_equals_the_reference_trainers_run(tmp_path, n):
         assert abs(h["resave_error_l1"] - g[f"{n}_resave_error_l1"][t]) <= 1e-4 * g[f"{n}_resave_error_l1"][t] + 2 / 255, where
         assert _close(h["adversarial_mean"], g[f"{n}_adversarial_mean"][t], 1e-3, 1e-6), where
         assert _close(h["adversarial_std"], g[f"{n}_adversarial_std"][t], 1e-3, 1e-6), where
+    # every scalar key the reference handed to wandb.log is in this trainer's records (the media keys - a table and two images -
+    # have no counterpart in the JSONL log); `accumulated_loss` once per optimiser step, with the reference's values
+    media = {"generated_text", "optimized_image", "optimized_tensor"}
+    probe = {"test_refuse_count", "test_target_acc", "test_target_first_word_acc", "test_total_questions"}      # the probe is off here
+    probe |= {"fix_error_mean", "fix_error_std"}     # --restart_num's two numbers compare a 0..255 image with a [0, 1] perturbation (Q5: not kept)
+    ours_keys = {k for h in hist for k in h}
+    assert {str(k) for k in g[f"{n}_log_keys"]} - media - probe <= ours_keys, sorted({str(k) for k in g[f"{n}_log_keys"]} - media - probe - ours_keys)
+    acc = [h["accumulated_loss"] for h in hist if "accumulated_loss" in h]
+    assert len(acc) == len(g[f"{n}_accumulated_loss"]) and all(_close(a, b, 1e-4) for a, b in zip(acc, g[f"{n}_accumulated_loss"]))
     run = os.path.join(tmp, "run")
     final = np.fromfile(os.path.join(run, "optimized_image_iter_final.bin"), dtype=np.float32)
     # x_0 + x of the last forward; p has taken iters - 1 AdamW steps whose first ones are sign-like: compare where the
@@ -134,6 +143,12 @@ def test_cross_train_equals_the_reference_cross_trainers_run(tmp_path, n):
         assert abs(h["resave_error_std"] - g[f"{n}_resave_error_std"][t]) <= 1e-4 * g[f"{n}_resave_error_std"][t] + 2 / (255 * (npx - 1) ** 0.5), where
         assert _close(h["adversarial_mean"], g[f"{n}_adversarial_mean"][t], 1e-3, 1e-6), where
         assert _close(h["adversarial_std"], g[f"{n}_adversarial_std"][t], 1e-3, 1e-6), where
+    media = {"generated_text", "optimized_image", "optimized_tensor"}
+    probe = {"test_refuse_count", "test_target_acc", "test_target_first_word_acc", "test_total_questions"}
+    ours_keys = {k for h in hist for k in h}
+    assert {str(k) for k in g[f"{n}_log_keys"]} - media - probe <= ours_keys, sorted({str(k) for k in g[f"{n}_log_keys"]} - media - probe - ours_keys)
+    acc = [h["accumulated_loss"] for h in hist if "accumulated_loss" in h]
+    assert len(acc) == len(g[f"{n}_accumulated_loss"]) and all(_close(a, b, 1e-4) for a, b in zip(acc, g[f"{n}_accumulated_loss"]))
     run = os.path.join(tmp, "run")
     final = np.fromfile(os.path.join(run, "optimized_image_iter_final.bin"), dtype=np.float32)
     want = g[f"{n}_final"]
