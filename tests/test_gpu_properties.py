@@ -166,3 +166,43 @@ def test_tensors_beyond_two_to_the_32_elements(dev):
     engines[0].backward_update([g])
     engines[1].backward_update([row[None]])
     assert torch.equal(engines[0].grad, engines[1].grad) and torch.equal(engines[0].p, engines[1].p)
+
+
+def test_two_engines_on_two_streams_do_not_see_each_other(dev):
+    """"No implicit synchronisation, re-entrant across streams, no global mutable state" (SURVEY 8b): two engines - LLaVA's fused
+    pair and Llama-3.2-Vision's prepared chain with a crop-less blur-less plan of their own - take their steps interleaved on two
+    HIP streams, nothing synchronising between the calls; each ends where it ends when it runs alone."""
+    from adversarialvlm_amd.pgd import PixelPGD
+    from adversarialvlm_amd.plan import Plan
+    gen = torch.Generator().manual_seed(21)
+    xa, xb = torch.rand(3, 336, 336, generator=gen).to(dev), torch.rand(3, 120, 200, generator=gen).to(dev)
+    Ba, Bb, steps = 16, 6, 6
+
+    def make():
+        return (PixelPGD(xa, [Plan.llava(336, 336)], lr=1e-2, fused_mode="pair", seed=1),
+                PixelPGD(xb, [Plan.mllama(120, 200, tile=56)], lr=1e-2, fused_mode="prepared", seed=2))
+    na, nb = make()[0].plans[0].out_numel, make()[1].plans[0].out_numel
+    ga = [(torch.randn(Ba, na, generator=gen) * 0.01).to(dev) for _ in range(steps)]
+    gb = [(torch.randn(Bb, nb, generator=gen) * 0.01).to(dev) for _ in range(steps)]
+
+    def step(eng, B, g):
+        pv = eng.forward(B)[0]
+        eng.backward_update([g.view_as(pv)])
+
+    alone_a, alone_b = make()
+    for t in range(steps):
+        step(alone_a, Ba, ga[t])
+    for t in range(steps):
+        step(alone_b, Bb, gb[t])
+    torch.cuda.synchronize()
+    ea, eb = make()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for t in range(steps):
+        with torch.cuda.stream(sa):
+            step(ea, Ba, ga[t])
+        with torch.cuda.stream(sb):
+            step(eb, Bb, gb[t])
+    torch.cuda.synchronize()
+    assert torch.equal(ea.p, alone_a.p) and torch.equal(eb.p, alone_b.p)
+    assert ea.stats_dict() == alone_a.stats_dict() and eb.stats_dict() == alone_b.stats_dict()
