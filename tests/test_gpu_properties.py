@@ -206,3 +206,60 @@ def test_two_engines_on_two_streams_do_not_see_each_other(dev):
     torch.cuda.synchronize()
     assert torch.equal(ea.p, alone_a.p) and torch.equal(eb.p, alone_b.p)
     assert ea.stats_dict() == alone_a.stats_dict() and eb.stats_dict() == alone_b.stats_dict()
+
+
+def test_two_host_threads_drive_two_engines(dev):
+    """The C ABI is called with the GIL released; its error string is thread-local and plans / scratch belong to their callers.
+    Two Python threads, each with an engine and a stream of its own, step at the same time - and a third keeps provoking (and
+    reading) argument errors meanwhile; every engine ends bit for bit where it ends alone and no error text crosses threads."""
+    import threading
+
+    from adversarialvlm_amd import _lib as L
+    from adversarialvlm_amd.pgd import PixelPGD
+    from adversarialvlm_amd.plan import Plan
+    gen = torch.Generator().manual_seed(22)
+    xs = [torch.rand(3, 96 + 8 * k, 120, generator=gen).to(dev) for k in range(2)]
+    steps, B = 25, 4
+
+    def make(k):
+        return PixelPGD(xs[k], [Plan.llava(96 + 8 * k, 120, 56, 56)], lr=1e-2, seed=5 + k, fused_mode="prepared")
+    n = make(0).plans[0].out_numel
+    gs = [[(torch.randn(B, n, generator=gen) * 0.01).to(dev) for _ in range(steps)] for _ in range(2)]
+    alone = [make(k) for k in range(2)]
+    for k in range(2):
+        for t in range(steps):
+            pv = alone[k].forward(B)[0]
+            alone[k].backward_update([gs[k][t].view_as(pv)])
+    torch.cuda.synchronize()
+    engines, errors, stop = [make(k) for k in range(2)], [], threading.Event()
+
+    def work(k):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for t in range(steps):
+                    pv = engines[k].forward(B)[0]
+                    engines[k].backward_update([gs[k][t].view_as(pv)])
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:                       # noqa: BLE001 - reported below
+            errors.append((k, repr(e)))
+
+    def provoke():
+        lib = L.load()
+        while not stop.is_set():
+            rc = lib.advx_plan_create(None, None)
+            msg = lib.advx_last_error()
+            if rc == 0 or not msg or b"plan" not in msg:
+                errors.append(("provoke", rc, msg))
+                return
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)] + [threading.Thread(target=provoke)]
+    for th in threads:
+        th.start()
+    for th in threads[:2]:
+        th.join()
+    stop.set()
+    threads[2].join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for k in range(2):
+        assert torch.equal(engines[k].p, alone[k].p), k
