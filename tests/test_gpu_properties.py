@@ -263,3 +263,40 @@ def test_two_host_threads_drive_two_engines(dev):
     assert not errors, errors
     for k in range(2):
         assert torch.equal(engines[k].p, alone[k].p), k
+
+
+def test_plans_and_engines_give_their_device_memory_back(dev):
+    """Plans own device copies of their tap tables, engines own scratch and (data parallel) exchange segments: creating and
+    dropping a few hundred of them, of every kind, must not move the device's free memory (hipMemGetInfo) - the library
+    allocates nothing that outlives its handles."""
+    import gc
+
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.pgd import PixelPGD
+    from adversarialvlm_amd.plan import Plan
+    img = torch.rand(3, 120, 200, device=dev)
+
+    def churn(rounds):
+        for r in range(rounds):
+            for mk in (lambda: Plan.llava(120, 200, 56, 56), lambda: Plan.mllama(120, 200, tile=56), lambda: Plan.qwen2vl(120, 200),
+                       lambda: Plan.phi3(120, 200, num_crops=4)):
+                plan = mk()
+                out = ops.emit(plan, img, 2)
+                ops.collect(plan, torch.ones_like(out), 2)
+                eng = PixelPGD(img, [mk()], blur_kernel=5 if r % 2 else None, use_crop=bool(r % 3 == 0), allow_fused=bool(r % 2))
+                pv = eng.forward(2, blur_sigma=1.0 if r % 2 else None)[0]
+                eng.backward_update([torch.ones_like(pv) * 0.01])
+                del plan, out, eng, pv
+            from adversarialvlm_amd import dp
+            ex = dp.PeerExchange(3 * 120 * 200, dev)          # one rank: the segment alone (uncached device memory)
+            ex.send.fill_(1.0)
+            assert float(ex.all_reduce().sum()) == 3 * 120 * 200
+            ex.close()
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        return torch.cuda.mem_get_info()[0]
+    churn(3)                       # first uses: code objects, allocator pools
+    before = churn(5)
+    after = churn(60)
+    assert before - after < 8 * 1024 * 1024, (before, after)
