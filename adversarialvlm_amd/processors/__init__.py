@@ -61,6 +61,16 @@ MODEL_MAP = {
         "input_class": "AdvQwen2VLInputs",
         "processor_class": "DifferentiableQwen2VLImageProcessor",
     },
+    "synthetic/mllama-11b": {
+        "module": "adversarialvlm_amd.processors.synthetic_vlms",
+        "input_class": "AdvMllamaInputs",
+        "processor_class": "DifferentiableMllamaImageProcessor",
+    },
+    "synthetic/qwen2-vl-7b": {
+        "module": "adversarialvlm_amd.processors.synthetic_vlms",
+        "input_class": "AdvQwen2VLInputs",
+        "processor_class": "DifferentiableQwen2VLImageProcessor",
+    },
     "synthetic/tiny-phi3v": {
         "module": "adversarialvlm_amd.processors.synthetic_phi3v",
         "input_class": "AdvPhiInputs",

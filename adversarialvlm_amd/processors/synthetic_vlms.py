@@ -11,6 +11,12 @@ random-init Llama-3.2-Vision (mllama) and Qwen2-VL models small enough for a CPU
                               `Qwen2VLImageProcessorPil` and a real `PreTrainedTokenizerFast`, joined by the one step
                               the HF class adds - each `<|image_pad|>` becomes grid_t*grid_h*grid_w / merge^2 copies
 
+    synthetic/mllama-11b      the released Llama-3.2-11B-Vision ARCHITECTURE (MllamaConfig defaults with 560-pixel tiles: 32 + 8
+                              vision layers of width 1280, 40 text layers of width 4096, eight cross-attention layers), random
+                              init, fp16 - for end-to-end timing (tools/e2e_bench.py); the real processor geometry (tile 560, 4 tiles)
+    synthetic/qwen2-vl-7b     the Qwen2-VL-7B ARCHITECTURE (28 layers of width 3584, 28 / 4 heads, 32-layer vision tower), random
+                              init, bf16; pixel bounds 56^2 .. 28^2 * 1280
+
 These are what puts the wiring of `attack_model.py:314-328` with `llama32processor.py:119-147,360-405`
 (`pixel_values [B,1,4,3,T,T]`, `aspect_ratio_ids/mask`, `cross_attention_mask`) and
 `qwen2VLprocessor.py:68-96,211-272` (`[B*n_patches, 1176]` + `image_grid_thw`) in front of a model's `forward`
@@ -63,6 +69,42 @@ def mllama_processor(tile=MLLAMA_TILE, max_tiles=MLLAMA_MAX_TILES, padding_side=
     ip = MllamaImageProcessorPil(size={"height": tile, "width": tile}, max_image_tiles=max_tiles, image_mean=list(CLIP_MEAN),
                                  image_std=list(CLIP_STD))
     return MllamaProcessor(image_processor=ip, tokenizer=fast, chat_template=MLLAMA_TEMPLATE), len(words)
+
+
+def mllama_11b(device, seed=0):
+    """Random-init model of the released 11B architecture, built on the device in fp16 (22 GB)."""
+    from transformers import MllamaConfig, MllamaForConditionalGeneration
+    from transformers.models.mllama.configuration_mllama import MllamaTextConfig, MllamaVisionConfig
+    torch.manual_seed(seed)
+    cfg = MllamaConfig(vision_config=MllamaVisionConfig(image_size=560), text_config=MllamaTextConfig(pad_token_id=0),
+                       image_token_index=MLLAMA_SPECIAL.index("<|image|>"))
+    with torch.device(device):
+        model = MllamaForConditionalGeneration(cfg).to(torch.float16)
+    model.eval().requires_grad_(False)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.numel() <= 16 and p.abs().max() == 0:      # the zero-initialised gates would hide the vision path
+                p.fill_(0.5)
+    return model
+
+
+def qwen2vl_7b(device, seed=0):
+    from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
+    torch.manual_seed(seed)
+    ids = {w: i for i, w in enumerate(QWEN_SPECIAL)}
+    cfg = Qwen2VLConfig(
+        vision_config=dict(depth=32, embed_dim=1280, hidden_size=3584, mlp_ratio=4, num_heads=16, in_channels=3, patch_size=14,
+                           spatial_merge_size=2, temporal_patch_size=2),
+        text_config=dict(vocab_size=152064, hidden_size=3584, intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28,
+                         num_key_value_heads=4, max_position_embeddings=32768, pad_token_id=ids["<pad>"], bos_token_id=None,
+                         eos_token_id=ids["<|im_end|>"],
+                         rope_parameters={"rope_type": "default", "mrope_section": [16, 24, 24], "rope_theta": 1000000.0}),
+        image_token_id=ids["<|image_pad|>"], video_token_id=ids["<|video_pad|>"], vision_start_token_id=ids["<|vision_start|>"],
+        vision_end_token_id=ids["<|vision_end|>"])
+    with torch.device(device):
+        model = Qwen2VLForConditionalGeneration(cfg).to(torch.bfloat16)
+    model.eval().requires_grad_(False)
+    return model
 
 
 def mllama_model(vocab_words, tile=MLLAMA_TILE, max_tiles=MLLAMA_MAX_TILES, seed=0):
@@ -130,13 +172,13 @@ class ToyQwen2VLProcessor:
         return BatchFeature({**enc, **img})
 
 
-def qwen2vl_processor():
+def qwen2vl_processor(min_pixels=None, max_pixels=None):
     from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
     words = _vocabulary(QWEN_SPECIAL)
     fast = _word_level_tokenizer(words, pad_token="<pad>", eos_token="<|im_end|>",
                                  additional_special_tokens=["<|image_pad|>", "<|video_pad|>", "<|vision_start|>", "<|vision_end|>"])
-    ip = Qwen2VLImageProcessorPil(patch_size=14, merge_size=2, temporal_patch_size=2, min_pixels=QWEN_MIN_PIXELS,
-                                  max_pixels=QWEN_MAX_PIXELS, image_mean=list(CLIP_MEAN), image_std=list(CLIP_STD))
+    ip = Qwen2VLImageProcessorPil(patch_size=14, merge_size=2, temporal_patch_size=2, min_pixels=min_pixels or QWEN_MIN_PIXELS,
+                                  max_pixels=max_pixels or QWEN_MAX_PIXELS, image_mean=list(CLIP_MEAN), image_std=list(CLIP_STD))
     return ToyQwen2VLProcessor(ip, fast, QWEN_TEMPLATE), len(words)
 
 
@@ -166,6 +208,12 @@ def load_model_and_processor(model_name: str, device, seed: int = 0, dtype=torch
     elif model_name == "synthetic/tiny-qwen2vl":
         proc, n = qwen2vl_processor()
         model = qwen2vl_model(n, seed=seed)
+    elif model_name == "synthetic/mllama-11b":
+        proc, _ = mllama_processor(tile=560, max_tiles=4)
+        return mllama_11b(device, seed=seed), proc
+    elif model_name == "synthetic/qwen2-vl-7b":
+        proc, _ = qwen2vl_processor(min_pixels=56 * 56, max_pixels=28 * 28 * 1280)
+        return qwen2vl_7b(device, seed=seed), proc
     else:
         raise ValueError(model_name)
     return model.to(dtype).to(device), proc
