@@ -402,6 +402,10 @@ def main():
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         replicas_identical = bool(torch.equal(lo, hi))
     exchange_timed_out = bool(eng.peer.timed_out()) if eng.peer is not None else None
+    # ... and the state the steps left must be numbers: a kernel that went wrong over a long region shows here, not in the timing
+    state_finite = bool(torch.isfinite(eng.p).all() and torch.isfinite(eng.m).all() and torch.isfinite(eng.v).all())
+    if not state_finite:
+        raise SystemExit("bench: the optimised tensor or the optimiser state holds non-finite values after the timed region")
 
     n_in = 3 * H * W
     bytes_fwd = io_bytes * B * n_in + 4 * 2 * n_in     # write B*P_out, read p,x0
@@ -479,7 +483,7 @@ def main():
                        "backend": args.backend if eng.exchange else None,
                        "launcher": os.environ.get("ADVX_BENCH_LAUNCHER", "external (torchrun environment)" if world > 1 else "none"),
                        "cache_state": main_key, "ring": ring,
-                       "replicas_identical": replicas_identical, "exchange_timed_out": exchange_timed_out},
+                       "replicas_identical": replicas_identical, "exchange_timed_out": exchange_timed_out, "state_finite": state_finite},
             "steps_per_s": round(steps_per_s, 1),
             "roofline": roofline,
         }
