@@ -33,7 +33,7 @@ def gaussian_blur(x, kernel_size, sigma):
     g = gaussian_kernel1d(kernel_size, sigma)
     k2d = torch.mm(g[:, None], g[None, :])
     C = x.shape[0]
-    w = k2d.expand(C, 1, kernel_size, kernel_size)
+    w = k2d.to(x.device).expand(C, 1, kernel_size, kernel_size)      # the CPU kernel, wherever x lives
     r = kernel_size // 2
     xp = F.pad(x.unsqueeze(0), [r, r, r, r], mode="reflect")
     return F.conv2d(xp, w, groups=C).squeeze(0)

@@ -225,3 +225,78 @@ def test_same_device_reference_path_four_steps(name, size, batch):
         assert rel_err(eng.p[conditioned], ora.p.detach()[conditioned], elementwise=None) < 1e-4, step
         worst = (eng.p[conditioned] - ora.p.detach()[conditioned]).abs().max()
         assert float(worst) <= 1e-3 * float(ora.p.detach().abs().max()), (step, float(worst))
+
+
+def test_blur_and_crop_branches_of_both_trainers_against_the_oracle_loop(tmp_path):
+    """The two branches of the loops that the reference's own `train()` cannot show here (its `GaussianBlur` / `RandomResizedCrop`
+    are torchvision's): `--use_gaussian_blur --use_local_crop` through THIS PACKAGE'S trainers against the oracle loop, same
+    device, same model objects.  Single trainer: blur 5 with the flag's sigma, a window drawn per iteration from torch's global
+    generator (attack_model.py:303-312).  Cross trainer: sigma redrawn per iteration, then the window (crossattack_models.py:
+    186-189, 336-343) - the oracle loop below draws them in that order from the same seed.  Loss per iteration 1e-5, final image
+    at the trajectory bar."""
+    from adversarialvlm_amd import attack_model, crossattack_models
+    from adversarialvlm_amd.processors import synthetic
+    from oracle import pixel_ops as P
+    from oracle.processors import LlavaOracle
+    dev = torch.device("cuda:0")
+    tmp = str(tmp_path)
+    H, W, B = 64, 48, 2
+    img = (np.random.default_rng(3).random((H, W, 3)) * 255).astype(np.uint8)
+    Image.fromarray(img).save(os.path.join(tmp, "in.png"))
+    x0 = torch.tensor(img.astype(np.float32) / 255).permute(2, 0, 1).contiguous().to(dev)
+    models = [synthetic.load_model_and_processor("synthetic/tiny-llava", dev, seed=s) for s in (0, 1)]
+    gen = torch.Generator().manual_seed(31)
+    zs = [[torch.randn(B, 3, 56, 56, generator=gen) for _ in range(2)] for _ in range(4)]
+    mask = P.create_mask("corner", 40, (3, H, W)).to(dev)
+    flags = dict(img_orig=os.path.join(tmp, "in.png"), prompt="describe this image", target_text="sure here it is", lr=1e-2, save_steps=10,
+                 batch_size=B, grad_accum_steps=1, scheduler_step_size=2, scheduler_gamma=0.5, restart_num=0, mask_type="corner", mask_size=40,
+                 clamp_method="tanh", sigma=1e-3, start_from_white=False, target_text_random=False, base_path=tmp, return_engine=True,
+                 log_every=1, seed=9, use_gaussian_blur=True, gblur_kernel_size=5, use_local_crop=True)
+
+    def inputs_for(proc):
+        return synthetic.AdvLlavaInputs(questions=["describe this image"], test_questions=["hi"], batch_size=B, original_image=None,
+                                        processor=proc, device=dev, target_text="sure here it is")
+
+    def ce(model, ip, inputs):
+        def f(pv):
+            return ip.get_loss(model(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"], pixel_values=pv).logits[:, :-1, :])
+        return f
+    # ---------------------------------------------------------------- single trainer
+    comp = ((lambda name, device: models[0]), synthetic.AdvLlavaInputs, synthetic.DifferentiableLlavaImageProcessor)
+    eng, hist = attack_model.train(exp_name="single", model_name="m0", num_iterations=4, epsilon=0.5, gblur_sigma=1.3, components=comp,
+                                   unit_noise_fn=lambda it, shape: zs[it][0].view(shape), **flags)
+    random.seed(9)
+    torch.manual_seed(9)                                   # where train() seeds the shared draws
+    ora = PGDOracle(x0, [LlavaOracle(56, 56)], epsilon=0.5, lr=1e-2, mask=mask, scheduler_step_size=2, scheduler_gamma=0.5, blur_kernel=5)
+    ip = inputs_for(models[0][1])
+    for t in range(4):
+        inputs = ip.get_inputs_train()
+        crop = P.random_resized_crop_params(H, W, (0.6, 1.0), (0.75, 1.33))
+        ora.forward(B, [zs[t][0].to(dev)], blur_sigma=1.3, crop=crop)
+        ref = ora.backward_update(loss_fns=[ce(models[0][0], ip, inputs)])
+        want = ref["model_losses"][0] + ref["img_loss"]
+        assert abs(hist[t]["loss"] - want) <= 1e-5 * abs(want), (t, hist[t]["loss"], want)
+        assert abs(hist[t]["resave_error_std"] - ref["sigma_next"]) <= 1e-4 * ref["sigma_next"] + 2 / (255 * (x0.numel() - 1) ** 0.5)
+    assert rel_err(eng.image(), ref["s"]) < 1e-5
+    # ---------------------------------------------------------------- cross trainer
+    names = ["m0", "m1"]
+    comps = {n: ((lambda name, device, k=k: models[k]), synthetic.AdvLlavaInputs, synthetic.DifferentiableLlavaImageProcessor)
+             for k, n in enumerate(names)}
+    eng, hist = crossattack_models.train(exp_name="cross", model_names=names, num_iterations=3, epsilon=0.4, attack_norm=0.4, DPO_flag=False,
+                                         model_weights=[0.6, 1.4], components=comps,
+                                         unit_noise_fn=lambda it, i, shape: zs[it][i].view(shape), **flags)
+    random.seed(9)
+    torch.manual_seed(9)
+    ora = PGDOracle(x0, [LlavaOracle(56, 56), LlavaOracle(56, 56)], epsilon=0.4, lr=1e-2, mask=mask, scheduler_step_size=2, scheduler_gamma=0.5,
+                    blur_kernel=5, model_weights=[0.6, 1.4], cross_mode=True)
+    ips = [inputs_for(models[k][1]) for k in range(2)]
+    for t in range(3):
+        sig = torch.empty(1).uniform_(0.1, 2.0).item()                                   # torchvision's GaussianBlur(kernel_size) draw (Q4)
+        crop = P.random_resized_crop_params(H, W, (0.6, 1.0), (0.75, 1.33))
+        inputs = [ip.get_inputs_train() for ip in ips]
+        ora.forward(B, [zs[t][k].to(dev) for k in range(2)], blur_sigma=sig, crop=crop)
+        ref = ora.backward_update(loss_fns=[ce(models[k][0], ips[k], inputs[k]) for k in range(2)])
+        for k, w in enumerate((0.6, 1.4)):
+            want = w * ref["model_losses"][k] + ref["img_loss"]
+            assert abs(hist[t][f"loss_{k}_{names[k]}"] - want) <= 1e-5 * abs(want), (t, k)
+    assert rel_err(eng.image(), ref["s"]) < 1e-5
