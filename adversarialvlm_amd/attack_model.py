@@ -328,6 +328,8 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
                    # inside the kernel, so these are the generator's parameters - what those statistics estimate
                    "noise_mean": 0.0, "noise_std": st["sigma"]}
             if stepped:
+                # summed over the iterations that were LOGGED since the last optimiser step: with the default --log_every 1 that
+                # is the reference's number; a sparser log cadence skips the device synchronisation the others would need
                 rec["accumulated_loss"] = accumulated_loss                                  # :349-352, once per optimiser step
                 accumulated_loss = 0.0
             if resaved_loss_every > 0 and iteration % resaved_loss_every == 0:
