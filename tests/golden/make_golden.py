@@ -7,7 +7,8 @@ from /root/reference/src, and against the stock torch calls the reference traine
 makes.  Only DATA (inputs + expected outputs) is written; no reference source text is
 stored.  The reference tree does not exist on the GPU box - nothing at test time reads it.
 
-    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz (+ cli_flags_reference.json)
+    GOLDEN_OUT=/tmp/g python tests/golden/make_golden.py     # ... into another directory, to compare with the committed ones
 
 Importability notes: llavaprocessor imports directly; qwen2VLprocessor /
 phi3processor have unused torchvision imports, so a bare stub module is registered after
@@ -25,6 +26,16 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("GOLDEN_OUT", HERE)        # GOLDEN_OUT=/tmp/x regenerates the fixtures somewhere else (to compare with the tree's)
+
+
+def repo_root():
+    """Where `adversarialvlm_amd/` lives (the trainer-run fixtures borrow its tiny random models): beside this file's tests/
+    directory, else the working directory, else /root/repo - so a copy of this script run from elsewhere still finds it."""
+    for cand in (os.path.dirname(os.path.dirname(HERE)), os.getcwd(), "/root/repo"):
+        if os.path.isdir(os.path.join(cand, "adversarialvlm_amd")):
+            return cand
+    raise SystemExit("adversarialvlm_amd/ not found: run from the repository root")
 REF = "/root/reference/src"
 
 CLIP_MEAN = [0.48145466, 0.4578275, 0.40821073]
@@ -55,7 +66,7 @@ def save(name, **arrays):
         out[k] = np.asarray(v)
     for k, v in meta().items():
         out["meta_" + k] = np.asarray(v)
-    np.savez_compressed(os.path.join(HERE, name), **out)
+    np.savez_compressed(os.path.join(OUT, name), **out)
     print("wrote", name, {k: out[k].shape for k in out if not k.startswith("meta_")})
 
 
@@ -354,7 +365,7 @@ def golden_mllama_reference(mllama):
 def golden_mllama_restated():
     """NOT a reference capture: produced by the oracle's restatement of
     llama32processor.py:360-405 (module not importable here)."""
-    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    sys.path.insert(0, repo_root())
     from oracle.processors import MllamaOracle
     arrays = {}
     for k, (name, ishape, tile) in enumerate([("a", (3, 40, 70), 32), ("b", (3, 90, 50), 32), ("c", (3, 30, 30), 32)]):
@@ -468,7 +479,7 @@ def golden_trainer_run(am, llava, qwen=None, mllama=None, phi3=None):
 
     from PIL import Image
 
-    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    sys.path.insert(0, repo_root())
     from adversarialvlm_amd.processors import synthetic
 
     class Recorder(types.ModuleType):
@@ -658,7 +669,7 @@ def golden_cross_trainer_run(llava, qwen, mllama, phi3=None):
 
     from PIL import Image
 
-    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    sys.path.insert(0, repo_root())
     from adversarialvlm_amd.processors import synthetic, synthetic_vlms
 
     import_reference_trainer()                      # placeholders for wandb / torchvision names
@@ -850,7 +861,7 @@ def golden_cli_flags(am):
     data = {"attack_model": grab(am), "crossattack_models": grab(cm), "meta": meta(), "launch_scripts": scripts,
             "train_signatures": {"attack_model": signature(am.train), "crossattack_models": signature(cm.train)},
             "plugin_classes": classes, "model_map": model_map}
-    with open(os.path.join(HERE, "cli_flags_reference.json"), "w") as f:
+    with open(os.path.join(OUT, "cli_flags_reference.json"), "w") as f:
         json.dump(data, f, indent=1, sort_keys=True)
     print("wrote cli_flags_reference.json", {k: len(v) for k, v in data.items() if k != "meta"})
 
