@@ -1,4 +1,5 @@
 """Build libadvx_hip.so in-tree with hipcc for gfx950 (no JIT cache, no CPU variant)."""
+import glob
 import os
 import shutil
 import subprocess
@@ -6,8 +7,15 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = [os.path.join(CSRC, "advx.hip")]
-HEADERS = [os.path.join(CSRC, f) for f in ("advx_taps.h", "advx_device.h", "advx_kernels.h", "advx_comm.h", "advx_ce.h")] + [
-    os.path.join(os.path.dirname(_HERE), "include", "advx.h")]
+PUBLIC_HEADER = os.path.join(os.path.dirname(_HERE), "include", "advx.h")
+
+
+def headers():
+    """Every header the library is compiled from: all of csrc/*.h (found, not listed - a new header cannot be
+    forgotten) and the public include/advx.h."""
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [PUBLIC_HEADER]
+
+
 OUT = os.path.join(_HERE, "libadvx_hip.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 
@@ -16,7 +24,7 @@ def _stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(f) > t for f in SOURCES + headers())
 
 
 def build_library(force=False, verbose=False):

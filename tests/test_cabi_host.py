@@ -307,3 +307,37 @@ def test_plain_c_host_compiles_and_links_against_the_header(tmp_path):
                          capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     assert os.path.exists(exe)
+
+
+def test_build_sees_an_edit_to_every_header(tmp_path, monkeypatch):
+    """CPU tier: `_stale()` follows every header advx.hip is compiled from - the list is found (glob), not written
+    down, and each `#include "…"` of the sources is in it.  Checked on copies: the tree's own files are not touched."""
+    import re
+    import shutil
+    from adversarialvlm_amd import build
+    names = {os.path.basename(h) for h in build.headers()}
+    for src in build.SOURCES + build.headers():
+        with open(src) as f:
+            for inc in re.findall(r'#include\s+"([^"]+)"', f.read()):
+                assert os.path.basename(inc) in names, (src, inc)
+    csrc, inc_dir = tmp_path / "pkg" / "csrc", tmp_path / "include"
+    shutil.copytree(build.CSRC, csrc)
+    inc_dir.mkdir()
+    shutil.copy(build.PUBLIC_HEADER, inc_dir / "advx.h")
+    out = tmp_path / "pkg" / "libadvx_hip.so"
+    out.write_bytes(b"")
+    monkeypatch.setattr(build, "CSRC", str(csrc))
+    monkeypatch.setattr(build, "SOURCES", [str(csrc / "advx.hip")])
+    monkeypatch.setattr(build, "PUBLIC_HEADER", str(inc_dir / "advx.h"))
+    monkeypatch.setattr(build, "OUT", str(out))
+    files = build.SOURCES + build.headers()
+    assert len(files) >= 9 and all(str(tmp_path) in f for f in files)
+    t_lib = os.path.getmtime(out)
+    for f in files:
+        os.utime(f, (t_lib - 100, t_lib - 100))
+    assert not build._stale()
+    for f in files:
+        os.utime(f, (t_lib + 100, t_lib + 100))
+        assert build._stale(), f
+        os.utime(f, (t_lib - 100, t_lib - 100))
+    assert not build._stale()
