@@ -18,9 +18,11 @@ PHILOX_STEP_CHAIN = 2     # use_philox of advx_fused_fwd: the one-launch chain's
 STAT_SIGMA, STAT_QERR_STD, STAT_QERR_MEAN, STAT_QERR_L1, STAT_IMGFIT, STAT_X_MEAN, STAT_X_STD, STAT_GRAD_NORM = range(8)
 STATS_N = 16
 MAX_STAGES = 2
+TUNE_RESET_ALL = 0
 TUNE_GENERIC_KERNELS = 1
 TUNE_FULL_TAP_ROWS = 3
 TUNE_SEPARATE_CROP = 4
+TUNE_PAIR_LEAN = 5
 
 
 class AdvxError(RuntimeError):

@@ -110,6 +110,13 @@ def save_state(engine, exp_path, global_iteration, iteration, name=None):
     return path
 
 
+def saved_chain(path):
+    """The kernel chain of the run that wrote `path` (None: a file from before round 4, or nothing to resume)."""
+    if not path:
+        return None
+    return torch.load(path, map_location="cpu")["engine"].get("chain")
+
+
 def load_state(engine, path):
     """-> (global_iteration, next iteration) of the run that wrote `path`."""
     sd = torch.load(path, map_location="cpu")
@@ -243,7 +250,11 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
         Image.fromarray((mask.permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8)).save(os.path.join(exp_path, "mask.png"))
 
     plan = adv_processor.plan_for(H, W)
+    # a resumed run stays on the chain it was started on (the one-launch chain draws its noise differently): `auto` would
+    # pick by the batch size of THIS call
+    chain = saved_chain(resume_from)
     engine = PixelPGD(x_0, [plan], epsilon=epsilon, lr=lr, sigma0=sigma, mask=mask,
+                      fused_mode=chain if chain in ("pair", "step", "prepared") else "auto",
                       scheduler_step_size=scheduler_step_size, scheduler_gamma=scheduler_gamma,
                       grad_accum_steps=grad_accum_steps, blur_kernel=gblur_kernel_size if use_gaussian_blur else None,
                       use_crop=use_local_crop, optimizer=optimizer, seed=seed + 7919 * rank,
@@ -273,6 +284,7 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
 
     global_iteration = 0
     accumulated_loss = 0.0
+    window_iterations = window_logged = 0       # of the current accumulation window: iterations seen / iterations logged
     refuse_flag = False
     history = []
     start_iteration = 0
@@ -310,6 +322,7 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
         loss_value = loss.detach()
         if stepped:
             global_iteration += 1
+        window_iterations += 1
         last = iteration == num_iterations - 1
         if world > 1 and (iteration % check_every == 0 or iteration % save_steps == 0 or last):
             # before anything of this step is written: a lost peer or diverged replicas end the run on EVERY rank
@@ -319,6 +332,7 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
             ce = float(loss_value)
             total = (ce + st["img_loss"]) / grad_accum_steps
             accumulated_loss += total
+            window_logged += 1
             rec = {"iteration": iteration, "global_iteration": global_iteration, "loss": total, "ce_loss": ce,
                    "image_loss": st["img_loss"], "grad norm": st["grad_norm"], "lr": engine.current_lr(),
                    "resave_error_std": st["sigma_next"], "resave_error_mean": st["qerr_mean"],
@@ -327,11 +341,11 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
                    # the reference logs the sample mean / std of the noise tensor it drew (:398-399); the noise here is drawn
                    # inside the kernel, so these are the generator's parameters - what those statistics estimate
                    "noise_mean": 0.0, "noise_std": st["sigma"]}
-            if stepped:
-                # summed over the iterations that were LOGGED since the last optimiser step: with the default --log_every 1 that
-                # is the reference's number; a sparser log cadence skips the device synchronisation the others would need
-                rec["accumulated_loss"] = accumulated_loss                                  # :349-352, once per optimiser step
-                accumulated_loss = 0.0
+            if stepped and window_logged == window_iterations:
+                # the reference's number (:349-352): the sum over the iterations since the last optimiser step.  Every one of them
+                # was logged (always so with the default --log_every 1); a window the log cadence only saw in part has no such
+                # key - never a sum mixed from several windows
+                rec["accumulated_loss"] = accumulated_loss
             if resaved_loss_every > 0 and iteration % resaved_loss_every == 0:
                 # :375-379 - the loss of the image as a PNG of it would be seen (no noise); a whole
                 # extra VLM forward, so periodic here instead of every step
@@ -342,6 +356,9 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
                 rec["loss_resaved"] = float(rl)
             history.append(rec)
             logger.log(rec)
+        if stepped:
+            # the reference resets at every optimiser step, logged or not
+            accumulated_loss, window_iterations, window_logged = 0.0, 0, 0
         if rank == 0 and (iteration % save_steps == 0 or iteration == num_iterations - 1):  # :410-416 (Q10 naming)
             img = engine.image()
             pil = adv_processor.tensor2pil(img)

@@ -157,6 +157,7 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
     if world > 1:
         torch.distributed.barrier()          # model loading skews the ranks by far more than a step
     accumulated_loss = 0.0
+    window_iterations = window_logged = 0       # of the current accumulation window: iterations seen / iterations logged
     for iteration in range(start_iteration, num_iterations):
         if world > 1:
             reseed_prompt_stream(inputs_processors, seed, rank, iteration)
@@ -198,6 +199,7 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
         stepped = engine.backward_update(grads)                                             # :391-406 (HIP)
         if stepped:
             global_iteration += 1
+        window_iterations += 1
         last = iteration == num_iterations - 1
         if world > 1 and (iteration % check_every == 0 or iteration % save_steps == 0 or last):
             # the sum this exchange replaces (crossattack_models.py:383-406) cannot silently drop a term
@@ -215,9 +217,12 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
                 rec[f"loss_{i}_{model_names[i].replace('/', '_')}"] = float(losses[k]) * model_weights[i] + st["img_loss"]
             rec["loss_per_iteration"] = float(np.mean([v for kk, v in rec.items() if kk.startswith("loss_")]))
             accumulated_loss += float(sum(v for kk, v in rec.items() if kk.startswith("loss_") and kk != "loss_per_iteration"))
-            if stepped:
-                rec["accumulated_loss"] = accumulated_loss                                  # :400-404, once per optimiser step
-                accumulated_loss = 0.0
+            window_logged += 1
+            if stepped and window_logged == window_iterations:
+                # the reference's number (:400-404): the sum over the iterations since the last optimiser step.  Every one of them
+                # was logged (always so with the default --log_every 1); a window the log cadence only saw in part has no such
+                # key - never a sum mixed from several windows
+                rec["accumulated_loss"] = accumulated_loss
             if resaved_loss_every > 0 and iteration % resaved_loss_every == 0:
                 # :434-445 - every model's loss on the image as its PNG would be read back (no noise),
                 # averaged; one extra forward per model, so periodic here
@@ -231,6 +236,9 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
                 rec["loss_resaved"] = float(np.mean(resaved))
             history.append(rec)
             logger.log(rec)
+        if stepped:
+            # the reference resets at every optimiser step, logged or not
+            accumulated_loss, window_iterations, window_logged = 0.0, 0, 0
         if rank == 0 and (iteration % save_steps == 0 or iteration == num_iterations - 1):
             img = engine.image()
             pil = adv_processors[0].tensor2pil(img)

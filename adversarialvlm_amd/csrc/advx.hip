@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/advx.h"
@@ -45,16 +47,25 @@ static int32_t fail(int32_t code, const std::string& msg) {
 // compare the specialised kernels with them bit for bit)
 static int g_generic_kernels = 0;
 static int g_pair_nt_loads = 0;
+static int g_pair_lean = 0;      // ADVX_TUNE_PAIR_LEAN (experiment; the float32 Philox pair only)
 static int g_full_tap_rows = 0;
 static int g_separate_crop = 0;   // ADVX_TUNE_SEPARATE_CROP: 1 = never compose a crop window with stage 0; 2 = compose wherever the tables fit (tests)
 static long long kRows3MinPositions = 250000;   // three channels per thread (k_stage_bwd3, k_crop_bwd_rows3) from here up (measured)
 extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
+  if (what == ADVX_TUNE_RESET_ALL) {       // every switch back to its default (test fixtures' finaliser)
+    g_generic_kernels = g_pair_nt_loads = g_pair_lean = g_full_tap_rows = g_separate_crop = 0;
+    return ADVX_OK;
+  }
   if (what == ADVX_TUNE_GENERIC_KERNELS) {
     g_generic_kernels = value ? 1 : 0;
     return ADVX_OK;
   }
   if (what == ADVX_TUNE_PAIR_NT_LOADS) {
     g_pair_nt_loads = value ? 1 : 0;
+    return ADVX_OK;
+  }
+  if (what == ADVX_TUNE_PAIR_LEAN) {
+    g_pair_lean = value ? 1 : 0;
     return ADVX_OK;
   }
   if (what == ADVX_TUNE_FULL_TAP_ROWS) {
@@ -770,6 +781,11 @@ static void emit_slices(long long n4, int batch, bool patch_layout, bool half_io
   *slices = sl;
   *b_per_slice = bps;
 }
+// Workgroups are dealt round-robin over the 8 XCDs by their LINEAR id (x + gx*y): with gx a multiple of 8 every batch slice
+// (blockIdx.y) of one column block runs on the XCD x % 8, so the one shared read of these launches - the canvas / v, once
+// per column block - is fetched into ONE XCD's L2 instead of up to eight (round 4, PMC: k_fused_fwd fetched 13.7 MB where
+// 2.7 MB are algorithmic at gx = 331 = 3 mod 8).  The padding blocks have no columns and return at once.
+static inline int pad_xcd(int gx) { return (gx + 7) & ~7; }
 static bool plan_has_patch_layout(const advx_plan* p);
 
 static bool plan_has_patch_layout(const advx_plan* p) {
@@ -838,7 +854,7 @@ extern "C" int32_t advx_emit_ex(advx_plan* p, const float* argument, int32_t bat
   }
   int gx, slices, bps;
   emit_slices(q_hi - q_lo, batch, plan_has_patch_layout(p), p->io != 0, &gx, &slices, &bps);
-  dim3 grid(gx, slices);
+  dim3 grid(pad_xcd(gx), slices);
 #define ADVX_EMIT_T(N, T)                                                                                           \
   hipLaunchKernelGGL((k_emit<N, T>), grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, \
                      offset, (void*)out, q_lo, q_hi, live_lo, live_hi, no_rider())
@@ -977,6 +993,50 @@ static int32_t check_multi(int32_t n, advx_plan* const* plans, const int32_t* ba
   return ADVX_OK;
 }
 
+// ------------------------------------------------------------------ which tables an image scratch holds
+// The crop window's tap tables (its own, or the ones composed with a plan's stage 0) are built into the caller's image
+// scratch by the forward of a step and read again by its backward, which skips the rebuild when they are still there.
+// "Still there" is a property of the SCRATCH, so the record is keyed by the address of the table area - not by the calling
+// host thread (rounds 2-3 kept it thread_local: a forward on one thread, another window built into the same scratch from a
+// second thread, and the first thread's backward trusted its own stale "same" - VERDICT r03).  One process-wide map under
+// a mutex; an entry is written only AFTER the launch that builds the last of the rows has been issued, and removed by every
+// call that carves other buffers over the area or rebuilds it.  Ordering on the device is the stream's: the record
+// carries the stream, and a different stream never matches.
+namespace {
+struct TableRecord {
+  int kind = 0;                    // 0: nothing known; 1: the window's own tables; 2: window o stage 0 of `plan`
+  const advx_plan* plan = nullptr;
+  int H = 0, W = 0, crop[4] = {0, 0, 0, 0};
+  hipStream_t stream = nullptr;
+  bool operator==(const TableRecord& o) const {
+    return kind == o.kind && plan == o.plan && H == o.H && W == o.W && stream == o.stream && crop[0] == o.crop[0] &&
+           crop[1] == o.crop[1] && crop[2] == o.crop[2] && crop[3] == o.crop[3];
+  }
+};
+struct PendingTables {             // built by a deferred construction; committed by whoever issues its last launch
+  const float* where = nullptr;
+  TableRecord rec;
+};
+std::mutex g_tables_mu;
+std::unordered_map<const float*, TableRecord> g_tables;
+bool tables_hold(const float* where, const TableRecord& rec) {
+  std::lock_guard<std::mutex> lock(g_tables_mu);
+  auto it = g_tables.find(where);
+  return it != g_tables.end() && it->second.kind != 0 && it->second == rec;
+}
+void tables_forget(const float* where) {
+  std::lock_guard<std::mutex> lock(g_tables_mu);
+  g_tables.erase(where);
+}
+void tables_commit(const float* where, const TableRecord& rec) {
+  if (!where || rec.kind == 0) return;
+  std::lock_guard<std::mutex> lock(g_tables_mu);
+  if (g_tables.size() >= 1024) g_tables.clear();     // scratch buffers come and go unannounced: forgetting only costs a rebuild
+  g_tables[where] = rec;
+}
+void tables_commit(const PendingTables& t) { tables_commit(t.where, t.rec); }
+}  // namespace
+
 namespace {
 struct PendingImageStats {   // what an advx_image_fwd left for the launches after it
   const double* partials = nullptr;   // statistics partials for the next launch to reduce
@@ -984,6 +1044,7 @@ struct PendingImageStats {   // what an advx_image_fwd left for the launches aft
   long long n_img = 0;
   float* stats = nullptr;
   TapRider later;                     // the crop window's transposed tap tables, to ride in the emit (blocks > 0)
+  PendingTables tables;               // ... and the record to commit once that launch has been issued
   PendingImageStats() { std::memset(&later, 0, sizeof(later)); }
 };
 }  // namespace
@@ -1101,18 +1162,19 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
   if (n > 1 && same_noise && !g_generic_kernels) {
     // one launch for all plans: the plans fill each other's tails (same values: same counters, same offsets).
     // (Largest plan first in the grid: no change for the emits, 3 us WORSE for the merged reductions - kept in caller order.)
-    dim3 grid(max_gx, max_slices, n);
+    dim3 grid(pad_xcd(max_gx), max_slices, n);
     if (noise_all == 0) hipLaunchKernelGGL(k_emit_multi<0>, grid, dim3(kBlock), 0, st, me, sigma_dev, seed, rider);
     else if (noise_all == 1) hipLaunchKernelGGL(k_emit_multi<1>, grid, dim3(kBlock), 0, st, me, sigma_dev, seed, rider);
     else hipLaunchKernelGGL(k_emit_multi<2>, grid, dim3(kBlock), 0, st, me, sigma_dev, seed, rider);
     LAUNCH_CHECK();
+    tables_commit(pend.tables);      // the riders of this call's image kernels have all been launched
     return ADVX_OK;
   }
   for (int i = 0; i < n; ++i) {
     advx_plan* p = plans[i];
     const EmitArgs& a = me.a[i];
     const int noise = a.unit_noise ? 1 : (use_philox ? 2 : 0);
-    dim3 grid(a.gx, a.slices);
+    dim3 grid(pad_xcd(a.gx), a.slices);
     const TapRider ride_i = (i == 0) ? rider : no_rider();
 #define ADVX_EMIT_T(N, T)                                                                                                 \
   hipLaunchKernelGGL((k_emit<N, T>), grid, dim3(kBlock), 0, st, p->dplan, a.ws, a.batch, a.b_per_slice, sigma_dev, a.unit_noise, \
@@ -1124,6 +1186,7 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
 #undef ADVX_EMIT_T
     LAUNCH_CHECK();
   }
+  tables_commit(pend.tables);        // the riders of this call's image kernels have all been launched
   return ADVX_OK;
 }
 
@@ -1247,23 +1310,16 @@ struct CropTables {
   DStage st;
 };
 
-// The backward of a step needs the tables its forward built: same window, same scratch, same
-// stream.  The host remembers the last build and advx_image_bwd skips the launch when it matches
-// (the tables sit right behind the statistics partials in both calls, so nothing in between
-// overwrites them).
-struct CropCache {
-  const float* where = nullptr;
-  int H = 0, W = 0, crop[4] = {0, 0, 0, 0};
-  hipStream_t stream = nullptr;
-};
-thread_local CropCache g_crop_cache;
-void g_compose_cache_invalidate();
+// The backward of a step needs the tables its forward built: same window, same scratch, same stream - the registry above
+// (tables_hold / tables_commit) remembers what each scratch holds, and advx_image_bwd* skip the launch when it matches
+// (the tables sit right behind the statistics partials in both calls).
 
 // carve the crop's tap tables out of scratch and launch their device-side construction
 // `deferred`: do not launch k_build_taps; hand the two descriptors to the caller, who builds the
 // tables inside its own first launch (k_prep_taps)
+// and set *pending, which the caller commits after the launch that builds the LAST rows has been issued
 int32_t build_crop_stage(int H, int W, const int32_t* crop, Bump& b, hipStream_t stq, DStage* out, bool may_reuse = false,
-                         TapBuild* deferred = nullptr) {
+                         TapBuild* deferred = nullptr, PendingTables* pending = nullptr) {
   int ci = crop[0], cj = crop[1], ch = crop[2], cw = crop[3];
   const float* where = b.base + b.used;
   REQUIRE(ch > 0 && cw > 0 && ci >= 0 && cj >= 0 && ci + ch <= H && cj + cw <= W, ADVX_E_BADARG, "crop window outside the image");
@@ -1294,21 +1350,24 @@ int32_t build_crop_stage(int H, int W, const int32_t* crop, Bump& b, hipStream_t
     f[ax] = DevTaps{outs[ax], strides[ax], a[ax].start, a[ax].count, a[ax].w};
     t[ax] = DevTaps{ins[ax], tstrides[ax], a[ax].tstart, a[ax].tcount, a[ax].tw};
   }
-  CropCache& cc = g_crop_cache;
-  const bool same = may_reuse && cc.where == where && cc.H == H && cc.W == W && cc.stream == stq && cc.crop[0] == ci &&
-                    cc.crop[1] == cj && cc.crop[2] == ch && cc.crop[3] == cw;
+  TableRecord rec;
+  rec.kind = 1; rec.H = H; rec.W = W; rec.stream = stq;
+  rec.crop[0] = ci; rec.crop[1] = cj; rec.crop[2] = ch; rec.crop[3] = cw;
+  REQUIRE(!deferred || pending, ADVX_E_BADARG, "build_crop_stage: a deferred construction needs somebody to commit it");
+  const bool same = may_reuse && !deferred && tables_hold(where, rec);
   if (!same) {
+    tables_forget(where);                  // whatever the area held is about to be overwritten
     if (deferred) {
       deferred[0] = a[0];
       deferred[1] = a[1];
+      pending->where = where;
+      pending->rec = rec;
     } else {
       int rows = std::max(H + ch, W + cw);
       hipLaunchKernelGGL(k_build_taps, dim3((rows + kBlock - 1) / kBlock, 2), dim3(kBlock), 0, stq, a[0], a[1]);
       LAUNCH_CHECK();
+      tables_commit(where, rec);
     }
-    cc.where = where; cc.H = H; cc.W = W; cc.stream = stq;
-    cc.crop[0] = ci; cc.crop[1] = cj; cc.crop[2] = ch; cc.crop[3] = cw;
-    g_compose_cache_invalidate();          // the same scratch now holds other tables
   }
   DStage D;
   std::memset(&D, 0, sizeof(D));
@@ -1320,15 +1379,6 @@ int32_t build_crop_stage(int H, int W, const int32_t* crop, Bump& b, hipStream_t
   return ADVX_OK;
 }
 // ---- crop window o stage 0 as ONE table per axis (k_stage0_fwd_multi / k_stage_bwd* then go image <-> canvas directly)
-struct ComposeCache {
-  const float* where = nullptr;
-  const advx_plan* plan = nullptr;
-  int H = 0, W = 0, crop[4] = {0, 0, 0, 0};
-  hipStream_t stream = nullptr;
-};
-thread_local ComposeCache g_compose_cache;
-void g_compose_cache_invalidate() { g_compose_cache = ComposeCache(); }
-
 struct ComposeGeom {
   int s[2], ts[2];      // forward / transposed row lengths per axis
 };
@@ -1380,7 +1430,7 @@ bool compose_geom(const advx_plan* p, int H, int W, const int32_t* crop, Compose
 
 // carve the composed tables out of scratch (the crop tables' place) and launch - or hand over, `deferred` - their construction
 int32_t build_composed_stage(const advx_plan* p, int H, int W, const int32_t* crop, Bump& b, hipStream_t stq, DStage* out,
-                             bool may_reuse = false, TapBuild* deferred = nullptr) {
+                             bool may_reuse = false, TapBuild* deferred = nullptr, PendingTables* pending = nullptr) {
   ComposeGeom g;
   REQUIRE(compose_geom(p, H, W, crop, &g), ADVX_E_UNSUPPORTED, "this crop window does not compose with the plan's stage 0");
   const DStage& D0 = p->dstage[0];
@@ -1405,13 +1455,18 @@ int32_t build_composed_stage(const advx_plan* p, int H, int W, const int32_t* cr
     f[ax] = DevTaps{outs[ax], g.s[ax], a[ax].start, a[ax].count, a[ax].w};
     t[ax] = DevTaps{mids[ax], g.ts[ax], a[ax].tstart, a[ax].tcount, a[ax].tw};
   }
-  ComposeCache& cc = g_compose_cache;
-  const bool same = may_reuse && cc.where == where && cc.plan == p && cc.H == H && cc.W == W && cc.stream == stq &&
-                    cc.crop[0] == crop[0] && cc.crop[1] == crop[1] && cc.crop[2] == crop[2] && cc.crop[3] == crop[3];
+  TableRecord rec;
+  rec.kind = 2; rec.plan = p; rec.H = H; rec.W = W; rec.stream = stq;
+  for (int k = 0; k < 4; ++k) rec.crop[k] = crop[k];
+  REQUIRE(!deferred || pending, ADVX_E_BADARG, "build_composed_stage: a deferred construction needs somebody to commit it");
+  const bool same = may_reuse && !deferred && tables_hold(where, rec);
   if (!same) {
+    tables_forget(where);                  // whatever the area held is about to be overwritten
     if (deferred) {
       deferred[0] = a[0];
       deferred[1] = a[1];
+      pending->where = where;
+      pending->rec = rec;
     } else {
       // the transposed rows read the finished forward table: two launches
       TapBuild fw[2] = {a[0], a[1]}, tr[2] = {a[0], a[1]};
@@ -1424,10 +1479,8 @@ int32_t build_composed_stage(const advx_plan* p, int H, int W, const int32_t* cr
       const int rows = std::max(a[0].row_hi, a[1].row_hi);
       hipLaunchKernelGGL(k_build_taps, dim3((rows + kBlock - 1) / kBlock, 2), dim3(kBlock), 0, stq, tr[0], tr[1]);
       LAUNCH_CHECK();
+      tables_commit(where, rec);
     }
-    cc.where = where; cc.plan = p; cc.H = H; cc.W = W; cc.stream = stq;
-    for (int k = 0; k < 4; ++k) cc.crop[k] = crop[k];
-    g_crop_cache = CropCache();            // the same scratch now holds other tables
   }
   DStage D = D0;                           // canvas geometry, padding, normalisation, nesting: the plan's
   D.src_h = H; D.src_w = W;                // the source is the whole image; rows outside the window have no taps
@@ -1468,6 +1521,7 @@ extern "C" int32_t advx_collect_crop(advx_plan* p, const void* grad_out, int32_t
   hipStream_t st = (hipStream_t)stream;
   Bump b{image_scratch};
   (void)b.take(partial_floats(H, W));          // the tables sit behind the statistics partials, as in advx_forward_multi
+  const float* table_area = b.base + b.used;
   DStage D;
   rc = build_composed_stage(p, H, W, crop, b, st, &D, /*may_reuse=*/true);     // the forward's tables, if still there
   if (rc) return rc;
@@ -1485,8 +1539,8 @@ extern "C" int32_t advx_collect_crop(advx_plan* p, const void* grad_out, int32_t
   launch_stage_bwd(D, stage_grad(p, 0, ws), grad_s, (long long)H * W, W, accumulate, st);
   LAUNCH_CHECK();
   // the tables have served their step: the image-level backward that follows carves its buffers over them, so a later call
-  // with the same window must rebuild, not trust the cache
-  g_compose_cache_invalidate();
+  // with the same window must rebuild, not trust the record
+  tables_forget(table_area);
   return ADVX_OK;
 }
 
@@ -1526,10 +1580,14 @@ static int32_t image_fwd_impl(const float* p, const float* x0, int32_t H, int32_
   DStage crop_stage;
   TapBuild taps[2];
   int tap_blocks = 0;          // per axis; > 0: the first launch below also builds the crop window's tap tables
+  PendingTables built;         // committed once the launch that builds the last rows has been issued (here, or by the emit)
+  bool commit_here = false;
+  if (!crop) tables_forget(b.base + b.used);      // a step without a window: whatever tables this scratch held are not this step's
   if (crop) {
-    int32_t rc = compose ? build_composed_stage(compose, H, W, crop, b, st, composed, false, taps)
-                         : build_crop_stage(H, W, crop, b, st, &crop_stage, false, taps);
+    int32_t rc = compose ? build_composed_stage(compose, H, W, crop, b, st, composed, false, taps, &built)
+                         : build_crop_stage(H, W, crop, b, st, &crop_stage, false, taps, &built);
     if (rc) return rc;
+    commit_here = true;
     tap_blocks = (std::max(taps[0].row_hi, taps[1].row_hi) + kBlock - 1) / kBlock;
     if (defer && !g_generic_kernels) {
       // the forward needs only the forward tables; a transposed row costs two binary searches and several rows of
@@ -1542,6 +1600,8 @@ static int32_t image_fwd_impl(const float* p, const float* x0, int32_t H, int32_
       // transposed rows: one per window row (own tables) or per image row (composed); forward rows: out_size
       defer->later.blocks = (std::max(defer->later.t[0].row_hi - defer->later.t[0].row_lo,
                                       defer->later.t[1].row_hi - defer->later.t[1].row_lo) + kBlock - 1) / kBlock;
+      defer->tables = built;       // the transposed rows are not built by this call: whoever launches them commits
+      commit_here = false;
       tap_blocks = (std::max(taps[0].out_size, taps[1].out_size) + kBlock - 1) / kBlock;
     }
   }
@@ -1592,6 +1652,7 @@ static int32_t image_fwd_impl(const float* p, const float* x0, int32_t H, int32_
       hipLaunchKernelGGL(k_prep<true>, dim3(nblk), dim3(kBlock), 0, st, p, x0, eps, n, s, partials);
     LAUNCH_CHECK();
   }
+  if (commit_here) tables_commit(built);          // every row of the window's tables was built by the launch(es) above
   if (crop && !compose) {
     // block 0 of the window's resize reduces the statistics partials: no one-block launch in between
     const float* src = s + (size_t)crop[0] * W + crop[1];
@@ -1697,6 +1758,7 @@ extern "C" int32_t advx_image_bwd(const float* p, const float* s, const float* g
   const float c_fit = imgfit_scale / (float)n;
   Bump b{scratch};
   (void)b.take(partial_floats(H, W));
+  if (!crop) tables_forget(b.base + b.used);      // the buffers below are carved where a window's tables would sit
   const float* gs = garg;
   if (blur_k > 0 && blur_bwd_fusable(blur_k / 2, H, W)) {
     int32_t rc = check_blur(H, W, blur_k, blur_sigma);
@@ -1806,6 +1868,7 @@ extern "C" int32_t advx_image_bwd_update(float* p, const float* s, const float* 
   const float c_fit = imgfit_scale / (float)n;
   Bump b{image_scratch};
   (void)b.take(partial_floats(H, W));
+  if (!crop) tables_forget(b.base + b.used);      // the buffers below are carved where a window's tables would sit
   double* partials = reinterpret_cast<double*>(update_scratch);
   const int nblk = grid_for(n, 2048);
   const OptScalars o = to_dev(opt);
@@ -1967,15 +2030,19 @@ static int32_t fused_fwd_impl(advx_plan* p, const float* pp, const float* x0, fl
     bps = 4;
     slices = (batch + 3) / 4;
   }
-  dim3 grid(gx, slices + 1);  // y == 0: statistics blocks, y >= 1: batch slices
+  dim3 grid(pad_xcd(gx), slices + 1);  // y == 0: statistics blocks, y >= 1: batch slices; x padded: see pad_xcd
 #define ADVX_FF_S(N, T, S)                                                                                       \
   ADVX_LAUNCH_TIMED(PROF_FWD, (k_fused_fwd<N, T, S>), grid, dim3(kBlock), st, (const float*)v_buf, (const float*)s_buf, x0, n, \
                     batch, bps, stats, unit_noise, seed, offset, out, f.hdr, f.img_rows[parity],                  \
-                    (const double*)f.norm_partials, sched)
+                    (const double*)f.norm_partials, sched, eps, fused_geom(p))
 #define ADVX_FF(N, T) do { if (sched) ADVX_FF_S(N, T, true); else ADVX_FF_S(N, T, false); } while (0)
 #define ADVX_FF_IO(N) \
   do { if (io == 0) ADVX_FF(N, 0); else if (io == 1) ADVX_FF(N, 1); else ADVX_FF(N, 2); } while (0)
-  if (noise == 0) ADVX_FF_IO(0); else if (noise == 1) ADVX_FF_IO(1); else if (noise == 2) ADVX_FF_IO(2);
+  if (g_pair_lean && noise == 2 && io == 0 && !sched && prepared) {
+    ADVX_LAUNCH_TIMED(PROF_FWD, (k_fused_fwd<2, 0, false, true>), grid, dim3(kBlock), st, pp, (const float*)s_buf, x0, n, batch, bps,
+                      stats, unit_noise, seed, offset, out, f.hdr, f.img_rows[parity], (const double*)f.norm_partials, sched, eps,
+                      fused_geom(p));
+  } else if (noise == 0) ADVX_FF_IO(0); else if (noise == 1) ADVX_FF_IO(1); else if (noise == 2) ADVX_FF_IO(2);
   else ADVX_FF_S(3, 0, false);      // float32 boundary only, like the chain it serves
 #undef ADVX_FF_IO
 #undef ADVX_FF
@@ -2031,6 +2098,11 @@ static int32_t fused_bwd_impl(advx_plan* p, const void* g, int32_t io, int32_t b
       if (io == 0) ADVX_FB(U, 0, O); else if (io == 1) ADVX_FB(U, 1, O); else ADVX_FB(U, 2, O);            \
     }                                                                                                      \
   } while (0)
+    if (g_pair_lean && io == 0 && !sched) {
+      ADVX_LAUNCH_TIMED(PROF_BWD, (k_fused_bwd<true, 0, false, true>), dim3(f.bwd_blocks), dim3(kBlock), st, g, batch, pp, x0, eps,
+                        fused_geom(p), c_fit, mask, m, v, grad_p, to_dev(opt), s_next, v_buf, f.norm_partials, stats, f.hdr,
+                        (const double*)f.img_partials, sched);
+    } else
     ADVX_FB_IO(true, to_dev(opt));
   } else {
     OptScalars none;
@@ -2608,7 +2680,7 @@ extern "C" int32_t advx_prepared_fwd(advx_plan* p, const float* pp, const float*
   }
   int gx, slices, bps;
   emit_slices(q_hi - q_lo, batch, plan_has_patch_layout(p), p->io != 0, &gx, &slices, &bps);
-  dim3 grid(gx, slices);
+  dim3 grid(pad_xcd(gx), slices);
   const float* sigma_dev = stats + ADVX_STAT_QERR_STD;   // quantise error of the PREVIOUS image (not yet rotated)
 #define ADVX_EMIT_T(N, T)                                                                                           \
   hipLaunchKernelGGL((k_emit<N, T>), grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, \

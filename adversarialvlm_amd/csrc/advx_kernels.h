@@ -1371,16 +1371,22 @@ __global__ void __launch_bounds__(kBlock) k_fused_prep(const float* __restrict__
 // addresses it (one block = four consecutive batch rows of ONE pixel; the host launches four rows per thread): the
 // forward the one-launch chain runs on its own - first step, first step after a resume - draws the noise the chain's
 // own emission would have drawn, so a resumed run continues bit for bit
-template <int NOISE, int IO, bool SCHED = false>   // SCHED: step scalars from device memory (graph replay), else arguments
+// LEAN (experiment, ADVX_TUNE_PAIR_LEAN): v_buf IS p; s and v are re-derived here from p and x0 with the expressions of
+// k_fused_prep / k_fused_bwd (same bits), so that the backward need not store s_next / v_buf
+template <int NOISE, int IO, bool SCHED = false, bool LEAN = false>   // SCHED: step scalars from device memory (graph replay), else arguments
 __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ v_buf, const float* __restrict__ s_buf,
                                                       const float* __restrict__ x0, long long n, int batch,
                                                       int b_per_slice, float* stats, const float* __restrict__ unit_noise,
                                                       unsigned long long seed, unsigned long long offset,
                                                       void* __restrict__ out, FusedHeader* __restrict__ hdr,
                                                       double* __restrict__ img_partials,
-                                                      const double* __restrict__ norm_partials, SchedDev* sched) {
+                                                      const double* __restrict__ norm_partials, SchedDev* sched,
+                                                      float eps, FusedGeom geo) {
   const long long n4 = n >> 2;
   const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // gridDim.x is padded to a multiple of 8 (host: pad_xcd); the column blocks that exist:
+  const int col_blocks = (int)((n4 + blockDim.x - 1) / blockDim.x);
+  if ((int)blockIdx.x >= col_blocks) return;
   if (SCHED) {
     const unsigned long long t = sched->fwd_step;       // uniform: a scalar load
     offset += t;
@@ -1395,7 +1401,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ 
     if (nb > 0) finalize_norm_block(norm_partials, nb, stats);
     if (threadIdx.x == 0) {
       hdr->norm_blocks = 0;
-      hdr->image_blocks = gridDim.x;
+      hdr->image_blocks = col_blocks;
     }
   }
   const long long i0 = q << 2;
@@ -1404,8 +1410,14 @@ __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ 
     // carries the double-precision reduction on its tail
     double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
     if (q < n4) {
-      float4 sv = *reinterpret_cast<const float4*>(s_buf + i0);
+      float4 sv;
       float4 xv = *reinterpret_cast<const float4*>(x0 + i0);
+      if (LEAN) {
+        const float4 pv = *reinterpret_cast<const float4*>(v_buf + i0);
+        sv = make_float4(xv.x + eps * tanhf(pv.x), xv.y + eps * tanhf(pv.y), xv.z + eps * tanhf(pv.z), xv.w + eps * tanhf(pv.w));
+      } else {
+        sv = *reinterpret_cast<const float4*>(s_buf + i0);
+      }
       stat_accumulate(sv.x, sv.x - xv.x, acc);
       stat_accumulate(sv.y, sv.y - xv.y, acc);
       stat_accumulate(sv.z, sv.z - xv.z, acc);
@@ -1415,7 +1427,14 @@ __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ 
     return;
   }
   if (q >= n4) return;
-  const float4 v = *reinterpret_cast<const float4*>(v_buf + i0);
+  float4 v = *reinterpret_cast<const float4*>(v_buf + i0);
+  if (LEAN) {
+    const float4 xv = *reinterpret_cast<const float4*>(x0 + i0);
+    const int c = (int)(i0 / geo.plane);          // plane % 4 == 0: one channel per float4
+    const float mu = geo.mean[c], sd = geo.stdv[c];
+    v = make_float4(((xv.x + eps * tanhf(v.x)) - mu) / sd, ((xv.y + eps * tanhf(v.y)) - mu) / sd,
+                    ((xv.z + eps * tanhf(v.z)) - mu) / sd, ((xv.w + eps * tanhf(v.w)) - mu) / sd);
+  }
   const int b0 = ((int)blockIdx.y - 1) * b_per_slice;
   const int b1 = min(batch, b0 + b_per_slice);
   if (NOISE == 3) {
@@ -1452,7 +1471,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ 
 // block = 64 float4 columns (256 pixels); the 4 waves split the batch and meet in LDS; then
 // thread t owns pixel t of the block.  Its per-pixel state is prefetched before the batch
 // loop so that no dependent load sits on the tail.
-template <bool UPDATE, int IO, bool SCHED = false>
+template <bool UPDATE, int IO, bool SCHED = false, bool LEAN = false>   // LEAN: no grad_p / s_next / v_buf stores (experiment)
 __global__ void __launch_bounds__(kBlock) k_fused_bwd(const void* __restrict__ g, int batch, float* __restrict__ p,
                                                       const float* __restrict__ x0, float eps, FusedGeom geo,
                                                       float c_fit, const float* __restrict__ mask,
@@ -1520,7 +1539,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_bwd(const void* __restrict__ g
     if (UPDATE) {
       gp = gp * mk;
       nacc[0] = (double)gp * (double)gp;
-      grad_p[i] = gp;
+      if (!LEAN) grad_p[i] = gp;
       if (o.apply) {
         if (o.kind == 0) {
           adamw_element(pp, mm, vv, gp, o);
@@ -1531,10 +1550,12 @@ __global__ void __launch_bounds__(kBlock) k_fused_bwd(const void* __restrict__ g
           p[i] = pp;
         }
       }
-      // prepare the next forward from the UPDATED p
-      float sn = xv + eps * tanhf(pp);
-      s_next[i] = sn;
-      v_buf[i] = (sn - geo.mean[c]) / sd;
+      if (!LEAN) {
+        // prepare the next forward from the UPDATED p
+        float sn = xv + eps * tanhf(pp);
+        s_next[i] = sn;
+        v_buf[i] = (sn - geo.mean[c]) / sd;
+      }
     } else {
       grad_p[i] = gp;
     }

@@ -206,12 +206,19 @@ def emit_multi(plans, argument, batches, sigma_dev=None, unit_noises=None, philo
 
 def forward_multi(p, x0, epsilon, stats, image_scratch, plans, batches, s, argument=None, blur=None, crop=None,
                   unit_noises=None, philox=None, workspaces=None, outs=None, keep_padding=False):
-    """image_fwd + emit_multi in one call (advx_forward_multi).  -> (list of pixel_values, argument)."""
+    """image_fwd + emit_multi in one call (advx_forward_multi).  -> (list of pixel_values, argument).
+
+    The returned `argument` is what the plans read: `s` without a crop window, the window resized back to H x W with one.
+    COMPOSED CROP: with ONE plan and a window for which `crop_composes(plan, H, W, crop)` holds, the library applies the
+    window's resize and the plan's own as one table (include/advx.h "Composed crop") and the resized window is never formed:
+    the second return value is then None (a buffer passed as `argument` is left untouched), and the backward of that step is
+    `collect_crop` + `image_bwd*` WITHOUT a crop window."""
     _require_cuda(p, x0, stats, image_scratch, s)
     dev = p.device
     _, H, W = p.shape
     n = len(plans)
-    if crop is not None and argument is None:
+    composed = bool(crop is not None and n == 1 and crop_composes(plans[0], H, W, crop))
+    if crop is not None and argument is None and not composed:
         argument = torch.empty_like(p)
     k, sig = (blur if blur is not None else (0, 0.0))
     keep, cptr = _crop_arg(crop)
@@ -235,6 +242,8 @@ def forward_multi(p, x0, epsilon, stats, image_scratch, plans, batches, s, argum
                                         int(seed), (C.c_uint64 * n)(*[int(o) for o in offsets]), _ptr_array(outs),
                                         _ptr_array(workspaces), (C.c_int64 * n)(*[int(w.numel()) for w in workspaces]),
                                         1 if keep_padding else 0, _stream(p)), "advx_forward_multi")
+    if composed:
+        return outs, None
     return outs, (argument if argument is not None else s)
 
 

@@ -507,12 +507,20 @@ class PixelPGD:
             else:
                 ops.fused_flush(self.plans[0], self.stats, self.fused_scratch)
         self._flush_norm()
+        # `chain`: the kernel chain that wrote the state.  The one-launch `step` chain addresses the noise generator
+        # differently from the others (ADVX_PHILOX_STEP_CHAIN): a run only continues bit for bit on the chain it started on
         return dict(p=self.p.clone(), m=self.m.clone(), v=self.v.clone(), grad=self.grad.clone(), stats=self.stats.clone(),
-                    lr=self.lr, opt_steps=self.opt_steps, iteration=self.iteration, seed=self.seed)
+                    lr=self.lr, opt_steps=self.opt_steps, iteration=self.iteration, seed=self.seed, chain=self.mode)
 
     def load_state_dict(self, sd):
         if self._last is not None:
             raise L.AdvxError("load_state_dict between forward and backward_update")
+        saved_chain = sd.get("chain")                # absent in files written before round 4: nothing to compare
+        if saved_chain is not None and saved_chain != self.mode:
+            raise L.AdvxError(f"this state was written by the '{saved_chain}' chain and this engine runs the '{self.mode}' chain "
+                              "(another batch size under fused_mode='auto', or another fused_mode): the run would go on with "
+                              f"another noise stream instead of continuing bit for bit - construct the engine with "
+                              f"fused_mode='{saved_chain}' (the trainers do so on --resume_from)")
         for k in ("p", "m", "v", "grad", "stats"):
             getattr(self, k).copy_(sd[k].to(self.p.device))
         self.lr, self.opt_steps, self.iteration = float(sd["lr"]), int(sd["opt_steps"]), int(sd["iteration"])

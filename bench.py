@@ -20,6 +20,16 @@ object (64 prompts in total on the same engine) is reported beside the weak `val
 `value` = prompts * steps / s over all ranks.  The VLM forward/backward (PyTorch-ROCm,
 ~1e15 FLOP per 64-prompt step) is NOT inside this number - see DESIGN.md "Measurement".
 
+Two timings, reported together:
+ (A) the owned pixel path isolated = `value`, `ms_per_step`, `roofline`.  The K-step region is timed by a HIP event pair on the
+     launch stream (`ms_per_step`; max over ranks) with the wall clock between the two fences beside it (`ms_per_step_wall`); no
+     per-launch event sits inside the K steps - the per-kernel averages of `roofline` come from the 1000-step region timed right
+     after it (`long_run`), where every stride-th launch carries its own event pair.
+ (B) end to end = `e2e`: the same loop around a random-init LLaVA-1.5-7B architecture in fp16 (tools/e2e_bench.py), run in a
+     FRESH CHILD PROCESS that is started and finished BEFORE this process makes its first GPU call, under a wall budget
+     (`--e2e-budget`, 240 s); `e2e: {"skipped": reason}` when the budget is hit or the child fails - (A) is never lost to (B).
+     Single GPU only (at N > 1 the self-launching parent runs it on one GPU before it starts the ranks).
+
 Cache state.  The two B*P_out tensors of a step (86.7 MB each) fit the 256 MiB Infinity Cache, and a loop
 that reuses ONE gradient tensor and ONE output block never leaves it; in the real loop a 7B VLM runs between
 the two launches.  The timed region therefore ROTATES through `--ring` (default 8) distinct gradient tensors
@@ -117,7 +127,57 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
-def launch_ranks(n, argv, backend, limit_s):
+def count_devices():
+    """GPUs this process could use, counted by a short-lived CHILD: torch.cuda.device_count() stays off HIP only while
+    torch's amdsmi route works - its fallback is hipGetDeviceCount, which would create a HIP context in a process that is
+    about to start GPU children.  The child may initialise whatever it likes; this process stays clean."""
+    try:
+        res = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                             capture_output=True, text=True, timeout=300)
+        return int(res.stdout.strip().splitlines()[-1]) if res.returncode == 0 and res.stdout.strip() else 0
+    except (OSError, ValueError, subprocess.TimeoutExpired):
+        return 0
+
+
+def run_e2e_child(args):
+    """Timing (B) of SURVEY 8(d): tools/e2e_bench.py as a fresh child, before this process touches the GPU.
+    -> the `e2e` object of the line.  Never raises: whatever goes wrong becomes {"skipped": reason}."""
+    assert not torch.cuda.is_initialized(), "the e2e child must run before this process makes a GPU call"
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--model", args.e2e_model, "--batch", str(args.e2e_batch),
+           "--micro", str(args.e2e_micro), "--steps", str(args.e2e_steps), "--warmup", "1", "--image", str(args.e2e_image)]
+    t0 = time.monotonic()
+    try:
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, cwd=ROOT)     # stderr inherited: its progress lines
+    except OSError as e:
+        return {"skipped": f"could not start tools/e2e_bench.py: {e}"}
+    try:
+        out, _ = proc.communicate(timeout=args.e2e_budget)
+    except subprocess.TimeoutExpired:
+        proc.terminate()                                  # exactly the PID started above
+        try:
+            proc.communicate(timeout=20)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            proc.communicate()
+        return {"skipped": f"wall budget of {args.e2e_budget:.0f} s hit (child stopped)", "model": args.e2e_model}
+    took = time.monotonic() - t0
+    if proc.returncode != 0:
+        return {"skipped": f"child exit status {proc.returncode}", "model": args.e2e_model, "wall_s": round(took, 1)}
+    try:
+        rec = json.loads([ln for ln in out.splitlines() if ln.strip().startswith("{")][-1])
+    except (IndexError, ValueError) as e:
+        return {"skipped": f"no JSON line from the child ({type(e).__name__})", "model": args.e2e_model}
+    return {"s_per_step": rec["s_per_step"], "prompt_steps_per_s": rec["e2e_prompt_steps_per_s"],
+            "first_step_s": rec.get("first_step_s"), "model": rec["model"], "batch": rec["batch"], "micro_batch": rec["micro_batch"],
+            "steps": args.e2e_steps, "seq_len": rec.get("seq_len"), "dtype": rec.get("dtype"), "chain": rec.get("chain"),
+            "approx_model_tflops": rec.get("approx_model_tflops"), "peak_mem_gb": rec.get("peak_mem_gb"), "wall_s": round(took, 1),
+            "n_gpus": 1,
+            "note": "random-init architecture (no weights offline), VLM forward + backward-to-pixels under PyTorch-ROCm: ~1e15 "
+                    "FLOP of dense GEMM per 64-prompt step that this repository does not own; fresh child process, finished "
+                    "before the pixel-path run started"}
+
+
+def launch_ranks(n, argv, backend, limit_s, e2e=None):
     """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks as fresh child
     processes - one per GPU, torchrun's environment variables, rendezvous on 127.0.0.1 - BEFORE this process makes
     any GPU call (a process that has initialised HIP must never fork/exec GPU work), wait for them and hand rank 0's
@@ -126,7 +186,8 @@ def launch_ranks(n, argv, backend, limit_s):
     one-process-per-GPU form of SURVEY 8(e).  With fewer GPUs than ranks (a one-GPU box) the ranks fold onto the
     devices there are and the host collectives travel over gloo, since RCCL refuses two ranks on one device: a
     rehearsal of the entry point, said so in the line's `config.launcher`."""
-    n_dev = torch.cuda.device_count()          # counts devices without creating a HIP context on this image
+    n_dev = count_devices()                    # asked of a child: this process makes no HIP call, whatever torch falls back to
+    assert not torch.cuda.is_initialized(), "the launcher must not hold a HIP context when it starts the ranks"
     if n_dev == 0:
         print("bench.py needs a GPU (there is no CPU fallback)", file=sys.stderr)
         return 2
@@ -141,6 +202,8 @@ def launch_ranks(n, argv, backend, limit_s):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ADVX_BENCH_LAUNCHER=note)
+        if e2e is not None and r == 0:
+            env["ADVX_BENCH_E2E"] = json.dumps(e2e)     # (B), measured by the parent before the ranks: rank 0 prints it
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL and the peer exchange need it
         env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores()[0] // n)))
         # rank 0 inherits stdout (its one JSON line); the other ranks' stdout goes to stderr
@@ -205,9 +268,18 @@ def main():
                     help="supplementary figure: the cold loop as a captured hipGraph, on an engine of its own")
     ap.add_argument("--no-strong", action="store_true",
                     help="N > 1: skip the supplementary strong-scaling region (64 prompts in total) after the weak one")
-    ap.add_argument("--launch-timeout", type=float, default=1500.0,
-                    help="self-launched ranks (no WORLD_SIZE in the environment) are stopped after this many seconds")
+    ap.add_argument("--launch-timeout", type=float, default=1200.0,
+                    help="self-launched ranks (no WORLD_SIZE in the environment) are stopped after this many seconds "
+                         "(below the driver's own 1500 s limit, so that this one fires first)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip timing (B): the end-to-end child run around a random-init VLM")
+    ap.add_argument("--e2e-budget", type=float, default=240.0, help="wall budget of the end-to-end child, seconds")
+    ap.add_argument("--e2e-model", default="synthetic/llava-1.5-7b")
+    ap.add_argument("--e2e-batch", type=int, default=BATCH)
+    ap.add_argument("--e2e-micro", type=int, default=32)
+    ap.add_argument("--e2e-steps", type=int, default=2)
+    ap.add_argument("--e2e-image", type=int, default=H)
     ap.add_argument("--nt-loads", action="store_true", help="experiment: the pair's backward reads grad_out non-temporally")
+    ap.add_argument("--lean", action="store_true", help="experiment: the pair without the s / v / grad_p streams (ADVX_TUNE_PAIR_LEAN)")
     args = ap.parse_args()
     io_dtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.io]
     io_bytes = 4 if args.io == "f32" else 2
@@ -215,9 +287,19 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # the driver's form, `python bench.py --gpus N`: no launcher around us - be the launcher.  Nothing above
         # this line has created a HIP context (importing torch and counting devices do not).
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.backend, args.launch_timeout))
+        e2e = None if args.no_e2e else run_e2e_child(args)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:] + ["--no-e2e"], args.backend, args.launch_timeout, e2e))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    # (B) first: a fresh child, started and finished before this process makes any GPU call
+    if "ADVX_BENCH_E2E" in os.environ:
+        e2e = json.loads(os.environ["ADVX_BENCH_E2E"])
+    elif args.no_e2e:
+        e2e = {"skipped": "--no-e2e"}
+    elif world > 1:
+        e2e = {"skipped": "external launcher with N > 1: the ranks are already running (python bench.py --gpus N runs it first)"}
+    else:
+        e2e = run_e2e_child(args)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start {args.gpus} ranks (or none: bench.py launches them)")
@@ -251,6 +333,9 @@ def main():
     if args.nt_loads:
         from adversarialvlm_amd import _lib
         _lib.check(_lib.load().advx_set_tuning(2, 1), "advx_set_tuning")
+    if args.lean:
+        from adversarialvlm_amd import _lib
+        _lib.check(_lib.load().advx_set_tuning(5, 1), "advx_set_tuning")
 
     if args.scaling == "strong":
         if BATCH % world:
@@ -303,28 +388,34 @@ def main():
 
     from adversarialvlm_amd import ops
 
-    def timed(step, steps=None, warmup=None):
-        """W warm-up steps, then exactly K steps between two fences; MAX over ranks.  Every stride-th launch of the
-        B*P_out movers carries its own start/stop HIP event pair on the launch stream (advx_profile_*,
-        hipExtLaunchKernelGGL); the stride is chosen so that at least 10 launches per kernel are timed whatever
-        K >= 10 is (64 from K = 640 up).  A timed launch is fenced off from its neighbours by the event
-        packets (measured: +0.6 us per timed launch with fence-free events), which is why not every launch is timed."""
+    def timed(step, steps=None, warmup=None, profile=False):
+        """W warm-up steps, then exactly K steps between two fences.  -> (device seconds, wall seconds, per-kernel profile | None),
+        each the MAX over ranks.  Device seconds = a HIP event pair recorded on the launch stream (torch's current stream IS the
+        stream every advx_* launch of the engine goes to) right after the first fence and right after the last launch.
+        profile=True: every stride-th launch of the B*P_out movers also carries its own start/stop event pair (advx_profile_*,
+        hipExtLaunchKernelGGL; at least 10 per kernel, 64 from K = 640 up) - used for the 1000-step region only, so that no
+        event packet sits inside the K steps that `value` is computed from (a timed launch costs +0.6 us)."""
         steps = args.steps if steps is None else steps
         for _ in range(args.warmup if warmup is None else warmup):
             step()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fence()
-        ops.profile_begin(max(steps, 1), stride=profile_stride(steps))
+        if profile:
+            ops.profile_begin(max(steps, 1), stride=profile_stride(steps))
         t0 = time.perf_counter()
+        ev0.record()
         for _ in range(steps):
             step()
+        ev1.record()
         fence()
-        dt = time.perf_counter() - t0
-        prof = ops.profile_end()
+        dt_wall = time.perf_counter() - t0
+        dt_dev = ev0.elapsed_time(ev1) * 1e-3
+        prof = ops.profile_end() if profile else None
         if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt_dev, dt_wall], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, prof
+            dt_dev, dt_wall = float(t[0].item()), float(t[1].item())
+        return dt_dev, dt_wall, prof
 
     runs = {}
     if args.cache in ("both", "cold"):
@@ -332,13 +423,16 @@ def main():
     held.clear()
     if args.cache in ("both", "hot"):
         runs["hot"] = timed(step_hot)
-    # A short timed region (the driver's K = 20 is 0.8 ms of device work) carries fixed costs - first launch after the
-    # fence, the fence itself, one timed launch in two - of about 130 us: the same loop over 1000 steps is reported
-    # beside it as `long_run` (supplementary; `value` stays the K steps asked for).
-    long_run = None
-    if args.steps < 500 and "cold" in runs:
-        long_run = timed(step_cold, steps=1000, warmup=0)
-        held.clear()
+    main_key = "cold" if "cold" in runs else "hot"
+    # The profiled region: the same loop as the headline over 1000 steps with per-launch event pairs on every stride-th
+    # launch.  It supplies the per-kernel averages of `roofline` and is reported as `long_run`; `value` stays the K steps asked
+    # for, timed above without any event packet between their launches.
+    PROFILED_STEPS = 1000
+    long_run = timed(step_cold if main_key == "cold" else step_hot, steps=PROFILED_STEPS, warmup=0, profile=True)
+    held.clear()
+    hot_prof = None
+    if main_key == "cold" and "hot" in runs:
+        hot_prof = timed(step_hot, steps=PROFILED_STEPS, warmup=0, profile=True)
     # Strong scaling beside the weak figure (N > 1): the same cold loop with the GLOBAL batch held at 64 prompts
     # (64/N per rank, SURVEY 8(e) form A) on the same engine and exchange - the batch is an argument of forward().
     strong_run = None
@@ -353,8 +447,8 @@ def main():
             eng.backward_update([gs_s[cnt_s[0] % ring]])
             cnt_s[0] += 1
 
-        sdt, _ = timed(step_strong, steps=max(args.steps, 200), warmup=max(args.warmup, 10))
-        strong_run = (sdt, max(args.steps, 200), Bs)
+        sdt, sdt_wall, _ = timed(step_strong, steps=max(args.steps, 200), warmup=max(args.warmup, 10))
+        strong_run = (sdt, sdt_wall, max(args.steps, 200), Bs)
         held_s.clear()
     # The same cold steps as a captured hipGraph (--graph; supplementary figure): `ring` steps of the pair - forward and
     # backward with their per-step scalars in device memory (advx_fused_*_sched) - captured once and replayed; no host work
@@ -390,8 +484,8 @@ def main():
             geng.advance(ring * (replays + 1))
             graph_run = (gdt, ring * replays)
         del geng
-    main_key = "cold" if "cold" in runs else "hot"
-    dt, prof = runs[main_key]
+    dt, dt_wall, _ = runs[main_key]
+    prof = long_run[2]
     # after the timed regions: the replicas of p must still hold the same bits on every rank, and no
     # barrier of the peer exchange may have timed out
     replicas_identical = None
@@ -412,8 +506,7 @@ def main():
     bytes_bwd = io_bytes * B * n_in + 4 * 8 * n_in     # read B*P_out; p,x0,mask,m,v in; p,m,v(+grad) out
     bytes_step = bytes_fwd + bytes_bwd                 # 4*(2*B*P_out + 10*P_in) at f32
 
-    def dominant(run):
-        dt_, prof_ = run
+    def dominant(prof_, step_ms):
         fwd_avg, bwd_avg, step_avg = prof_["fwd"][0], prof_["bwd"][0], prof_["step"][0]
         if eng.mode == "step":
             # one launch per step: backward of step t + forward of step t+1 in the same kernel
@@ -421,7 +514,7 @@ def main():
         if eng.mode == "pair":
             return (("k_fused_fwd", bytes_fwd, fwd_avg) if fwd_avg >= bwd_avg else ("k_fused_bwd", bytes_bwd, bwd_avg))
         # generic chain: k_emit / k_batch_reduce are not instrumented; price the whole step
-        return "generic chain (whole step, wall)", bytes_step, dt_ / args.steps * 1e3
+        return "generic chain (whole step, HIP events)", bytes_step, step_ms
 
     def kernel_ms(prof_):
         return {"k_fused_fwd": round(prof_["fwd"][0], 5), "k_fused_bwd": round(prof_["bwd"][0], 5),
@@ -436,7 +529,8 @@ def main():
         return out
 
     steps_per_s = args.steps / dt
-    dom_name, dom_bytes, dom_ms = dominant(runs[main_key])
+    ldt, ldt_wall, _ = long_run
+    dom_name, dom_bytes, dom_ms = dominant(prof, ldt / PROFILED_STEPS * 1e3)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     traffic = traffic_source = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -451,6 +545,18 @@ def main():
         if traffic is not None:
             traffic_source = ("stored rocprofv3 PMC pass (profiles/pmc_traffic.json), not a live counter of this run: " +
                               (f"commit {meta['commit']}, {meta['date_utc']} UTC" if meta else "round 2, unstamped"))
+    # who ran this: one row per rank - the line itself answers "did the backend see N ranks on N devices?"
+    topo = None
+    if world > 1 or args.force_exchange:
+        props = torch.cuda.get_device_properties(dev)
+        bus = ":".join(f"{int(getattr(props, k)):02x}" for k in ("pci_domain_id", "pci_bus_id", "pci_device_id") if hasattr(props, k))
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "pci": bus or None,
+                "uuid": str(getattr(props, "uuid", "")) or None, "host": socket.gethostname(), "pid": os.getpid()}
+        rows = [None] * torch.distributed.get_world_size()
+        torch.distributed.all_gather_object(rows, mine)
+        keys = {(r["host"], r["pci"] or r["uuid"] or r["device"]) for r in rows}
+        topo = {"ranks": rows, "backend_world_size": torch.distributed.get_world_size(),
+                "backend_name": torch.distributed.get_backend(), "devices_distinct": len(keys) == len(rows)}
     if rank == 0:
         roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -461,6 +567,8 @@ def main():
                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 5),
                     "kernel_ms": kernel_ms(prof), "kernel_frac": kernel_fracs(prof),
                     "timed_launches": {k: v[1] for k, v in prof.items()},
+                    "kernel_timing": f"per-launch HIP event pairs on the launch stream, every {profile_stride(PROFILED_STEPS)}th launch of the "
+                                     f"{PROFILED_STEPS}-step region (`long_run`) that follows the K steps of `value`; none inside the K steps",
                     "step_algorithmic_bytes": bytes_step,
                     "step_frac_of_hbm_peak": round(bytes_step * steps_per_s / 1e9 / HBM_PEAK_GBS, 4)}
         line = {
@@ -469,6 +577,10 @@ def main():
             "unit": "prompt-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 5),
+            "ms_per_step_wall": round(dt_wall / args.steps * 1e3, 5),
+            "value_wall": round(args.steps / dt_wall * B * world, 1),
+            "timing": "value / ms_per_step: HIP event pair on the launch stream around exactly K steps, between two "
+                      "barrier + synchronize fences, max over ranks; *_wall: time.perf_counter() between the same fences",
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"LLaVA-1.5 tanh-clamp attack, 336x336x3 image, {B}-prompt batch per GPU, "
@@ -487,11 +599,18 @@ def main():
             "steps_per_s": round(steps_per_s, 1),
             "roofline": roofline,
         }
+        if topo is not None:
+            line["config"].update(topo)
+            line["config"]["multi_gpu_hardware_evidence"] = (
+                "this line" if topo["devices_distinct"] and topo["backend_name"] == "nccl" else
+                "none: ranks share a device or the backend is not RCCL - a rehearsal of the entry point, not a scaling figure")
         if main_key == "cold" and "hot" in runs:
-            hdt, hprof = runs["hot"]
-            hname, hbytes, hms = dominant(runs["hot"])
+            hdt, hdt_wall, _ = runs["hot"]
+            hprof = hot_prof[2]
+            hname, hbytes, hms = dominant(hprof, hot_prof[0] / PROFILED_STEPS * 1e3)
             line["in_cache"] = {"value": round(args.steps / hdt * B * world, 1), "unit": "prompt-steps/s",
                                 "ms_per_step": round(hdt / args.steps * 1e3, 5),
+                                "ms_per_step_wall": round(hdt_wall / args.steps * 1e3, 5),
                                 "steps_per_s": round(args.steps / hdt, 1),
                                 "note": "same K steps on ONE resident gradient tensor / output block (both fit the "
                                         "256 MiB Infinity Cache): the round-1 loop, an upper estimate"}
@@ -501,16 +620,17 @@ def main():
             roofline["kernel_ms_in_cache"] = kernel_ms(hprof)
             roofline["kernel_frac_in_cache"] = kernel_fracs(hprof)
             roofline["step_frac_of_hbm_peak_in_cache"] = round(bytes_step * (args.steps / hdt) / 1e9 / HBM_PEAK_GBS, 4)
-        if long_run is not None:
-            ldt, lprof = long_run
-            line["long_run"] = {"value": round(1000 / ldt * B * world, 1), "unit": "prompt-steps/s", "steps": 1000,
-                                "ms_per_step": round(ldt / 1000 * 1e3, 5), "kernel_ms": kernel_ms(lprof),
-                                "note": f"the same cold loop over 1000 steps, timed after the K = {args.steps} above: fixed costs "
-                                        "of a short region (first launch, fence, timed launches) amortised; supplementary"}
+        line["long_run"] = {"value": round(PROFILED_STEPS / ldt * B * world, 1), "unit": "prompt-steps/s", "steps": PROFILED_STEPS,
+                            "ms_per_step": round(ldt / PROFILED_STEPS * 1e3, 5),
+                            "ms_per_step_wall": round(ldt_wall / PROFILED_STEPS * 1e3, 5), "kernel_ms": kernel_ms(prof),
+                            "note": f"the same {main_key} loop over {PROFILED_STEPS} steps, timed after the K = {args.steps} above, "
+                                    f"with per-launch event pairs on every {profile_stride(PROFILED_STEPS)}th launch (the source of "
+                                    "roofline.kernel_ms); supplementary"}
         if strong_run is not None:
-            sdt, ssteps, Bs = strong_run
+            sdt, sdt_wall, ssteps, Bs = strong_run
             line["strong"] = {"value": round(ssteps / sdt * Bs * world, 1), "unit": "prompt-steps/s", "scaling": "strong",
-                              "steps": ssteps, "ms_per_step": round(sdt / ssteps * 1e3, 5), "steps_per_s": round(ssteps / sdt, 1),
+                              "steps": ssteps, "ms_per_step": round(sdt / ssteps * 1e3, 5),
+                              "ms_per_step_wall": round(sdt_wall / ssteps * 1e3, 5), "steps_per_s": round(ssteps / sdt, 1),
                               "prompts_per_gpu": Bs, "global_prompts": Bs * world,
                               "note": "same engine and exchange, global batch held at 64 prompts; timed after the weak region"}
         if isinstance(graph_run, str):
@@ -521,6 +641,7 @@ def main():
                                     "ms_per_step": round(gdt / gsteps * 1e3, 5),
                                     "note": f"the cold loop as a hipGraph: {ring} steps of the pair captured once (per-step scalars in "
                                             "device memory), replayed; supplementary - `value` is the eager loop"}
+        line["e2e"] = e2e
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

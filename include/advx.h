@@ -118,7 +118,10 @@ const char* advx_last_error(void);
 /* Development switch.  ADVX_TUNE_GENERIC_KERNELS = 1 makes every call take the general kernels (run-time blur
  * radius, one launch per operation) instead of the specialised / merged ones; results are bit-identical, which
  * is what the tests use it for.  Process-wide, not thread-safe. */
+#define ADVX_TUNE_RESET_ALL 0         /* every switch back to its default, whatever `value` is */
 #define ADVX_TUNE_GENERIC_KERNELS 1
+#define ADVX_TUNE_PAIR_LEAN 5       /* experiment (round 4): the float32 Philox pair re-derives s, v in the forward; the backward stores neither
+                                     them nor grad_p - measured, not the default */
 #define ADVX_TUNE_PAIR_NT_LOADS 2   /* advx_fused_bwd reads grad_out with non-temporal loads (same results) */
 #define ADVX_TUNE_SEPARATE_CROP 4   /* 1: never compose a crop window with a plan's stage 0 (advx_forward_multi) - the window is resized
                                      * into `argument` and the plan resamples that, two launches each way, bit-identical to the

@@ -39,6 +39,17 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _tuning_switches_back_to_default():
+    """The library's development switches (advx_set_tuning) are process-wide: whatever a test did with them - through the
+    context managers of ops.py, or directly, or by failing half way - the next test starts from the defaults."""
+    yield
+    lib_mod = sys.modules.get("adversarialvlm_amd._lib")
+    lib = getattr(lib_mod, "_lib", None) if lib_mod is not None else None       # only if a test loaded it
+    if lib is not None:
+        lib.advx_set_tuning(0, 0)           # ADVX_TUNE_RESET_ALL
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name))
 

@@ -57,7 +57,7 @@ def _launch(monkeypatch, n, n_dev, codes, after=None, limit=100.0):
         return made[-1]
     FakeClock.now = 0.0
     monkeypatch.setattr(bench.subprocess, "Popen", popen)
-    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: n_dev)
+    monkeypatch.setattr(bench, "count_devices", lambda: n_dev)      # the real one asks a child process
     monkeypatch.setattr(bench.time, "monotonic", FakeClock.monotonic)
     monkeypatch.setattr(bench.time, "sleep", FakeClock.sleep)
     rc = bench.launch_ranks(n, ["--gpus", str(n), "--steps", "20"], "nccl", limit)
@@ -101,3 +101,59 @@ def test_nonzero_exit_without_a_hang_and_the_time_limit(monkeypatch):
     assert rc == 1
     rc, procs = _launch(monkeypatch, 2, 2, [0, 0], after=[1e9, 1e9], limit=30.0)
     assert rc == 1 and all(p.terminated for p in procs) and FakeClock.now < 60.0
+
+
+def test_devices_are_counted_by_a_child_and_the_launcher_stays_off_the_gpu(monkeypatch):
+    """torch.cuda.device_count() may fall back to hipGetDeviceCount - the count is asked of a child instead, and
+    the launcher asserts that it holds no HIP context when it starts the ranks."""
+    seen = {}
+
+    def run(argv, **kw):
+        seen["argv"] = argv
+
+        class R:
+            returncode, stdout = 0, "noise\n3\n"
+        return R()
+    monkeypatch.setattr(bench.subprocess, "run", run)
+    assert bench.count_devices() == 3
+    assert seen["argv"][0] == sys.executable and "device_count" in seen["argv"][-1]
+    monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: (_ for _ in ()).throw(OSError("no python")))
+    assert bench.count_devices() == 0
+    monkeypatch.setattr(bench.torch.cuda, "is_initialized", lambda: True)
+    with pytest.raises(AssertionError):
+        _launch(monkeypatch, 2, 2, [0, 0])
+
+
+def test_e2e_child_outcomes_never_raise(monkeypatch):
+    """Timing (B): whatever the child does - result, failure, time-out, garbage - becomes the `e2e` object; (A) is never lost."""
+    import argparse
+    import json
+    import subprocess
+    args = argparse.Namespace(e2e_model="synthetic/tiny-llava", e2e_batch=4, e2e_micro=2, e2e_steps=2, e2e_image=56, e2e_budget=5.0)
+
+    class Child:
+        def __init__(self, out, code=0, hang=False):
+            self.out, self.returncode, self.hang, self.stopped = out, code, hang, False
+
+        def communicate(self, timeout=None):
+            if self.hang and not self.stopped:
+                raise subprocess.TimeoutExpired("e2e", timeout)
+            return self.out, None
+
+        def terminate(self):
+            self.stopped = True
+
+        def kill(self):
+            self.stopped = True
+    rec = {"s_per_step": 1.5, "e2e_prompt_steps_per_s": 42.0, "first_step_s": 6.0, "model": "m", "batch": 4, "micro_batch": 2}
+    good = Child("[e2e] chatter\n" + json.dumps(rec) + "\n")
+    monkeypatch.setattr(bench.subprocess, "Popen", lambda *a, **k: good)
+    out = bench.run_e2e_child(args)
+    assert out["s_per_step"] == 1.5 and out["prompt_steps_per_s"] == 42.0 and out["first_step_s"] == 6.0 and "skipped" not in out
+    for child, word in ((Child("", code=1), "exit status 1"), (Child("no json here"), "no JSON"), (Child("", hang=True), "budget")):
+        monkeypatch.setattr(bench.subprocess, "Popen", lambda *a, _c=child, **k: _c)
+        out = bench.run_e2e_child(args)
+        assert word in out["skipped"], out
+    assert child.stopped                                     # the hung child was stopped (its own PID only)
+    monkeypatch.setattr(bench.subprocess, "Popen", lambda *a, **k: (_ for _ in ()).throw(OSError("x")))
+    assert "could not start" in bench.run_e2e_child(args)["skipped"]

@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.timeout(600)
 def test_bench_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                          "--e2e-model", "synthetic/tiny-llava", "--e2e-batch", "4", "--e2e-micro", "2", "--e2e-image", "56"],
                          capture_output=True, text=True, env=env, cwd=ROOT, timeout=540)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
@@ -30,6 +31,17 @@ def test_bench_launches_its_own_ranks():
     assert line["config"]["exchange_report"]["chosen"] in ("peer", "host")
     assert line["strong"]["scaling"] == "strong" and line["strong"]["global_prompts"] == 64 and line["strong"]["value"] > 0
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+    # the line proves its topology: two ranks, both on the one device of this box - NOT hardware evidence, and it says so
+    cfg = line["config"]
+    assert cfg["backend_world_size"] == 2 and [r["rank"] for r in cfg["ranks"]] == [0, 1]
+    assert len({r["pid"] for r in cfg["ranks"]}) == 2 and all(r["host"] for r in cfg["ranks"])
+    import torch
+    if torch.cuda.device_count() == 1:
+        assert cfg["devices_distinct"] is False and cfg["backend_name"] == "gloo"
+        assert cfg["multi_gpu_hardware_evidence"].startswith("none")
+    # (B) was measured once, by the parent, before the ranks were started (tiny model here)
+    assert line["e2e"].get("s_per_step", 0) > 0 and line["e2e"]["model"] == "synthetic/tiny-llava", line["e2e"]
+    assert line["ms_per_step"] > 0 and line["ms_per_step_wall"] >= line["ms_per_step"] * 0.9
     print("bench --gpus 2 (self-launched):", line["value"], line["unit"], "| strong", line["strong"]["value"],
           "|", line["config"]["exchange"])
 
@@ -52,9 +64,39 @@ def test_bench_launcher_reports_a_failing_rank():
     """A rank that fails must fail the whole call: no JSON line on stdout, exit status 1, the ranks' exit codes on stderr - never a
     hang and never a line from a partial run.  (The one-launch chain cannot host the gradient exchange: every rank raises.)"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--chain", "step"],
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--chain", "step", "--no-e2e"],
                          capture_output=True, text=True, env=env, cwd=ROOT, timeout=540)
     assert res.returncode == 1, (res.returncode, res.stderr[-1500:])
     assert res.stdout.strip() == ""
     assert "rank exit codes" in res.stderr or "ranks stopped" in res.stderr
     assert "cannot host the gradient all-reduce" in res.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_single_gpu_line_carries_both_timings():
+    """`python3 bench.py --gpus 1 --steps 20 --warmup 5` as the driver runs it, with a tiny model standing in for the 7B
+    architecture of timing (B): ONE line with (A) - HIP-event `ms_per_step`, wall beside it, `roofline` from the profiled
+    1000-step region - and (B) `e2e` from a child that ran before the parent touched the GPU; and a child that fails costs (A) nothing."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"]
+    res = subprocess.run(cmd + ["--e2e-model", "synthetic/tiny-llava", "--e2e-batch", "4", "--e2e-micro", "2", "--e2e-image", "56"],
+                         capture_output=True, text=True, env=env, cwd=ROOT, timeout=540)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    e2e = line["e2e"]
+    for key in ("s_per_step", "prompt_steps_per_s", "first_step_s", "model", "batch", "micro_batch"):
+        assert key in e2e, (key, e2e)
+    assert e2e["s_per_step"] > 0 and e2e["batch"] == 4 and e2e["micro_batch"] == 2
+    assert line["ms_per_step"] > 0 and line["ms_per_step_wall"] > 0 and line["value_wall"] > 0
+    assert abs(line["value"] - 64 * 1e3 / line["ms_per_step"]) <= 1e-3 * line["value"]
+    # the K = 20 region timed by events is within a few per cent of the 1000-step region (3 % asked; 6 % allowed for a busy box)
+    assert abs(line["ms_per_step"] / line["long_run"]["ms_per_step"] - 1.0) < 0.06, (line["ms_per_step"], line["long_run"])
+    assert line["roofline"]["timed_launches"]["bwd"] >= 64 and "long_run" in line["roofline"]["kernel_timing"]
+    # a child that cannot run (unknown model): (A) is all there, e2e says why it is not
+    res = subprocess.run(cmd + ["--e2e-model", "synthetic/no-such-model"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=540)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line2 = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][-1])
+    assert "skipped" in line2["e2e"] and line2["value"] > 0 and line2["roofline"]["frac"] > 0

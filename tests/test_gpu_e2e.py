@@ -171,6 +171,47 @@ def test_resume_continues_bit_for_bit(tmp_path, size, batch, mode):
     assert a.size == 3 * size * size and np.array_equal(a, b)
 
 
+def test_resume_stays_on_the_chain_that_wrote_the_state(tmp_path):
+    """the state records its kernel chain.  A run started with 4 prompts (one-launch `step` chain) and resumed with
+    20 (where `auto` alone would pick the pair, which addresses the noise generator differently) stays on the step chain; an
+    engine on another chain refuses the state instead of going on with another noise stream."""
+    from adversarialvlm_amd import _lib as L
+    from adversarialvlm_amd import attack_model
+    from adversarialvlm_amd.pgd import PixelPGD
+    from adversarialvlm_amd.plan import Plan
+    tmp = str(tmp_path)
+    img = _gray(tmp, 56)
+    attack_model.train(**_kw(tmp, "part", 4, img_orig=img, batch_size=4))
+    path = os.path.join(tmp, "part", "state_iter_4.pt")
+    assert attack_model.saved_chain(path) == "step"
+    eng, _ = attack_model.train(**_kw(tmp, "rest", 6, img_orig=img, batch_size=20, resume_from=path, return_engine=True))
+    assert eng.mode == "step"
+    sd = torch.load(path, map_location="cpu")["engine"]
+    pair = PixelPGD(torch.rand(3, 56, 56, device="cuda:0"), [Plan.llava(56, 56, 56, 56)], fused_mode="pair")
+    with pytest.raises(L.AdvxError, match="written by the 'step' chain"):
+        pair.load_state_dict(sd)
+    sd.pop("chain")                          # a file from before round 4 carries no chain: accepted as before
+    pair.load_state_dict(sd)
+
+
+def test_accumulated_loss_never_mixes_accumulation_windows(tmp_path):
+    """ADVICE r03 (attack_model.py:349-353 of the reference resets at EVERY optimiser step): with the default log cadence the key
+    is the sum of the window's `loss` values; under a sparser cadence a window that was only partly logged has no key at all."""
+    from adversarialvlm_amd import attack_model
+    tmp = str(tmp_path)
+    _, dense = attack_model.train(**_kw(tmp, "dense", 8, grad_accum_steps=2, return_engine=True))
+    assert [("accumulated_loss" in h) for h in dense] == [False, True] * 4
+    for k in (1, 3, 5, 7):
+        assert dense[k]["accumulated_loss"] == pytest.approx(dense[k - 1]["loss"] + dense[k]["loss"], rel=1e-12)
+    _, sparse = attack_model.train(**_kw(tmp, "sparse", 8, grad_accum_steps=2, log_every=3, return_engine=True))
+    assert [h["iteration"] for h in sparse] == [0, 3, 6, 7]
+    # iteration 3 steps, but its window (2, 3) was logged in part; iteration 7's window (6, 7) was logged in full
+    assert "accumulated_loss" not in sparse[1] and "accumulated_loss" not in sparse[0] and "accumulated_loss" not in sparse[2]
+    assert sparse[3]["accumulated_loss"] == pytest.approx(sparse[2]["loss"] + sparse[3]["loss"], rel=1e-12)
+    # same run, same numbers: the log cadence changes what is written, not what is computed
+    assert sparse[3]["loss"] == dense[7]["loss"] and sparse[1]["loss"] == dense[3]["loss"]
+
+
 def test_generation_probe_writes_reference_csv(tmp_path):
     import csv
     from adversarialvlm_amd import attack_model

@@ -389,6 +389,38 @@ def test_forward_multi_is_image_fwd_then_emit_multi(dev, blur, crop):
         assert float(runs[0][-1][L.STAT_SIGMA]) == pytest.approx(0.02)     # rotated from the previous QERR_STD
 
 
+def test_forward_multi_with_a_composed_crop_returns_no_argument(dev):
+    """one LLaVA plan + a window that composes - advx_forward_multi never forms the resized window, so
+    ops.forward_multi returns None for it (not an uninitialised buffer) and leaves a caller's buffer untouched; the
+    pixel_values equal the two-launch form's at 1e-4 (the composed map drops one float32 rounding)."""
+    from adversarialvlm_amd import _lib as L
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan
+    H, W = 80, 72
+    gen = torch.Generator().manual_seed(5)
+    x0 = torch.rand(3, H, W, generator=gen).to(dev)
+    p = (torch.randn(3, H, W, generator=gen) * 0.4).to(dev)
+    plan, win = Plan.llava(H, W, 64, 64), (5, 4, 60, 56)
+    assert ops.crop_composes(plan, H, W, win)
+    stats = torch.zeros(L.STATS_N, device=dev)
+    scr = ops.image_scratch(H, W, 0, dev)
+    s = torch.empty_like(x0)
+    sentinel = torch.full_like(x0, -7.0)
+    outs, arg = ops.forward_multi(p, x0, 0.5, stats, scr, [plan], [2], s, argument=sentinel, crop=win)
+    assert arg is None and bool((sentinel == -7.0).all())
+    outs2, arg2 = ops.forward_multi(p, x0, 0.5, stats, scr, [plan], [2], s, crop=win)
+    assert arg2 is None and torch.equal(outs[0], outs2[0])
+    # the two-launch form (window resized to an image, then the plan's resize)
+    stats_b = torch.zeros(L.STATS_N, device=dev)
+    _, arg_b = ops.image_fwd(p, x0, 0.5, stats_b, ops.image_scratch(H, W, 0, dev), crop=win, s=torch.empty_like(x0))
+    ref = ops.emit(plan, arg_b, 2)
+    assert rel_err(outs[0].cpu(), ref.cpu()) < 1e-4
+    # a window that does not compose (three plans): the resized window IS returned
+    plans = [Plan.llava(H, W, 64, 64), Plan.phi3(H, W), Plan.mllama(H, W, tile=32)]
+    outs3, arg3 = ops.forward_multi(p, x0, 0.5, stats, scr, plans, [1, 1, 1], s, crop=win)
+    assert arg3 is not None and torch.equal(arg3, arg_b)
+
+
 @pytest.mark.parametrize("fam", ["llava", "qwen2vl", "phi3", "mllama"])
 @pytest.mark.parametrize("size", [(336, 336), (512, 512), (400, 600)])
 def test_full_size_reference_captures(dev, fam, size):

@@ -265,6 +265,71 @@ def test_two_host_threads_drive_two_engines(dev):
         assert torch.equal(engines[k].p, alone[k].p), k
 
 
+@pytest.mark.parametrize("composed", [False, True])
+def test_table_records_follow_the_scratch_not_the_calling_thread(dev, composed):
+    """the record of which crop tables an image scratch holds is keyed by the scratch, not by the host thread.
+    ONE scratch: forward with window X on thread A, forward with window Y on thread B, backward of X on thread A - with the
+    round-3 thread_local record, thread A trusted its stale "same window" and gathered through Y's tables.  The gradient
+    must equal the single-thread run (forward X, backward X) bit for bit; own tables (image_fwd / image_bwd) and composed ones
+    (forward_multi / collect_crop)."""
+    import threading
+    from adversarialvlm_amd import _lib as L
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan
+    H, W = 96, 80
+    gen = torch.Generator().manual_seed(17)
+    x0 = torch.rand(3, H, W, generator=gen).to(dev)
+    p = (torch.randn(3, H, W, generator=gen) * 0.3).to(dev)
+    plan = Plan.llava(H, W, 64, 64)
+    X, Y = (6, 4, 70, 60), (20, 10, 60, 64)
+    assert ops.crop_composes(plan, H, W, X) and ops.crop_composes(plan, H, W, Y)
+    g_img = torch.randn(3, H, W, generator=gen).to(dev)
+    g_out = torch.randn(2, plan.out_numel, generator=gen).to(dev)
+    ws = torch.empty(plan.workspace_floats, device=dev)
+
+    def run(interleave):
+        scratch = ops.image_scratch(H, W, 0, dev)
+        stats = torch.zeros(L.STATS_N, device=dev)
+        s = torch.empty_like(x0)
+        out = {}
+
+        def fwd(win):
+            if composed:
+                ops.forward_multi(p, x0, 0.5, stats, scratch, [plan], [2], s, crop=win, workspaces=[ws])
+            else:
+                ops.image_fwd(p, x0, 0.5, stats, scratch, crop=win, s=s)
+
+        def bwd(win):
+            if composed:
+                out["g"] = ops.collect_crop(plan, g_out, 2, win, scratch, grad_s=torch.empty_like(x0), workspace=ws).clone()
+            else:
+                out["g"] = ops.image_bwd(p, s, g_img, 0.5, 1.0, torch.empty_like(x0), scratch, crop=win).clone()
+
+        def on_thread(fn, *a):
+            err = []
+
+            def body():
+                try:
+                    fn(*a)
+                    torch.cuda.synchronize()
+                except Exception as e:      # noqa: BLE001 - re-raised on the main thread
+                    err.append(e)
+            t = threading.Thread(target=body)
+            t.start()
+            t.join()
+            if err:
+                raise err[0]
+        fwd(X)                              # thread A = this thread
+        if interleave:
+            on_thread(fwd, Y)               # thread B overwrites the tables in the same scratch
+        bwd(X)                              # thread A again
+        torch.cuda.synchronize()
+        return out["g"]
+    alone, mixed = run(False), run(True)
+    assert torch.equal(alone, mixed)
+    assert float(alone.abs().max()) > 0
+
+
 def test_plans_and_engines_give_their_device_memory_back(dev):
     """Plans own device copies of their tap tables, engines own scratch and (data parallel) exchange segments: creating and
     dropping a few hundred of them, of every kind, must not move the device's free memory (hipMemGetInfo) - the library

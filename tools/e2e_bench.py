@@ -108,10 +108,13 @@ def main():
         eng.backward_update([grad])
         return loss_total
 
+    first_step_s = None
     for k in range(args.warmup):
         t1 = time.perf_counter()
         step()
         torch.cuda.synchronize()
+        if first_step_s is None:
+            first_step_s = time.perf_counter() - t1
         print(f"[e2e] warm-up step {k}: {time.perf_counter() - t1:.2f} s, peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB",
               file=sys.stderr, flush=True)
     torch.cuda.synchronize()
@@ -131,6 +134,7 @@ def main():
                       "pixel_io": args.pixel_io, "chain": eng.mode, "image": size,
                       "pixel_values_shape": list(pv_shape), "approx_model_tflops": round(flops / dt / 1e12, 1),
                       "losses": [round(v, 4) for v in losses], "load_s": round(t_load, 1),
+                      "first_step_s": None if first_step_s is None else round(first_step_s, 2),
                       "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
 
 
