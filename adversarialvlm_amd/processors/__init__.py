@@ -4,9 +4,12 @@ Same map and the same `load_components` contract as the reference's
 `src/processors/__init__.py:5-76` (ValueError for unknown names; a `processor_class` of None is
 accepted and yields None, as for the reference's evaluation-only judge entry `google/gemma-3-12b-it`
 - that entry itself is NOT registered here: the judge and the evaluation harness are out of scope,
-SURVEY.md section 2 rows 9 and 13-14), resolved inside this package.
+SURVEY.md section 2 rows 9 and 13-14), resolved inside this package.  The random-init `synthetic/*` architectures the tests and the end-to-end benchmark use are
+NOT part of this map: they live in `adversarialvlm_amd.testing` and register themselves when that package is imported
+(directly, or by name through ADVX_PLUGIN_MODULES).
 """
 import importlib
+import os
 from typing import Tuple
 
 MODEL_MAP = {
@@ -45,42 +48,6 @@ MODEL_MAP = {
         "input_class": "AdvLlavaInputs",
         "processor_class": "DifferentiableLlavaImageProcessor",
     },
-    # offline, random-init architectures with synthetic token ids (no weights in the container)
-    "synthetic/tiny-llava": {
-        "module": "adversarialvlm_amd.processors.synthetic",
-        "input_class": "AdvLlavaInputs",
-        "processor_class": "DifferentiableLlavaImageProcessor",
-    },
-    "synthetic/tiny-mllama": {
-        "module": "adversarialvlm_amd.processors.synthetic_vlms",
-        "input_class": "AdvMllamaInputs",
-        "processor_class": "DifferentiableMllamaImageProcessor",
-    },
-    "synthetic/tiny-qwen2vl": {
-        "module": "adversarialvlm_amd.processors.synthetic_vlms",
-        "input_class": "AdvQwen2VLInputs",
-        "processor_class": "DifferentiableQwen2VLImageProcessor",
-    },
-    "synthetic/mllama-11b": {
-        "module": "adversarialvlm_amd.processors.synthetic_vlms",
-        "input_class": "AdvMllamaInputs",
-        "processor_class": "DifferentiableMllamaImageProcessor",
-    },
-    "synthetic/qwen2-vl-7b": {
-        "module": "adversarialvlm_amd.processors.synthetic_vlms",
-        "input_class": "AdvQwen2VLInputs",
-        "processor_class": "DifferentiableQwen2VLImageProcessor",
-    },
-    "synthetic/tiny-phi3v": {
-        "module": "adversarialvlm_amd.processors.synthetic_phi3v",
-        "input_class": "AdvPhiInputs",
-        "processor_class": "DifferentiablePhi3VImageProcessor",
-    },
-    "synthetic/llava-1.5-7b": {
-        "module": "adversarialvlm_amd.processors.synthetic",
-        "input_class": "AdvLlavaInputs",
-        "processor_class": "DifferentiableLlavaImageProcessor",
-    },
 }
 
 
@@ -89,7 +56,17 @@ def register(model_name: str, module: str, input_class: str, processor_class):
     MODEL_MAP[model_name] = {"module": module, "input_class": input_class, "processor_class": processor_class}
 
 
+def _import_plugin_modules():
+    """ADVX_PLUGIN_MODULES = comma-separated module names; importing one registers its models (`register`).  How a process
+    that is only handed a model NAME - a trainer run as a command - learns of models outside the map above, e.g. the random-init
+    architectures of adversarialvlm_amd.testing that the tests and the end-to-end benchmark run around."""
+    for name in filter(None, (m.strip() for m in os.environ.get("ADVX_PLUGIN_MODULES", "").split(","))):
+        importlib.import_module(name)
+
+
 def load_components(model_name: str) -> Tuple[object, object, object]:
+    if model_name not in MODEL_MAP:
+        _import_plugin_modules()
     if model_name not in MODEL_MAP:
         raise ValueError(f"Model {model_name} not found in MODEL_MAP. Please add it to the map.")
     info = MODEL_MAP[model_name]

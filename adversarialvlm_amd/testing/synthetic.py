@@ -19,7 +19,7 @@ from types import SimpleNamespace
 import torch
 
 from ..plan import CLIP_MEAN, CLIP_STD
-from .llavaprocessor import AdvLlavaInputs, DifferentiableLlavaImageProcessor  # noqa: F401  (registry looks them up here)
+from ..processors.llavaprocessor import AdvLlavaInputs, DifferentiableLlavaImageProcessor  # noqa: F401  (registry looks them up here)
 
 IMAGE_TOKEN = "<image>"
 

@@ -32,7 +32,7 @@ import torch.nn.functional as F
 from PIL import Image
 
 from ..plan import CLIP_MEAN, CLIP_STD
-from .phi3processor import AdvPhiInputs, DifferentiablePhi3VImageProcessor  # noqa: F401  (registry looks them up here)
+from ..processors.phi3processor import AdvPhiInputs, DifferentiablePhi3VImageProcessor  # noqa: F401  (registry looks them up here)
 from .synthetic_vlms import _vocabulary
 
 CROP = 336

@@ -25,8 +25,8 @@ without weights or a network (tests/test_gpu_e2e_families.py).  Phi-3.5-Vision i
 import torch
 
 from ..plan import CLIP_MEAN, CLIP_STD
-from .llama32processor import AdvMllamaInputs, DifferentiableMllamaImageProcessor  # noqa: F401  (registry looks them up here)
-from .qwen2VLprocessor import AdvQwen2VLInputs, DifferentiableQwen2VLImageProcessor  # noqa: F401
+from ..processors.llama32processor import AdvMllamaInputs, DifferentiableMllamaImageProcessor  # noqa: F401  (registry looks them up here)
+from ..processors.qwen2VLprocessor import AdvQwen2VLInputs, DifferentiableQwen2VLImageProcessor  # noqa: F401
 
 # a closed word list (word-level tokenizers have no hashing): everything else is <unk>
 _COMMON = ("describe item number in this picture what is shown region of the image sure here it of course answer scene please "

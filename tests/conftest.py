@@ -11,6 +11,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the random-init `synthetic/*` model architectures are test support, outside the product's registry: this process registers
+# them by importing the package, the trainers the tests run as COMMANDS find them through the environment
+os.environ.setdefault("ADVX_PLUGIN_MODULES", "adversarialvlm_amd.testing")
+import adversarialvlm_amd.testing  # noqa: E402,F401
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _tiny(device):
-    from adversarialvlm_amd.processors.synthetic import load_model_and_processor
+    from adversarialvlm_amd.testing.synthetic import load_model_and_processor
     return load_model_and_processor("synthetic/tiny-llava", device, seed=0)
 
 

@@ -8,7 +8,7 @@ import torch
 
 from adversarialvlm_amd import dp
 from adversarialvlm_amd.processors import MODEL_MAP, load_components
-from adversarialvlm_amd.processors.synthetic import ToyLlavaProcessor
+from adversarialvlm_amd.testing.synthetic import ToyLlavaProcessor
 
 
 def test_registry_contract():
@@ -336,3 +336,27 @@ def test_reference_launch_scripts_find_their_options_here():
             hits = [o for o in options if o == flag] or [o for o in options if o.startswith(flag)]
             assert len(hits) == 1, (script, flag, hits)
     assert seen >= 14
+
+
+def test_product_registry_has_no_test_models_until_a_plugin_module_brings_them():
+    """the random-init `synthetic/*` architectures are test support (adversarialvlm_amd.testing), not
+    entries of the product's MODEL_MAP.  A fresh process sees the reference's seven names only; ADVX_PLUGIN_MODULES (what the
+    trainers run as commands rely on) or an import of the package registers the rest."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("from adversarialvlm_amd.processors import MODEL_MAP, load_components\n"
+            "names = sorted(MODEL_MAP)\n"
+            "assert len(names) == 7 and not any(n.startswith('synthetic/') for n in names), names\n"
+            "try:\n"
+            "    load_components('synthetic/tiny-llava')\n"
+            "    print('found')\n"
+            "except ValueError as e:\n"
+            "    print('unknown')\n")
+    env = {k: v for k, v in os.environ.items() if k != "ADVX_PLUGIN_MODULES"}
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=env, timeout=120)
+    assert res.returncode == 0 and res.stdout.strip() == "unknown", res.stderr[-2000:]
+    env["ADVX_PLUGIN_MODULES"] = "adversarialvlm_amd.testing"
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=env, timeout=120)
+    assert res.returncode == 0 and res.stdout.strip() == "found", res.stderr[-2000:]

@@ -25,7 +25,7 @@ TOL = 2e-5        # same torch ops on both sides; the model's GEMMs may take ano
 
 def families():
     """name in the captures -> (loader(device), AdvInputs, DifferentiableProcessor, oracle processor factory)"""
-    from adversarialvlm_amd.processors import synthetic, synthetic_phi3v as F3, synthetic_vlms as S
+    from adversarialvlm_amd.testing import synthetic, synthetic_phi3v as F3, synthetic_vlms as S
     from oracle.processors import MllamaOracle, Phi3Oracle, Qwen2VLOracle
     llava0 = (lambda d: synthetic.load_model_and_processor("synthetic/tiny-llava", d, seed=0), synthetic.AdvLlavaInputs,
               synthetic.DifferentiableLlavaImageProcessor, lambda: LlavaOracle(56, 56))

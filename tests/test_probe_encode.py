@@ -19,7 +19,7 @@ def _image(H, W):
 
 
 def test_mllama_probe_encodes_several_prompts():
-    from adversarialvlm_amd.processors.synthetic_vlms import AdvMllamaInputs, mllama_processor
+    from adversarialvlm_amd.testing.synthetic_vlms import AdvMllamaInputs, mllama_processor
     proc, _ = mllama_processor()
     img = _image(60, 90)
     ip = AdvMllamaInputs(questions=QUESTIONS, test_questions=QUESTIONS, batch_size=2, original_image=img, processor=proc,
@@ -40,7 +40,7 @@ def test_qwen2vl_batches_equal_one_processor_call(size):
     """get_inputs_train() (cached tokenisation, hand-assembled left padding, image_grid_thw from the PLAN) against
     ONE call of the processor on the same prompts, key by key - qwen2VLprocessor.py:68-96 keeps whatever that call
     returns.  `mm_token_type_ids` (transformers 5.x) follows input_ids' padding."""
-    from adversarialvlm_amd.processors.synthetic_vlms import (AdvQwen2VLInputs, DifferentiableQwen2VLImageProcessor,
+    from adversarialvlm_amd.testing.synthetic_vlms import (AdvQwen2VLInputs, DifferentiableQwen2VLImageProcessor,
                                                               qwen2vl_processor)
     proc, _ = qwen2vl_processor()
     H, W = size
@@ -68,9 +68,9 @@ def test_qwen2vl_batches_equal_one_processor_call(size):
 def test_phi3v_twin_batches_equal_the_reference_assembly(size):
     """get_inputs_train() of the Phi-3.5 plugin (cached tokenisation, image_sizes from the PLAN) against what the
     reference assembles per step - one processor call per prompt, pad_left, cat (phi3processor.py:275-311) - on the twin of
-    the remote processor (processors/synthetic_phi3v.py): key by key.  The number of negative placeholder ids equals the
+    the remote processor (testing/synthetic_phi3v.py): key by key.  The number of negative placeholder ids equals the
     plan's num_img_tokens, i.e. the HD geometry of the HIP path (C side) and of the twin's PIL path agree."""
-    from adversarialvlm_amd.processors.synthetic_phi3v import (AdvPhiInputs, DifferentiablePhi3VImageProcessor, phi3v_processor)
+    from adversarialvlm_amd.testing.synthetic_phi3v import (AdvPhiInputs, DifferentiablePhi3VImageProcessor, phi3v_processor)
     from adversarialvlm_amd.processors.phi3processor import pad_left
     proc, _ = phi3v_processor()
     H, W = size

@@ -39,6 +39,7 @@ def main():
     args = ap.parse_args()
     import threading
 
+    import adversarialvlm_amd.testing  # noqa: F401  (registers the random-init `synthetic/*` architectures)
     from adversarialvlm_amd.pgd import PixelPGD
     from adversarialvlm_amd.processors import load_components
     # MIOpen searches its convolution kernels the first time it sees a shape: the first step of a vision tower can take minutes

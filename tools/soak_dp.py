@@ -13,6 +13,8 @@ import sys
 import tempfile
 import time
 
+os.environ.setdefault("ADVX_PLUGIN_MODULES", "adversarialvlm_amd.testing")     # the synthetic/* models, also in the spawned ranks
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
