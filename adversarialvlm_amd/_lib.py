@@ -87,6 +87,10 @@ SIGNATURES = {
     "advx_forward_multi": (_I32, [_P, _P, _I32, _I32, _F, _I32, _F, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _I32, _U64, _P, _P, _P,
                                   _P, _I32, _P]),
     "advx_image_scratch_floats": (_I64, [_I32, _I32, _I32]),
+    "advx_image_step_supported": (_I32, [_I32, _I32, _I32]),
+    "advx_image_step": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _F, _I32, _F, _F, _P, _P, C.POINTER(OptScalars), _P, _P, _P,
+                               _F, _P, _P, _P, _P]),
+    "advx_forward_multi_ready": (_I32, [_I32, _I32, _I32, _P, _P, _P, _P, _I32, _P, _P, _P, _I32, _U64, _P, _P, _P, _P, _I32, _P]),
     "advx_image_fwd": (_I32, [_P, _P, _I32, _I32, _F, _I32, _F, _P, _P, _P, _P, _P, _P]),
     "advx_image_bwd": (_I32, [_P, _P, _P, _I32, _I32, _F, _I32, _F, _P, _F, _P, _I32, _P, _P]),
     "advx_update": (_I32, [_P, _P, _P, _P, _P, _I64, C.POINTER(OptScalars), _P, _P, _P]),

@@ -99,15 +99,32 @@ def random_resized_crop_params(height, width, scale, ratio):
 EXCHANGE_TIMEOUT_S = 300.0
 
 
-def save_state(engine, exp_path, global_iteration, iteration, name=None):
+def save_state(engine, exp_path, global_iteration, iteration, name=None, torch_rng=None):
     """True resume state (not in the reference): optimiser moments, schedules, the global RNG
     streams the shared draws come from (identical on all ranks).  Rank-local streams are re-derived on load:
-    the noise seed from the rank, the prompt stream from (seed, rank, iteration)."""
+    the noise seed from the rank, the prompt stream from (seed, rank, iteration).
+    torch_rng: the generator state to store instead of the current one - a loop that has already drawn the NEXT iteration's
+    crop window / blur sigma (draw_image_params ahead of the backward) hands in the state from before that draw, so that a
+    resumed run draws the same values at the top of its first iteration."""
     path = os.path.join(exp_path, name or f"state_iter_{global_iteration}.pt")
     torch.save({"engine": {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in engine.state_dict().items()},
                 "global_iteration": global_iteration, "iteration": iteration, "py_random": random.getstate(),
-                "torch_rng": torch.get_rng_state()}, path)
+                "torch_rng": torch.get_rng_state() if torch_rng is None else torch_rng}, path)
     return path
+
+
+def draw_image_params(use_gaussian_blur, gblur_sigma, use_local_crop, H, W, crop_scale, crop_ratio, sigma_per_step=False):
+    """(blur sigma | None, crop window | None) of ONE iteration, drawn from torch's global generator in the reference's order:
+    the cross trainer draws a sigma ~ U(0.1, 2) per step (crossattack_models.py:336-337, Q4) and then the window (:341-343); the
+    single trainer's sigma is a constant (attack_model.py:191-194) and only the window is drawn (:307-310).  Both loops call
+    this at the top of an iteration - or, when the engine fuses the next step's image kernel into this step's backward
+    (PixelPGD.step_fusion), one iteration ahead, right before backward_update: nothing else draws from that generator in
+    between, so the sequence of values is the same."""
+    sigma = None
+    if use_gaussian_blur:
+        sigma = torch.empty(1).uniform_(0.1, 2.0).item() if sigma_per_step else float(gblur_sigma)
+    crop = random_resized_crop_params(H, W, crop_scale, crop_ratio) if use_local_crop else None
+    return sigma, crop
 
 
 def saved_chain(path):
@@ -287,6 +304,9 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
     window_iterations = window_logged = 0       # of the current accumulation window: iterations seen / iterations logged
     refuse_flag = False
     history = []
+    ahead = None        # (blur sigma, crop window) of the next iteration when it was drawn ahead
+    image_draw = (use_gaussian_blur, gblur_sigma, use_local_crop, H, W, (crop_scale_min, crop_scale_max),
+                  (crop_ratio_min, crop_ratio_max), False)
     start_iteration = 0
     if resume_from:
         global_iteration, start_iteration = load_state(engine, resume_from)
@@ -299,14 +319,15 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
         if target_text_random:
             inputs_processor.set_target_text(random.choice(inputs_processor.target_texts))  # :283-290
         inputs = inputs_processor.get_inputs_train()                                        # :292
-        crop = None
-        if use_local_crop:
-            crop = random_resized_crop_params(H, W, (crop_scale_min, crop_scale_max), (crop_ratio_min, crop_ratio_max))
+        if ahead is not None:
+            blur_sigma, crop = ahead               # drawn one iteration ahead, for the fused step (same values, same order)
+            ahead = None
+        else:
+            blur_sigma, crop = draw_image_params(*image_draw)
         given = None
         if unit_noise_fn is not None:
             given = [unit_noise_fn(iteration, (local_batch * plan.out_shape[0],) + tuple(plan.out_shape[1:])).to(device)]
-        pixel_values = engine.forward(local_batch, unit_noises=given, blur_sigma=float(gblur_sigma) if use_gaussian_blur else None,
-                                      crop=crop)[0]                                         # :300-321 (HIP)
+        pixel_values = engine.forward(local_batch, unit_noises=given, blur_sigma=blur_sigma, crop=crop)[0]   # :300-321 (HIP)
         pixel_values.requires_grad_(True)
         inputs["pixel_values"] = pixel_values
         if suffix_only_ce:
@@ -318,7 +339,14 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
             loss = inputs_processor.get_loss(logits)                                        # :327
         loss = -loss if refuse_flag else loss
         (loss * engine.loss_scale(0)).backward()                                            # :330-332
-        stepped = engine.backward_update([pixel_values.grad])                               # :335-346, 366-373 (HIP)
+        rng_before, nxt = None, {}
+        if getattr(engine, "step_fusion", False) and iteration + 1 < num_iterations:
+            # the blur chain's backward also runs the NEXT iteration's tanh + blur (one launch, advx_image_step): it needs that
+            # iteration's window now.  A checkpoint of this iteration stores the generator as it was before the draw.
+            rng_before = torch.get_rng_state()
+            ahead = draw_image_params(*image_draw)
+            nxt = dict(next_blur_sigma=ahead[0], next_crop=ahead[1])
+        stepped = engine.backward_update([pixel_values.grad], **nxt)                        # :335-346, 366-373 (HIP)
         loss_value = loss.detach()
         if stepped:
             global_iteration += 1
@@ -363,7 +391,7 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
             img = engine.image()
             pil = adv_processor.tensor2pil(img)
             save_checkpoint(pil, img, exp_path, global_iteration)
-            save_state(engine, exp_path, global_iteration, iteration)
+            save_state(engine, exp_path, global_iteration, iteration, torch_rng=rng_before)
             if generation_probe:                                                            # :435-445
                 from .train_test import run_model_test
                 first_row, probe = run_model_test([model], [processor], [inputs_processor], [model_name], test_questions,

@@ -26,7 +26,7 @@ from PIL import Image
 
 from . import prompts as P
 from .attack_model import (EXCHANGE_TIMEOUT_S, JsonlLogger, add_dp_arguments, assert_replicas, create_directory,
-                           create_mask, load_state, random_resized_crop_params, reseed_prompt_stream, run_main,
+                           create_mask, draw_image_params, load_state, reseed_prompt_stream, run_main,
                            save_checkpoint, save_state, setup_device)
 from .pgd import PixelPGD
 from .processors import load_components
@@ -156,6 +156,9 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
     check_every = int(replica_check_every) if replica_check_every else int(save_steps)
     if world > 1:
         torch.distributed.barrier()          # model loading skews the ranks by far more than a step
+    ahead = None        # (blur sigma, crop window) of the next iteration when it was drawn ahead
+    image_draw = (use_gaussian_blur, None, use_local_crop, H, W, (crop_scale_min, crop_scale_max),
+                  (crop_ratio_min, crop_ratio_max), True)
     accumulated_loss = 0.0
     window_iterations = window_logged = 0       # of the current accumulation window: iterations seen / iterations logged
     for iteration in range(start_iteration, num_iterations):
@@ -173,10 +176,11 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
             else:
                 for ip in inputs_processors:
                     ip.set_target_text(target_text if isinstance(target_text, str) else target_text[0])
-        blur_sigma = torch.empty(1).uniform_(0.1, 2.0).item() if use_gaussian_blur else None    # Q4
-        crop = None
-        if use_local_crop:
-            crop = random_resized_crop_params(H, W, (crop_scale_min, crop_scale_max), (crop_ratio_min, crop_ratio_max))
+        if ahead is not None:
+            blur_sigma, crop = ahead               # drawn one iteration ahead, for the fused step (same values, same order)
+            ahead = None
+        else:
+            blur_sigma, crop = draw_image_params(*image_draw)                               # Q4: a sigma per step, then the window
         given = None
         if unit_noise_fn is not None:
             given = [unit_noise_fn(iteration, i, (local_batch * pl.out_shape[0],) + tuple(pl.out_shape[1:])).to(device)
@@ -196,7 +200,13 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
             (model_loss * engine.loss_scale(k)).backward()
             grads.append(pv.grad)
             losses.append(model_loss.detach())
-        stepped = engine.backward_update(grads)                                             # :391-406 (HIP)
+        rng_before, nxt = None, {}
+        if getattr(engine, "step_fusion", False) and iteration + 1 < num_iterations:
+            # as in attack_model.train: the blur chain's backward also runs the next iteration's tanh + blur
+            rng_before = torch.get_rng_state()
+            ahead = draw_image_params(*image_draw)
+            nxt = dict(next_blur_sigma=ahead[0], next_crop=ahead[1])
+        stepped = engine.backward_update(grads, **nxt)                                      # :391-406 (HIP)
         if stepped:
             global_iteration += 1
         window_iterations += 1
@@ -243,7 +253,7 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
             img = engine.image()
             pil = adv_processors[0].tensor2pil(img)
             save_checkpoint(pil, img, exp_path, global_iteration)
-            save_state(engine, exp_path, global_iteration, iteration)
+            save_state(engine, exp_path, global_iteration, iteration, torch_rng=rng_before)
         if generation_probe and (iteration % save_steps == 0 or last):                       # :475-497
             # every rank probes the model(s) it holds; with one process that is all of them, like the reference
             from .train_test import run_model_test

@@ -47,6 +47,7 @@ static int32_t fail(int32_t code, const std::string& msg) {
 // compare the specialised kernels with them bit for bit)
 static int g_generic_kernels = 0;
 static int g_pair_nt_loads = 0;
+static int g_xcd_map = 1;        // ADVX_TUNE_XCD_MAP: 0 = grids as they come (rounds 1-3), 1 = gx padded to a multiple of 8 (default)
 static int g_pair_lean = 0;      // ADVX_TUNE_PAIR_LEAN (experiment; the float32 Philox pair only)
 static int g_full_tap_rows = 0;
 static int g_separate_crop = 0;   // ADVX_TUNE_SEPARATE_CROP: 1 = never compose a crop window with stage 0; 2 = compose wherever the tables fit (tests)
@@ -54,6 +55,11 @@ static long long kRows3MinPositions = 250000;   // three channels per thread (k_
 extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
   if (what == ADVX_TUNE_RESET_ALL) {       // every switch back to its default (test fixtures' finaliser)
     g_generic_kernels = g_pair_nt_loads = g_pair_lean = g_full_tap_rows = g_separate_crop = 0;
+    g_xcd_map = 1;
+    return ADVX_OK;
+  }
+  if (what == ADVX_TUNE_XCD_MAP) {
+    g_xcd_map = value ? 1 : 0;
     return ADVX_OK;
   }
   if (what == ADVX_TUNE_GENERIC_KERNELS) {
@@ -785,7 +791,7 @@ static void emit_slices(long long n4, int batch, bool patch_layout, bool half_io
 // (blockIdx.y) of one column block runs on the XCD x % 8, so the one shared read of these launches - the canvas / v, once
 // per column block - is fetched into ONE XCD's L2 instead of up to eight (round 4, PMC: k_fused_fwd fetched 13.7 MB where
 // 2.7 MB are algorithmic at gx = 331 = 3 mod 8).  The padding blocks have no columns and return at once.
-static inline int pad_xcd(int gx) { return (gx + 7) & ~7; }
+static inline int pad_xcd(int gx) { return g_xcd_map ? ((gx + 7) & ~7) : gx; }
 static bool plan_has_patch_layout(const advx_plan* p);
 
 static bool plan_has_patch_layout(const advx_plan* p) {
@@ -1567,8 +1573,12 @@ static int32_t check_blur(int H, int W, int k, float sigma) {
 static int32_t image_fwd_impl(const float* p, const float* x0, int32_t H, int32_t W, float eps, int32_t blur_k,
                               float blur_sigma, const int32_t* crop, float* s, float* argument, float* stats,
                               float* scratch, PendingImageStats* defer, void* stream, const advx_plan* compose = nullptr,
-                              DStage* composed = nullptr) {
-  REQUIRE(p && x0 && s && stats && scratch, ADVX_E_BADARG, "advx_image_fwd: null argument");
+                              DStage* composed = nullptr, bool image_ready = false) {
+  // image_ready: advx_image_step of the previous step already ran this step's first image kernel - s, its statistics
+  // partials and the forward rows of the window's composed tables are in place; only the bookkeeping below is redone
+  REQUIRE(!image_ready || (defer && blur_k > 0 && (!crop || compose) && !g_generic_kernels), ADVX_E_UNSUPPORTED,
+          "advx_forward_multi_ready: needs blur, and a crop window only if it composes with the plan");
+  REQUIRE((image_ready || (p && x0)) && s && stats && scratch, ADVX_E_BADARG, "advx_image_fwd: null argument");
   REQUIRE(H > 0 && W > 0 && H <= 16384 && W <= 16384, ADVX_E_SHAPE, "advx_image_fwd: bad image size");
   REQUIRE(!crop || argument || compose, ADVX_E_BADARG, "advx_image_fwd: crop needs an argument buffer");
   REQUIRE(!crop || argument != s, ADVX_E_BADARG, "advx_image_fwd: with a crop, argument must not alias s");
@@ -1606,7 +1616,9 @@ static int32_t image_fwd_impl(const float* p, const float* x0, int32_t H, int32_
     }
   }
   int nblk;
-  if (blur_k > 0) {
+  if (image_ready) {
+    nblk = (int)blur_tiles(H, W);
+  } else if (blur_k > 0) {
     int32_t rc = check_blur(H, W, blur_k, blur_sigma);
     if (rc) return rc;
     // x = eps*tanh(p) is formed while the blur loads its tiles (k_blur<0, 1>): no launch, no buffer for x.
@@ -1684,12 +1696,12 @@ extern "C" int32_t advx_image_fwd(const float* p, const float* x0, int32_t H, in
 // advx_image_fwd followed by advx_emit_multi in one call: same tensors, and without a crop window the
 // statistics of the image are reduced by block (0,0) of the plans' resize launch instead of a launch
 // of their own.  The noise sigma the emits read is stats[ADVX_STAT_SIGMA] (rotated by that reduction).
-extern "C" int32_t advx_forward_multi(const float* p, const float* x0, int32_t H, int32_t W, float eps, int32_t blur_k,
-                                      float blur_sigma, const int32_t* crop, float* s, float* argument, float* stats,
-                                      float* image_scratch, int32_t n, advx_plan* const* plans, const int32_t* batches,
-                                      const float* const* unit_noises, int32_t use_philox, uint64_t seed,
-                                      const uint64_t* offsets, void* const* outs, float* const* wss,
-                                      const int64_t* ws_floats, int32_t pad_mode, void* stream) {
+static int32_t forward_multi_impl(const float* p, const float* x0, int32_t H, int32_t W, float eps, int32_t blur_k,
+                                  float blur_sigma, const int32_t* crop, float* s, float* argument, float* stats,
+                                  float* image_scratch, int32_t n, advx_plan* const* plans, const int32_t* batches,
+                                  const float* const* unit_noises, int32_t use_philox, uint64_t seed,
+                                  const uint64_t* offsets, void* const* outs, float* const* wss,
+                                  const int64_t* ws_floats, int32_t pad_mode, void* stream, bool image_ready) {
   PendingImageStats pend;
   // one plan and a crop window whose resize composes with the plan's stage 0: the window is never resized into `argument`
   // (advx_crop_composes; the backward of such a step is advx_collect_crop)
@@ -1702,7 +1714,7 @@ extern "C" int32_t advx_forward_multi(const float* p, const float* x0, int32_t H
     if (rc) return rc;
   }
   rc = image_fwd_impl(p, x0, H, W, eps, blur_k, blur_sigma, crop, s, argument, stats, image_scratch, &pend, stream,
-                      compose ? plans[0] : nullptr, compose ? &composed : nullptr);
+                      compose ? plans[0] : nullptr, compose ? &composed : nullptr, image_ready);
   if (rc) return rc;
   const float* arg = compose ? s : ((crop || (argument && argument != s)) ? argument : s);
   rc = emit_multi_impl(n, plans, arg, batches, stats + ADVX_STAT_SIGMA, unit_noises, use_philox, seed, offsets, outs, wss,
@@ -1719,6 +1731,34 @@ extern "C" int32_t advx_forward_multi(const float* p, const float* x0, int32_t H
                        pend.later.t[1]);
   }
   return rc;
+}
+
+extern "C" int32_t advx_forward_multi(const float* p, const float* x0, int32_t H, int32_t W, float eps, int32_t blur_k,
+                                      float blur_sigma, const int32_t* crop, float* s, float* argument, float* stats,
+                                      float* image_scratch, int32_t n, advx_plan* const* plans, const int32_t* batches,
+                                      const float* const* unit_noises, int32_t use_philox, uint64_t seed,
+                                      const uint64_t* offsets, void* const* outs, float* const* wss,
+                                      const int64_t* ws_floats, int32_t pad_mode, void* stream) {
+  return forward_multi_impl(p, x0, H, W, eps, blur_k, blur_sigma, crop, s, argument, stats, image_scratch, n, plans, batches,
+                            unit_noises, use_philox, seed, offsets, outs, wss, ws_floats, pad_mode, stream, false);
+}
+
+// advx_forward_multi of a step whose first image kernel already ran inside the previous step's advx_image_step: `s` holds the
+// image, the statistics partials and (with a composing crop window) the forward rows of the composed tables are in
+// image_scratch.  What remains: the plans' resizes (reducing the statistics, building the transposed rows) and the emits.
+extern "C" int32_t advx_forward_multi_ready(int32_t H, int32_t W, int32_t blur_k, const int32_t* crop, float* s, float* stats,
+                                            float* image_scratch, int32_t n, advx_plan* const* plans, const int32_t* batches,
+                                            const float* const* unit_noises, int32_t use_philox, uint64_t seed,
+                                            const uint64_t* offsets, void* const* outs, float* const* wss,
+                                            const int64_t* ws_floats, int32_t pad_mode, void* stream) {
+  REQUIRE(advx_image_step_supported(H, W, blur_k), ADVX_E_UNSUPPORTED, "advx_forward_multi_ready: no advx_image_step for this geometry");
+  if (crop) {
+    ComposeGeom cg;
+    REQUIRE(n == 1 && plans && plans[0] && compose_geom(plans[0], H, W, crop, &cg), ADVX_E_UNSUPPORTED,
+            "advx_forward_multi_ready: the crop window must compose with the (one) plan");
+  }
+  return forward_multi_impl(nullptr, nullptr, H, W, 0.0f, blur_k, 1.0f, crop, s, nullptr, stats, image_scratch, n, plans, batches,
+                            unit_noises, use_philox, seed, offsets, outs, wss, ws_floats, pad_mode, stream, true);
 }
 
 // The image-level backward behind the plans' resizes as ONE launch (advx_blur.h) when the radius is one of
@@ -1934,6 +1974,93 @@ extern "C" int32_t advx_update_flush(int64_t n, float* stats, float* update_scra
   REQUIRE(n > 0 && stats && update_scratch, ADVX_E_BADARG, "advx_update_flush: bad argument");
   hipLaunchKernelGGL(k_finalize_norm, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, reinterpret_cast<const double*>(update_scratch),
                      -1, stats);          // the number of partials is whatever the last producer left beside them
+  LAUNCH_CHECK();
+  return ADVX_OK;
+}
+
+// --------------------------------------------------------------- backward of step t + first image kernel of step t+1
+constexpr int kBlurStepMaxR = 4;     // kernel sizes 3..9 (the reference's presets: 5 and 9)
+extern "C" int32_t advx_image_step_supported(int32_t H, int32_t W, int32_t blur_k) {
+  if (g_generic_kernels || blur_k < 3 || blur_k % 2 == 0) return 0;
+  const int r = blur_k / 2;
+  if (r > kBlurStepMaxR || std::min(H, W) < kBlurTile + 3 * r + 2) return 0;      // one reflected border per pixel range
+  return blur_bwd_fusable(r, H, W) ? 1 : 0;
+}
+
+// advx_image_bwd_update (blur, no crop window: `garg` is the gradient w.r.t. the image s, as advx_collect* /
+// advx_collect_crop leave it) and the FIRST image kernel of the next step's advx_forward_multi - tanh of the updated p,
+// blur, s_next = x0 + blur, its statistics partials, the forward rows of the next crop window's composed tables - in ONE
+// launch (k_blur_step: every tile recomputes the update on its R-halo).  p, m, v are read from the step's buffers and
+// written to p_out, m_out, v_out (other buffers: the caller ping-pongs); s_next must not alias s.  The next step's
+// forward is then advx_forward_multi_ready.  Results are bit for bit those of the two calls it replaces.
+extern "C" int32_t advx_image_step(const float* p, const float* m, const float* v, float* p_out, float* m_out, float* v_out,
+                                   const float* s, const float* garg, int32_t H, int32_t W, float eps, int32_t blur_k,
+                                   float blur_sigma, float imgfit_scale, float* grad_p, const float* mask,
+                                   const advx_opt_scalars* opt, float* image_scratch, float* update_scratch, const float* x0,
+                                   float next_blur_sigma, const int32_t* next_crop, advx_plan* next_plan, float* s_next,
+                                   void* stream) {
+  REQUIRE(p && p_out && s && garg && grad_p && mask && opt && image_scratch && update_scratch && x0 && s_next, ADVX_E_BADARG,
+          "advx_image_step: null argument");
+  REQUIRE(p_out != p && s_next != s, ADVX_E_BADARG, "advx_image_step: p_out / s_next must be other buffers than p / s");
+  REQUIRE(advx_image_step_supported(H, W, blur_k), ADVX_E_UNSUPPORTED,
+          "advx_image_step: kernel sizes 3..9 on images of at least 32 + 3r + 2 pixels per side");
+  int32_t rc = check_opt(opt, m, v);
+  if (rc) return rc;
+  REQUIRE(opt->apply, ADVX_E_UNSUPPORTED, "advx_image_step always steps (accumulation windows take the two calls)");
+  REQUIRE(opt->kind != ADVX_OPT_ADAMW || (m_out && v_out && m_out != m && v_out != v), ADVX_E_BADARG,
+          "advx_image_step: AdamW needs m_out / v_out (other buffers than m / v)");
+  rc = check_blur(H, W, blur_k, blur_sigma);
+  if (rc) return rc;
+  rc = check_blur(H, W, blur_k, next_blur_sigma);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = 3LL * H * W;
+  const float c_fit = imgfit_scale / (float)n;
+  Bump b{image_scratch};
+  double* img_partials = reinterpret_cast<double*>(b.take(partial_floats(H, W)));     // where advx_forward_multi looks for them
+  tables_forget(b.base + b.used);
+  TapBuild taps[2];
+  std::memset(taps, 0, sizeof(taps));
+  int tap_blocks = 0;
+  if (next_crop) {
+    ComposeGeom cg;
+    REQUIRE(next_plan && compose_geom(next_plan, H, W, next_crop, &cg), ADVX_E_UNSUPPORTED,
+            "advx_image_step: the next crop window must compose with the plan (advx_crop_composes)");
+    rc = advx_plan_upload(next_plan, stream);
+    if (rc) return rc;
+    DStage unused;
+    PendingTables pending;       // never committed here: the transposed rows are built by the next forward's launches
+    rc = build_composed_stage(next_plan, H, W, next_crop, b, st, &unused, false, taps, &pending);
+    if (rc) return rc;
+    for (int ax = 0; ax < 2; ++ax) taps[ax].row_hi = taps[ax].out_size;                // forward rows only
+    tap_blocks = (std::max(taps[0].out_size, taps[1].out_size) + kBlock - 1) / kBlock;
+  }
+  dim3 grid((W + kBlurTile - 1) / kBlurTile, (H + kBlurTile - 1) / kBlurTile, 3);
+  int riding = 0;
+  if (tap_blocks > 0) {
+    if ((long long)grid.x * grid.y >= 2LL * tap_blocks) {
+      riding = tap_blocks;
+      grid.z = 4;
+    } else {
+      hipLaunchKernelGGL(k_build_taps, dim3(tap_blocks, 2), dim3(kBlock), 0, st, taps[0], taps[1]);
+      LAUNCH_CHECK();
+    }
+  }
+  TapBuild none;
+  std::memset(&none, 0, sizeof(none));
+  double* norm_partials = reinterpret_cast<double*>(update_scratch);
+  const OptScalars o = to_dev(opt);
+#define ADVX_STEP_R(R_)                                                                                                     \
+  hipLaunchKernelGGL((k_blur_step<R_>), grid, dim3(kBlock), 0, st, garg, s, H, W, blur_sigma, eps, c_fit, p, m, v, p_out, m_out, \
+                     v_out, grad_p, mask, o, norm_partials, x0, next_blur_sigma, s_next, img_partials, riding ? taps[0] : none,  \
+                     riding ? taps[1] : none, riding)
+  switch (blur_k / 2) {
+    case 1: ADVX_STEP_R(1); break;
+    case 2: ADVX_STEP_R(2); break;
+    case 3: ADVX_STEP_R(3); break;
+    default: ADVX_STEP_R(4); break;
+  }
+#undef ADVX_STEP_R
   LAUNCH_CHECK();
   return ADVX_OK;
 }

@@ -205,14 +205,18 @@ def emit_multi(plans, argument, batches, sigma_dev=None, unit_noises=None, philo
 
 
 def forward_multi(p, x0, epsilon, stats, image_scratch, plans, batches, s, argument=None, blur=None, crop=None,
-                  unit_noises=None, philox=None, workspaces=None, outs=None, keep_padding=False):
+                  unit_noises=None, philox=None, workspaces=None, outs=None, keep_padding=False, image_ready=False):
     """image_fwd + emit_multi in one call (advx_forward_multi).  -> (list of pixel_values, argument).
 
     The returned `argument` is what the plans read: `s` without a crop window, the window resized back to H x W with one.
     COMPOSED CROP: with ONE plan and a window for which `crop_composes(plan, H, W, crop)` holds, the library applies the
     window's resize and the plan's own as one table (include/advx.h "Composed crop") and the resized window is never formed:
     the second return value is then None (a buffer passed as `argument` is left untouched), and the backward of that step is
-    `collect_crop` + `image_bwd*` WITHOUT a crop window."""
+    `collect_crop` + `image_bwd*` WITHOUT a crop window.
+
+    image_ready=True (advx_forward_multi_ready): the previous step's `image_step` already ran this step's first image kernel -
+    `s` holds the image, its statistics partials and the composed tables' forward rows are in `image_scratch`; only the
+    plans' resizes and the emits are launched.  Needs blur, and a crop window only if it composes."""
     _require_cuda(p, x0, stats, image_scratch, s)
     dev = p.device
     _, H, W = p.shape
@@ -235,6 +239,17 @@ def forward_multi(p, x0, epsilon, stats, image_scratch, plans, batches, s, argum
         if z is not None and z.numel() != B * pl.out_numel:
             raise L.AdvxError("unit_noise has the wrong number of elements")
     seed, offsets = (philox if philox is not None else (0, [0] * n))
+    if image_ready:
+        if crop is not None and not composed:
+            raise L.AdvxError("forward_multi(image_ready=True): the crop window must compose with the plan")
+        L.check(L.load().advx_forward_multi_ready(H, W, int(k), cptr, L.ptr(s), L.ptr(stats), L.ptr(image_scratch), n,
+                                                  (C.c_void_p * n)(*[pl.handle.value for pl in plans]),
+                                                  (C.c_int32 * n)(*[int(b) for b in batches]), _ptr_array(zs),
+                                                  int(philox is not None), int(seed), (C.c_uint64 * n)(*[int(o) for o in offsets]),
+                                                  _ptr_array(outs), _ptr_array(workspaces),
+                                                  (C.c_int64 * n)(*[int(w.numel()) for w in workspaces]),
+                                                  1 if keep_padding else 0, _stream(s)), "advx_forward_multi_ready")
+        return outs, (None if composed else s)
     L.check(L.load().advx_forward_multi(L.ptr(p), L.ptr(x0), H, W, float(epsilon), int(k), float(sig), cptr, L.ptr(s),
                                         L.ptr(argument) if argument is not None else None, L.ptr(stats), L.ptr(image_scratch),
                                         n, (C.c_void_p * n)(*[pl.handle.value for pl in plans]),
@@ -332,6 +347,27 @@ def image_bwd_update(p, s, grad_argument, epsilon, imgfit_scale, grad_p, mask, m
                                            L.ptr(m), L.ptr(v), C.byref(opt), L.ptr(stats), L.ptr(image_scratch),
                                            L.ptr(update_scratch), int(bool(finalize_norm)), _stream(p)), "advx_image_bwd_update")
     return grad_p
+
+
+def image_step_supported(H, W, blur_kernel):
+    return bool(blur_kernel) and bool(L.load().advx_image_step_supported(int(H), int(W), int(blur_kernel)))
+
+
+def image_step(p, m, v, p_out, m_out, v_out, s, grad_s, epsilon, imgfit_scale, grad_p, mask, opt, image_scratch, update_scratch,
+               x0, s_next, blur, next_blur_sigma, next_crop=None, next_plan=None):
+    """Backward + update of step t and the first image kernel of step t+1 in ONE launch (advx_image_step): `grad_s` is the
+    gradient w.r.t. the image s (collect / collect_crop); p, m, v -> p_out, m_out, v_out (other buffers), s_next another buffer
+    than s.  The next forward is forward_multi(..., image_ready=True) with the same blur kernel size, `next_crop` and plans."""
+    _require_cuda(p, p_out, s, grad_s, grad_p, mask, image_scratch, update_scratch, x0, s_next)
+    _, H, W = p.shape
+    k, sig = blur
+    keep, cptr = _crop_arg(next_crop)
+    L.check(L.load().advx_image_step(L.ptr(p), L.ptr(m), L.ptr(v), L.ptr(p_out), L.ptr(m_out), L.ptr(v_out), L.ptr(s),
+                                     L.ptr(_f32c(grad_s)), H, W, float(epsilon), int(k), float(sig), float(imgfit_scale),
+                                     L.ptr(grad_p), L.ptr(mask), C.byref(opt), L.ptr(image_scratch), L.ptr(update_scratch),
+                                     L.ptr(x0), float(next_blur_sigma), cptr,
+                                     next_plan.handle if (next_plan is not None and next_crop is not None) else None,
+                                     L.ptr(s_next), _stream(p)), "advx_image_step")
 
 
 def update_flush(n, stats, update_scratch):

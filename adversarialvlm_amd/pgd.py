@@ -167,6 +167,14 @@ class PixelPGD:
             self.workspaces = [torch.empty(pl.workspace_floats, dtype=torch.float32, device=dev) for pl in self.plans]
             self.noise_on_padding = bool(noise_on_padding)
             self._outs = [None] * len(self.plans)     # persistent pixel_values (noise_on_padding=False)
+            # step-to-step fusion of the blur chains (advx_image_step): the backward of step t also runs the first image
+            # kernel of step t+1 when the caller names that step's blur sigma / crop window (backward_update(next_...)).
+            # p, m, v and s are double-buffered for it: a tile recomputes its halo from the OLD state.
+            self.step_fusion = bool(self.mode == "generic" and blur_kernel is not None and not self.exchange
+                                    and self.accum == 1 and ops.image_step_supported(H, W, blur_kernel))
+            if self.step_fusion:
+                self._alt = dict(p=torch.zeros_like(self.x0), m=torch.zeros_like(self.x0), v=torch.zeros_like(self.x0),
+                                 s=torch.empty_like(self.x0))
             if self.mode == "prepared":
                 self.prep_scratch = ops.prepared_scratch(self.plans[0], dev)
                 self.rows_prepare, self.rows_bwd = ops.prepared_rows(self.plans[0])
@@ -176,6 +184,7 @@ class PixelPGD:
                 self.rows_in = 0
                 self.prepared = False
         self._last = None
+        self._next_ready = None        # (blur sigma, crop window) of a forward whose image kernel already ran (image_step)
         for pl in self.plans:
             pl.upload()
 
@@ -304,10 +313,16 @@ class PixelPGD:
                     self._outs[i] = torch.zeros((B, pl.out_numel), dtype=ops._plan_dtype(pl), device=self.p.device)
             bufs = self._outs
         ph = None if (given or not use_philox) else (self.seed, [self.iteration * n + i for i in range(n)])
+        ready, self._next_ready = self._next_ready, None
+        crop_key = None if crop is None else tuple(int(c) for c in crop)
+        image_ready = bool(ready is not None and blur is not None and ready == (float(blur[1]), crop_key))
+        if image_ready:
+            # the previous backward_update already ran this step's image kernel into the other image buffer
+            self.s, self._alt["s"] = self._alt["s"], self.s
         res, _ = ops.forward_multi(self.p, self.x0, self.eps, self.stats, self.img_scratch, self.plans, batches, self.s,
                                    argument=self.argument if crop is not None else None, blur=blur, crop=crop,
                                    unit_noises=unit_noises if given else None, philox=ph, workspaces=self.workspaces,
-                                   outs=bufs, keep_padding=keep)
+                                   outs=bufs, keep_padding=keep, image_ready=image_ready)
         outs = [o.view((B * pl.out_shape[0],) + pl.out_shape[1:]) for o, pl, B in zip(res, self.plans, batches)]
         # one plan and a window that composes with its stage 0: the library applied both resizes as one table
         # (include/advx.h "Composed crop") - the backward then goes canvas -> image in one gather
@@ -316,11 +331,15 @@ class PixelPGD:
         return outs
 
     # ----------------------------------------------------------------- backward
-    def backward_update(self, grads, next_unit_noise=None, next_batch=None, use_philox=True):
+    def backward_update(self, grads, next_unit_noise=None, next_batch=None, use_philox=True, next_blur_sigma=None,
+                        next_crop=None):
         """grads[i] = d(loss)/d(pixel_values_i) as produced by autograd with the loss already
         multiplied by loss_scale(i).  In the one-launch `step` chain the same kernel emits the
         pixel_values of the NEXT step: `next_unit_noise` (parity mode) / Philox noise and
-        `next_batch` (default: same batch) describe that emission."""
+        `next_batch` (default: same batch) describe that emission.
+        next_blur_sigma (and next_crop, for an engine built with use_crop): what the NEXT forward() will be called with.  A
+        blur engine on one rank (`self.step_fusion`) then runs that forward's image kernel inside this call's last launch
+        (advx_image_step); a next forward() with other arguments simply recomputes.  Same bits either way."""
         if not isinstance(grads, (list, tuple)):
             grads = [grads]
         st = self._last
@@ -399,6 +418,25 @@ class PixelPGD:
             else:
                 pl, g, B = self.plans[0], grads[0], st["batches"][0]
                 ops.collect(pl, g.reshape(B, pl.out_numel), B, grad_argument=self.garg, workspace=self.workspaces[0])
+            nxt_crop = None if next_crop is None else tuple(int(c) for c in next_crop)
+            if (getattr(self, "step_fusion", False) and take_step and not accumulate and next_blur_sigma is not None
+                    and st["blur"] is not None and st["crop"] is None and (nxt_crop is not None) == self.use_crop
+                    and (nxt_crop is None or (len(self.plans) == 1 and ops.crop_composes(self.plans[0], self.H, self.W, nxt_crop)))):
+                # blur^T, update AND the next step's tanh + blur in one launch (every tile recomputes its halo); the state
+                # goes to the other buffers
+                a = self._alt
+                ops.image_step(self.p, self.m, self.v, a["p"], a["m"], a["v"], self.s, self.garg, self.eps, self.imgfit_scale(),
+                               self.grad, self.mask, opt, self.img_scratch, self.upd_scratch, self.x0, a["s"], st["blur"],
+                               float(next_blur_sigma), next_crop=nxt_crop, next_plan=self.plans[0] if nxt_crop is not None else None)
+                self.p, a["p"] = a["p"], self.p
+                self.m, a["m"] = a["m"], self.m
+                self.v, a["v"] = a["v"], self.v
+                self._next_ready = (float(next_blur_sigma), nxt_crop)      # self.s stays the image of THIS step until then
+                self._norm_pending = True
+                self._scheduler_step()
+                self.iteration += 1
+                self._last = None
+                return take_step
             if not (self.exchange and take_step):
                 # nothing between the image-level backward and the optimiser: one call, the tanh backward
                 # (and the crop's transposed resize) inside the optimiser's launch
@@ -525,6 +563,7 @@ class PixelPGD:
             getattr(self, k).copy_(sd[k].to(self.p.device))
         self.lr, self.opt_steps, self.iteration = float(sd["lr"]), int(sd["opt_steps"]), int(sd["iteration"])
         self._norm_pending = False                 # the loaded statistics are complete
+        self._next_ready = None                    # nothing of the next forward has run on the loaded state
         # the noise seed is NOT taken from the file: under data parallelism only rank 0 writes it, and every
         # rank keeps the stream it was constructed with (seed + 7919 * rank in the trainers)
         if self.fused:

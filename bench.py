@@ -279,6 +279,7 @@ def main():
     ap.add_argument("--e2e-steps", type=int, default=2)
     ap.add_argument("--e2e-image", type=int, default=H)
     ap.add_argument("--nt-loads", action="store_true", help="experiment: the pair's backward reads grad_out non-temporally")
+    ap.add_argument("--no-xcd-pad", action="store_true", help="experiment: grids as in rounds 1-3 (gx not padded to a multiple of 8)")
     ap.add_argument("--lean", action="store_true", help="experiment: the pair without the s / v / grad_p streams (ADVX_TUNE_PAIR_LEAN)")
     args = ap.parse_args()
     io_dtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.io]
@@ -333,6 +334,9 @@ def main():
     if args.nt_loads:
         from adversarialvlm_amd import _lib
         _lib.check(_lib.load().advx_set_tuning(2, 1), "advx_set_tuning")
+    if args.no_xcd_pad:
+        from adversarialvlm_amd import _lib
+        _lib.check(_lib.load().advx_set_tuning(6, 0), "advx_set_tuning")
     if args.lean:
         from adversarialvlm_amd import _lib
         _lib.check(_lib.load().advx_set_tuning(5, 1), "advx_set_tuning")

@@ -122,6 +122,8 @@ const char* advx_last_error(void);
 #define ADVX_TUNE_GENERIC_KERNELS 1
 #define ADVX_TUNE_PAIR_LEAN 5       /* experiment (round 4): the float32 Philox pair re-derives s, v in the forward; the backward stores neither
                                      them nor grad_p - measured, not the default */
+#define ADVX_TUNE_XCD_MAP 6         /* 1 (default): the grids of the B x P_out writers have gx padded to a multiple of 8, so that all batch
+                                     slices of a column block run on one XCD (one L2 fetches the shared canvas / v); 0: rounds 1-3 */
 #define ADVX_TUNE_PAIR_NT_LOADS 2   /* advx_fused_bwd reads grad_out with non-temporal loads (same results) */
 #define ADVX_TUNE_SEPARATE_CROP 4   /* 1: never compose a crop window with a plan's stage 0 (advx_forward_multi) - the window is resized
                                      * into `argument` and the plan resamples that, two launches each way, bit-identical to the
@@ -309,6 +311,35 @@ int32_t advx_image_bwd_update(float* p, const float* s, const float* grad_argume
  * k-th step skips the one-block reduction on the others. */
 int32_t advx_update_flush(int64_t n, float* stats, float* update_scratch, void* stream);
 int64_t advx_update_scratch_floats(int64_t n);
+
+/* ------------------------------------------- step-to-step fusion of the blur chains (round 4)
+ * The reference's production presets blur every step (attack_clamp_tanh_llava_gblur.sh:24-60: kernel 9, a crop window
+ * per step).  advx_image_step is advx_image_bwd_update of step t (blur, `grad_argument` = gradient w.r.t. the image s, as
+ * advx_collect* / advx_collect_crop leave it; no crop window here) AND the first image kernel of step t+1's
+ * advx_forward_multi - eps*tanh of the UPDATED p, blur with next_blur_sigma, s_next = x0 + blur, its statistics partials,
+ * and with next_crop_ijhw the forward rows of (window o next_plan's stage 0) - in ONE launch: every 32 x 32 tile recomputes
+ * the gradient and the optimiser update on its r-halo (same inputs, same order: the owner's bits), only the owner stores.
+ * attack_model.py:300-304 of iteration t+1 thereby move behind :335-346 of iteration t; the values do not change.
+ *   p, m, v      : state of step t (read only);  p_out, m_out, v_out : state of step t+1 - OTHER buffers (a neighbouring tile
+ *                  must read the old p whenever the owner's block runs); the caller ping-pongs.  m / v may be NULL for ADVX_OPT_SIGN.
+ *   s            : image of step t (read, with halos);  s_next : image of step t+1, another buffer.
+ *   next_crop_ijhw / next_plan : NULL, or a window with advx_crop_composes(next_plan, H, W, window) == 1.
+ * Supported (advx_image_step_supported): odd kernel sizes 3..9, min(H, W) >= 32 + 3r + 2, opt->apply == 1.
+ * The next forward is advx_forward_multi_ready (same H, W, blur_kernel, window, plans, image_scratch): the plans' resizes -
+ * which also reduce the statistics and build the composed tables' transposed rows - and the emits; `s` = s_next above.
+ * Bit for bit the results of advx_image_bwd_update + advx_forward_multi. */
+int32_t advx_image_step_supported(int32_t H, int32_t W, int32_t blur_kernel);
+int32_t advx_image_step(const float* p, const float* m, const float* v, float* p_out, float* m_out, float* v_out,
+                        const float* s, const float* grad_argument, int32_t H, int32_t W, float epsilon,
+                        int32_t blur_kernel, float blur_sigma, float imgfit_scale, float* p_grad, const float* mask,
+                        const advx_opt_scalars* opt, float* image_scratch, float* update_scratch, const float* x0,
+                        float next_blur_sigma, const int32_t* next_crop_ijhw, advx_plan* next_plan, float* s_next,
+                        void* stream);
+int32_t advx_forward_multi_ready(int32_t H, int32_t W, int32_t blur_kernel, const int32_t* crop_ijhw, float* s, float* stats,
+                                 float* image_scratch, int32_t n, advx_plan* const* plans, const int32_t* batches,
+                                 const float* const* unit_noises, int32_t use_philox, uint64_t seed,
+                                 const uint64_t* offsets, void* const* outs, float* const* workspaces,
+                                 const int64_t* workspace_floats, int32_t pad_mode, void* stream);
 
 /* ------------------------------------------- fused fast path (headline config)
  * The whole owned step of attack_model.py:300-346,366-373 for a plan whose resize is the

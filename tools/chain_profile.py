@@ -42,7 +42,8 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         eng.forward(B, blur_sigma=sig, crop=crop)
-        eng.backward_update(gs)
+        # the trainers announce the next step's blur sigma / window: a blur chain then takes advx_image_step (ADVX_NO_ANNOUNCE=1: rounds 1-3)
+        eng.backward_update(gs, **(dict(next_blur_sigma=sig, next_crop=crop) if (sig and not os.environ.get("ADVX_NO_ANNOUNCE")) else {}))
     torch.cuda.synchronize()
     print(f"{which} {chain}: {(time.perf_counter() - t0) / 50 * 1e6:.1f} us/step (wall, 50 steps)")
 

@@ -12,7 +12,8 @@ from adversarialvlm_amd.pgd import PixelPGD  # noqa: E402
 from adversarialvlm_amd.plan import Plan  # noqa: E402
 
 
-def run(name, plans, H, W, B, blur=None, crop=None, steps=50, cross=False, pad_noise=True, prepared=False, io=torch.float32):
+def run(name, plans, H, W, B, blur=None, crop=None, steps=50, cross=False, pad_noise=True, prepared=False, io=torch.float32,
+        announce=True):
     dev = torch.device("cuda:0")
     x0 = torch.rand(3, H, W, device=dev)
     eng = PixelPGD(x0, plans, blur_kernel=blur, use_crop=crop is not None, cross_mode=cross, allow_fused=prepared,
@@ -20,9 +21,15 @@ def run(name, plans, H, W, B, blur=None, crop=None, steps=50, cross=False, pad_n
     name = f"{name} [{eng.mode}{'' if io == torch.float32 else ', ' + str(io).split('.')[-1]}]"
     gs = [torch.randn(B, pl.out_numel, device=dev).to(io) for pl in plans]
 
+    # announce: tell backward_update the next step's blur sigma / window (the trainers do): a blur chain on one rank then runs
+    # the next step's image kernel inside the backward's last launch (advx_image_step)
+    nxt = dict(next_blur_sigma=7.0, next_crop=crop) if (blur and announce) else {}
+    if blur:
+        name += " [step fusion]" if (nxt and getattr(eng, "step_fusion", False)) else " [no step fusion]"
+
     def step():
         eng.forward(B, blur_sigma=7.0 if blur else None, crop=crop)
-        eng.backward_update(gs)
+        eng.backward_update(gs, **nxt)
     for _ in range(5):
         step()
     torch.cuda.synchronize()
@@ -48,7 +55,12 @@ if __name__ == "__main__":
     run("llava 336 identity (generic)", [Plan.llava(336, 336)], 336, 336, 64)
     run("llava 512->336", [Plan.llava(512, 512)], 512, 512, 64)
     run("llava 512->336", [Plan.llava(512, 512)], 512, 512, 64, prepared=True)
+    run("llava 512->336 blur9 crop", [Plan.llava(512, 512)], 512, 512, 64, blur=9, crop=(20, 30, 400, 420), announce=False)
     run("llava 512->336 blur9 crop", [Plan.llava(512, 512)], 512, 512, 64, blur=9, crop=(20, 30, 400, 420))
+    run("llava 512->336 blur9", [Plan.llava(512, 512)], 512, 512, 64, blur=9, announce=False)
+    run("llava 512->336 blur9", [Plan.llava(512, 512)], 512, 512, 64, blur=9)
+    run("llava 336 blur5 crop", [Plan.llava(336, 336)], 336, 336, 64, blur=5, crop=(20, 30, 280, 300), announce=False)
+    run("llava 336 blur5 crop", [Plan.llava(336, 336)], 336, 336, 64, blur=5, crop=(20, 30, 280, 300))
     run("mllama 336 (4x560 tiles)", [Plan.mllama(336, 336)], 336, 336, 64)
     run("mllama 336, padding kept zero", [Plan.mllama(336, 336)], 336, 336, 64, pad_noise=False)
     run("mllama 336 (4x560 tiles)", [Plan.mllama(336, 336)], 336, 336, 64, prepared=True)
@@ -65,6 +77,8 @@ if __name__ == "__main__":
     run("phi3 512", [Plan.phi3(512, 512)], 512, 512, 64, prepared=True, io=torch.float16)
     run("qwen2vl 512", [Plan.qwen2vl(512, 512)], 512, 512, 64, prepared=True, io=torch.bfloat16)
     run("llava 512->336", [Plan.llava(512, 512)], 512, 512, 64, prepared=True, io=torch.float16)
+    run("cross phi3+qwen+mllama 336 blur5", [Plan.phi3(336, 336), Plan.qwen2vl(336, 336), Plan.mllama(336, 336)], 336, 336,
+        16, blur=5, cross=True, announce=False)
     run("cross phi3+qwen+mllama 336 blur5", [Plan.phi3(336, 336), Plan.qwen2vl(336, 336), Plan.mllama(336, 336)], 336, 336,
         16, blur=5, cross=True)
     run("cross, padding kept zero", [Plan.phi3(336, 336), Plan.qwen2vl(336, 336), Plan.mllama(336, 336)], 336, 336,
