@@ -208,7 +208,7 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
           use_wandb=False, seed=0, base_path="./runs", components=None, return_engine=False,
           generation_probe=False, resume_from=None, pixel_io="float32", resaved_loss_every=0,
           noise_on_padding=True, suffix_only_ce=False, replica_check_every=None, exchange_transport="auto",
-          exchange_timeout_s=EXCHANGE_TIMEOUT_S, unit_noise_fn=None):
+          exchange_timeout_s=EXCHANGE_TIMEOUT_S, unit_noise_fn=None, step_fusion=False):
     """pixel_io: "float32" hands the VLM fp32 pixel_values as the reference does; "model" lets
     the fused pair write them in model.dtype (the cast the vision tower's patch embedding applies
     first anyway) and read the half gradient directly - same numbers, half the traffic.
@@ -271,7 +271,7 @@ def train(exp_name, img_orig, prompt, target_text, model_name, lr, num_iteration
     # pick by the batch size of THIS call
     chain = saved_chain(resume_from)
     engine = PixelPGD(x_0, [plan], epsilon=epsilon, lr=lr, sigma0=sigma, mask=mask,
-                      fused_mode=chain if chain in ("pair", "step", "prepared") else "auto",
+                      fused_mode=chain if chain in ("pair", "step", "prepared") else "auto", step_fusion=step_fusion,
                       scheduler_step_size=scheduler_step_size, scheduler_gamma=scheduler_gamma,
                       grad_accum_steps=grad_accum_steps, blur_kernel=gblur_kernel_size if use_gaussian_blur else None,
                       use_crop=use_local_crop, optimizer=optimizer, seed=seed + 7919 * rank,
@@ -466,6 +466,9 @@ def build_parser():
                         "the HIP library: same loss, no [B, S, V] logits tensor")
     p.add_argument("--pixel_io", type=str, default="float32", choices=["float32", "model"],
                    help="dtype of pixel_values at the VLM boundary (model = the VLM's own half dtype)")
+    p.add_argument("--step_fusion", action="store_true",
+                   help="blur runs on one rank: the backward's last launch also runs the next iteration's tanh + blur "
+                        "(advx_image_step; same bits; not faster on MI355X, hence off by default)")
     add_dp_arguments(p)
     return p
 

@@ -49,7 +49,8 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
           questions_file=None, test_questions_file=None, answers_file=None, log_every=1, use_wandb=False, seed=0,
           base_path="./runs", return_engine=False, resaved_loss_every=0, noise_on_padding=True,
           suffix_only_ce=False, pixel_io="float32", components=None, generation_probe=False, resume_from=None,
-          replica_check_every=None, exchange_transport="auto", exchange_timeout_s=EXCHANGE_TIMEOUT_S, unit_noise_fn=None):
+          replica_check_every=None, exchange_transport="auto", exchange_timeout_s=EXCHANGE_TIMEOUT_S, unit_noise_fn=None,
+          step_fusion=False):
     """components: optional {model_name: (load_model_and_processor, AdvInputs, DiffProc)} overriding the registry
     (tests).  generation_probe / resume_from / replica_check_every: as in attack_model.train.
     unit_noise_fn (parity tests): callable(iteration, model index, shape) -> N(0, 1) draws on the CPU that replace the in-kernel
@@ -138,7 +139,7 @@ def train(exp_name, img_orig, prompt, target_text, model_names, lr, num_iteratio
                       seed=seed + 7919 * rank, allow_fused=(len(plans) == 1),   # one model on this rank: pipelined chains
                       process_group=torch.distributed.group.WORLD if world > 1 else None, grad_prescale=prescale,
                       noise_on_padding=noise_on_padding, exchange_transport=exchange_transport,
-                      exchange_timeout_s=exchange_timeout_s)
+                      exchange_timeout_s=exchange_timeout_s, step_fusion=step_fusion)
     if pixel_io == "model":
         # every model receives pixel_values in its own dtype (Qwen2-VL runs bf16, the others fp16)
         from .ops import IO_DTYPES
@@ -323,6 +324,8 @@ def build_parser():
                    help="keep the constant padding tiles of Mllama / Phi-3.5 exact zeros (the reference adds noise there)")
     p.add_argument("--pixel_io", type=str, default="float32", choices=["float32", "model"],
                    help="dtype of pixel_values at each VLM's boundary (model = that VLM's own half dtype)")
+    p.add_argument("--step_fusion", action="store_true",
+                   help="blur runs on one rank: the backward's last launch also runs the next iteration's tanh + blur (advx_image_step)")
     p.add_argument("--suffix_only_ce", action="store_true",
                    help="logits of the target positions only (logits_to_keep) + HIP cross entropy: same loss, no [B,S,V] tensor")
     p.add_argument("--resaved_loss_every", type=int, default=0,

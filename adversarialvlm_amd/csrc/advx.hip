@@ -47,7 +47,7 @@ static int32_t fail(int32_t code, const std::string& msg) {
 // compare the specialised kernels with them bit for bit)
 static int g_generic_kernels = 0;
 static int g_pair_nt_loads = 0;
-static int g_xcd_map = 1;        // ADVX_TUNE_XCD_MAP: 0 = grids as they come (rounds 1-3), 1 = gx padded to a multiple of 8 (default)
+static int g_xcd_map = 2;        // ADVX_TUNE_XCD_MAP: 0 = grids as they come (rounds 1-3), 1 = gx padded to a multiple of 8, 2 = padded + a contiguous range of column blocks per XCD
 static int g_pair_lean = 0;      // ADVX_TUNE_PAIR_LEAN (experiment; the float32 Philox pair only)
 static int g_full_tap_rows = 0;
 static int g_separate_crop = 0;   // ADVX_TUNE_SEPARATE_CROP: 1 = never compose a crop window with stage 0; 2 = compose wherever the tables fit (tests)
@@ -55,11 +55,11 @@ static long long kRows3MinPositions = 250000;   // three channels per thread (k_
 extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
   if (what == ADVX_TUNE_RESET_ALL) {       // every switch back to its default (test fixtures' finaliser)
     g_generic_kernels = g_pair_nt_loads = g_pair_lean = g_full_tap_rows = g_separate_crop = 0;
-    g_xcd_map = 1;
+    g_xcd_map = 2;
     return ADVX_OK;
   }
   if (what == ADVX_TUNE_XCD_MAP) {
-    g_xcd_map = value ? 1 : 0;
+    g_xcd_map = (value == 2) ? 2 : (value ? 1 : 0);
     return ADVX_OK;
   }
   if (what == ADVX_TUNE_GENERIC_KERNELS) {
@@ -863,7 +863,7 @@ extern "C" int32_t advx_emit_ex(advx_plan* p, const float* argument, int32_t bat
   dim3 grid(pad_xcd(gx), slices);
 #define ADVX_EMIT_T(N, T)                                                                                           \
   hipLaunchKernelGGL((k_emit<N, T>), grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, \
-                     offset, (void*)out, q_lo, q_hi, live_lo, live_hi, no_rider())
+                     offset, (void*)out, q_lo, q_hi, live_lo, live_hi, no_rider(), g_xcd_map)
 #define ADVX_EMIT(N) \
   do { if (p->io == 0) ADVX_EMIT_T(N, 0); else if (p->io == 1) ADVX_EMIT_T(N, 1); else ADVX_EMIT_T(N, 2); } while (0)
   if (noise == 0) ADVX_EMIT(0); else if (noise == 1) ADVX_EMIT(1); else ADVX_EMIT(2);
@@ -1184,7 +1184,7 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
     const TapRider ride_i = (i == 0) ? rider : no_rider();
 #define ADVX_EMIT_T(N, T)                                                                                                 \
   hipLaunchKernelGGL((k_emit<N, T>), grid, dim3(kBlock), 0, st, p->dplan, a.ws, a.batch, a.b_per_slice, sigma_dev, a.unit_noise, \
-                     seed, a.offset, a.out, a.q_lo, a.q_hi, a.live_lo, a.live_hi, ride_i)
+                     seed, a.offset, a.out, a.q_lo, a.q_hi, a.live_lo, a.live_hi, ride_i, g_xcd_map)
 #define ADVX_EMIT(N) \
   do { if (p->io == 0) ADVX_EMIT_T(N, 0); else if (p->io == 1) ADVX_EMIT_T(N, 1); else ADVX_EMIT_T(N, 2); } while (0)
     if (noise == 0) ADVX_EMIT(0); else if (noise == 1) ADVX_EMIT(1); else ADVX_EMIT(2);
@@ -2161,14 +2161,14 @@ static int32_t fused_fwd_impl(advx_plan* p, const float* pp, const float* x0, fl
 #define ADVX_FF_S(N, T, S)                                                                                       \
   ADVX_LAUNCH_TIMED(PROF_FWD, (k_fused_fwd<N, T, S>), grid, dim3(kBlock), st, (const float*)v_buf, (const float*)s_buf, x0, n, \
                     batch, bps, stats, unit_noise, seed, offset, out, f.hdr, f.img_rows[parity],                  \
-                    (const double*)f.norm_partials, sched, eps, fused_geom(p))
+                    (const double*)f.norm_partials, sched, eps, fused_geom(p), g_xcd_map)
 #define ADVX_FF(N, T) do { if (sched) ADVX_FF_S(N, T, true); else ADVX_FF_S(N, T, false); } while (0)
 #define ADVX_FF_IO(N) \
   do { if (io == 0) ADVX_FF(N, 0); else if (io == 1) ADVX_FF(N, 1); else ADVX_FF(N, 2); } while (0)
   if (g_pair_lean && noise == 2 && io == 0 && !sched && prepared) {
     ADVX_LAUNCH_TIMED(PROF_FWD, (k_fused_fwd<2, 0, false, true>), grid, dim3(kBlock), st, pp, (const float*)s_buf, x0, n, batch, bps,
                       stats, unit_noise, seed, offset, out, f.hdr, f.img_rows[parity], (const double*)f.norm_partials, sched, eps,
-                      fused_geom(p));
+                      fused_geom(p), g_xcd_map);
   } else if (noise == 0) ADVX_FF_IO(0); else if (noise == 1) ADVX_FF_IO(1); else if (noise == 2) ADVX_FF_IO(2);
   else ADVX_FF_S(3, 0, false);      // float32 boundary only, like the chain it serves
 #undef ADVX_FF_IO
@@ -2811,7 +2811,7 @@ extern "C" int32_t advx_prepared_fwd(advx_plan* p, const float* pp, const float*
   const float* sigma_dev = stats + ADVX_STAT_QERR_STD;   // quantise error of the PREVIOUS image (not yet rotated)
 #define ADVX_EMIT_T(N, T)                                                                                           \
   hipLaunchKernelGGL((k_emit<N, T>), grid, dim3(kBlock), 0, st, p->dplan, ws, batch, bps, sigma_dev, unit_noise, seed, \
-                     offset, (void*)out, q_lo, q_hi, live_lo, live_hi, no_rider())
+                     offset, (void*)out, q_lo, q_hi, live_lo, live_hi, no_rider(), g_xcd_map)
 #define ADVX_EMIT(N) \
   do { if (p->io == 0) ADVX_EMIT_T(N, 0); else if (p->io == 1) ADVX_EMIT_T(N, 1); else ADVX_EMIT_T(N, 2); } while (0)
   if (noise == 0) ADVX_EMIT(0); else if (noise == 1) ADVX_EMIT(1); else ADVX_EMIT(2);

@@ -889,6 +889,17 @@ __device__ inline void io_store4(void* __restrict__ base, size_t idx, float4 v) 
   __builtin_nontemporal_store(packed, reinterpret_cast<u2v*>(reinterpret_cast<unsigned short*>(base) + idx));
 }
 
+// XCD-aware column blocks (ADVX_TUNE_XCD_MAP = 2).  Workgroups are dealt round-robin over the 8 XCDs by linear id; with gridDim.x
+// a multiple of 8, physical block bx runs on XCD bx % 8 whatever blockIdx.y is.  Mode 2 hands XCD k the CONTIGUOUS range of
+// column blocks [k*per, (k+1)*per): all batch slices of a column block still share one XCD (one L2 fetches the shared v /
+// canvas), and every XCD's stores sweep all address residues - where "column block = bx" (mode 1) pins XCD k to the 4 KiB
+// stripes = k mod 8 of every row, measured 0.9 us slower on k_fused_fwd than no mapping at all (profiles/r04).
+__device__ inline unsigned xcd_column_block(unsigned bx, unsigned gx_padded, int xmap) {
+  if (xmap != 2) return bx;
+  const unsigned per = gx_padded >> 3;
+  return (bx & 7u) * per + (bx >> 3);
+}
+
 // ================================================================================ emit
 // out[b, idx] = canvas value of flat index idx (+ sigma * N(0,1)); one thread = 4
 // consecutive flat indices (16-byte coalesced stores), blockIdx.y = slice of the batch.
@@ -1014,13 +1025,13 @@ __global__ void __launch_bounds__(kBlock) k_emit(DPlan pl, const float* __restri
                                                  const float* __restrict__ sigma_dev, const float* __restrict__ unit_noise,
                                                  unsigned long long seed, unsigned long long offset,
                                                  void* __restrict__ out, long long q_lo, long long q_hi,
-                                                 long long live_lo, long long live_hi, TapRider rider) {
+                                                 long long live_lo, long long live_hi, TapRider rider, int xmap) {
   // the crop window's transposed tap tables (read by the backward) built by the first workgroups of this launch, which
   // then go on with their own columns: hidden in a launch this long, where the image kernels they used to ride in
   // were extended by them (advx_forward_multi)
   if (blockIdx.y == 0) ride_taps(rider, blockIdx.x);
   emit_body<NOISE, IO>(pl, ws, batch, b_per_slice, sigma_dev, unit_noise, seed, offset, out, q_lo, q_hi, live_lo, live_hi,
-                       blockIdx.x, blockIdx.y);
+                       xcd_column_block(blockIdx.x, gridDim.x, xmap), blockIdx.y);
 }
 
 // Cross-model runs: the emits of all plans in ONE launch (blockIdx.z = plan).  Each emit alone ends in a tail in which
@@ -1381,12 +1392,13 @@ __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ 
                                                       void* __restrict__ out, FusedHeader* __restrict__ hdr,
                                                       double* __restrict__ img_partials,
                                                       const double* __restrict__ norm_partials, SchedDev* sched,
-                                                      float eps, FusedGeom geo) {
+                                                      float eps, FusedGeom geo, int xmap) {
   const long long n4 = n >> 2;
-  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  // gridDim.x is padded to a multiple of 8 (host: pad_xcd); the column blocks that exist:
+  const unsigned cb = xcd_column_block(blockIdx.x, gridDim.x, xmap);      // column block of this workgroup
+  const long long q = (long long)cb * blockDim.x + threadIdx.x;
+  // gridDim.x may be padded to a multiple of 8 (host: pad_xcd); the column blocks that exist:
   const int col_blocks = (int)((n4 + blockDim.x - 1) / blockDim.x);
-  if ((int)blockIdx.x >= col_blocks) return;
+  if ((int)cb >= col_blocks) return;
   if (SCHED) {
     const unsigned long long t = sched->fwd_step;       // uniform: a scalar load
     offset += t;
@@ -1423,7 +1435,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_fwd(const float* __restrict__ 
       stat_accumulate(sv.z, sv.z - xv.z, acc);
       stat_accumulate(sv.w, sv.w - xv.w, acc);
     }
-    block_sum_store<kStatSlots>(acc, img_partials + (size_t)blockIdx.x * kStatSlots);
+    block_sum_store<kStatSlots>(acc, img_partials + (size_t)cb * kStatSlots);
     return;
   }
   if (q >= n4) return;

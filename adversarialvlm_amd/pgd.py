@@ -43,7 +43,7 @@ class PixelPGD:
                  optimizer="adamw", cross_mode=False, betas=(0.9, 0.999), adam_eps=1e-8, weight_decay=1e-2, seed=0,
                  process_group=None, allow_fused=True, fused_mode="auto", grad_prescale=None, force_exchange=False,
                  io_dtype=torch.float32, exchange_transport="auto", noise_on_padding=True, exchange_timeout_s=5.0,
-                 batch_hint=None):
+                 batch_hint=None, step_fusion=False):
         """io_dtype: dtype of the pixel_values handed to the VLM (every chain but `step`).  float32 is
         the reference's own boundary; float16 / bfloat16 emit the tensor already cast to the
         model's dtype (the cast the model's first layer would apply) and let backward_update
@@ -60,7 +60,11 @@ class PixelPGD:
         exchange_timeout_s: wall-clock bound of every wait of the peer exchange; a wait that gives up sets
         a sticky error word (`self.peer.timed_out()`, `dp.check_replicas`) and lets its kernel go on.
         batch_hint: the prompt batch forward() will be called with, if the caller knows it: fused_mode="auto" then
-        picks the one-launch `step` chain for small batches on a single rank (see STEP_CHAIN_MAX_BATCH)."""
+        picks the one-launch `step` chain for small batches on a single rank (see STEP_CHAIN_MAX_BATCH).
+        step_fusion: blur chains on one rank - let backward_update(next_blur_sigma=, next_crop=) run the NEXT forward's image kernel
+        inside the backward's last launch (advx_image_step, bit-identical).  Off by default: measured on MI355X the one launch
+        (25.6 us at 512 x 512, kernel 9) is no faster than the two it replaces (14.1 + 10.7) - these kernels are bound by
+        instruction issue, and the halo recompute adds a third more of it (profiles/r04)."""
         if not x0.is_cuda:
             raise L.AdvxError("PixelPGD needs x0 on a ROCm device (there is no CPU fallback)")
         if not isinstance(plans, (list, tuple)):
@@ -170,7 +174,7 @@ class PixelPGD:
             # step-to-step fusion of the blur chains (advx_image_step): the backward of step t also runs the first image
             # kernel of step t+1 when the caller names that step's blur sigma / crop window (backward_update(next_...)).
             # p, m, v and s are double-buffered for it: a tile recomputes its halo from the OLD state.
-            self.step_fusion = bool(self.mode == "generic" and blur_kernel is not None and not self.exchange
+            self.step_fusion = bool(step_fusion and self.mode == "generic" and blur_kernel is not None and not self.exchange
                                     and self.accum == 1 and ops.image_step_supported(H, W, blur_kernel))
             if self.step_fusion:
                 self._alt = dict(p=torch.zeros_like(self.x0), m=torch.zeros_like(self.x0), v=torch.zeros_like(self.x0),

@@ -22,8 +22,8 @@ object (64 prompts in total on the same engine) is reported beside the weak `val
 
 Two timings, reported together:
  (A) the owned pixel path isolated = `value`, `ms_per_step`, `roofline`.  The K-step region is timed by a HIP event pair on the
-     launch stream (`ms_per_step`; max over ranks) with the wall clock between the two fences beside it (`ms_per_step_wall`); no
-     per-launch event sits inside the K steps - the per-kernel averages of `roofline` come from the 1000-step region timed right
+     launch stream (`ms_per_step`; max over ranks) with the wall clock between two fences beside it (`ms_per_step_wall`; for
+     a short K the two clocks get a region of K steps each, see timed()); no per-launch event sits inside the K steps - the per-kernel averages of `roofline` come from the 1000-step region timed right
      after it (`long_run`), where every stride-th launch carries its own event pair.
  (B) end to end = `e2e`: the same loop around a random-init LLaVA-1.5-7B architecture in fp16 (tools/e2e_bench.py), run in a
      FRESH CHILD PROCESS that is started and finished BEFORE this process makes its first GPU call, under a wall budget
@@ -279,7 +279,9 @@ def main():
     ap.add_argument("--e2e-steps", type=int, default=2)
     ap.add_argument("--e2e-image", type=int, default=H)
     ap.add_argument("--nt-loads", action="store_true", help="experiment: the pair's backward reads grad_out non-temporally")
-    ap.add_argument("--no-xcd-pad", action="store_true", help="experiment: grids as in rounds 1-3 (gx not padded to a multiple of 8)")
+    ap.add_argument("--xcd-map", type=int, default=None, choices=[0, 1, 2],
+                    help="experiment (ADVX_TUNE_XCD_MAP): 0 = grids as in rounds 1-3, 1 = gx padded to a multiple of 8, "
+                         "2 = padded + a contiguous range of column blocks per XCD (the library's default)")
     ap.add_argument("--lean", action="store_true", help="experiment: the pair without the s / v / grad_p streams (ADVX_TUNE_PAIR_LEAN)")
     args = ap.parse_args()
     io_dtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.io]
@@ -334,9 +336,9 @@ def main():
     if args.nt_loads:
         from adversarialvlm_amd import _lib
         _lib.check(_lib.load().advx_set_tuning(2, 1), "advx_set_tuning")
-    if args.no_xcd_pad:
+    if args.xcd_map is not None:
         from adversarialvlm_amd import _lib
-        _lib.check(_lib.load().advx_set_tuning(6, 0), "advx_set_tuning")
+        _lib.check(_lib.load().advx_set_tuning(6, args.xcd_map), "advx_set_tuning")
     if args.lean:
         from adversarialvlm_amd import _lib
         _lib.check(_lib.load().advx_set_tuning(5, 1), "advx_set_tuning")
@@ -392,27 +394,45 @@ def main():
 
     from adversarialvlm_amd import ops
 
-    def timed(step, steps=None, warmup=None, profile=False):
+    gate_buf = torch.empty(64 * 2 ** 20, dtype=torch.float32, device=dev)        # 256 MiB: see timed()
+
+    def timed(step, steps=None, warmup=None, profile=False, split=False):
         """W warm-up steps, then exactly K steps between two fences.  -> (device seconds, wall seconds, per-kernel profile | None),
         each the MAX over ranks.  Device seconds = a HIP event pair recorded on the launch stream (torch's current stream IS the
-        stream every advx_* launch of the engine goes to) right after the first fence and right after the last launch.
-        profile=True: every stride-th launch of the B*P_out movers also carries its own start/stop event pair (advx_profile_*,
-        hipExtLaunchKernelGGL; at least 10 per kernel, 64 from K = 640 up) - used for the 1000-step region only, so that no
-        event packet sits inside the K steps that `value` is computed from (a timed launch costs +0.6 us)."""
+        stream every advx_* launch of the engine goes to) right before the first and right after the last launch.
+        split=True (the K-step region of `value`, K small): TWO regions of exactly K steps each.  The first is bracketed by the
+        wall clock alone (fence, K steps, fence) -> wall seconds.  The second is the event-timed one: a 256 MiB fill is queued
+        ahead of the first event, so that the K steps' launches are already waiting in the queue when the device reaches the
+        event (the host's latency of the first launch after an idle fence, ~10-25 us, is not device time of the path; in the
+        trainers the VLM's kernels keep the queue busy) - the fill also leaves the caches cold.  Otherwise one region carries
+        both clocks.  profile=True: every stride-th launch of the B*P_out movers also carries its own start/stop event pair
+        (advx_profile_*, hipExtLaunchKernelGGL; at least 10 per kernel, 64 from K = 640 up) - used for the 1000-step region
+        only, so that no event packet sits inside the K steps that `value` is computed from (a timed launch costs +0.6 us)."""
         steps = args.steps if steps is None else steps
         for _ in range(args.warmup if warmup is None else warmup):
             step()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dt_wall = None
+        if split:
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            fence()
+            dt_wall = time.perf_counter() - t0
         fence()
         if profile:
             ops.profile_begin(max(steps, 1), stride=profile_stride(steps))
         t0 = time.perf_counter()
+        if split:
+            gate_buf.fill_(0.0)
         ev0.record()
         for _ in range(steps):
             step()
         ev1.record()
         fence()
-        dt_wall = time.perf_counter() - t0
+        if dt_wall is None:
+            dt_wall = time.perf_counter() - t0
         dt_dev = ev0.elapsed_time(ev1) * 1e-3
         prof = ops.profile_end() if profile else None
         if world > 1:
@@ -423,10 +443,10 @@ def main():
 
     runs = {}
     if args.cache in ("both", "cold"):
-        runs["cold"] = timed(step_cold)
+        runs["cold"] = timed(step_cold, split=args.steps < 500)
     held.clear()
     if args.cache in ("both", "hot"):
-        runs["hot"] = timed(step_hot)
+        runs["hot"] = timed(step_hot, split=args.steps < 500)
     main_key = "cold" if "cold" in runs else "hot"
     # The profiled region: the same loop as the headline over 1000 steps with per-launch event pairs on every stride-th
     # launch.  It supplies the per-kernel averages of `roofline` and is reported as `long_run`; `value` stays the K steps asked
@@ -583,8 +603,11 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 5),
             "ms_per_step_wall": round(dt_wall / args.steps * 1e3, 5),
             "value_wall": round(args.steps / dt_wall * B * world, 1),
-            "timing": "value / ms_per_step: HIP event pair on the launch stream around exactly K steps, between two "
-                      "barrier + synchronize fences, max over ranks; *_wall: time.perf_counter() between the same fences",
+            "timing": "value / ms_per_step: HIP event pair on the launch stream around exactly K steps, max over ranks; "
+                      "*_wall: time.perf_counter() around exactly K steps between two barrier + synchronize fences" +
+                      ("; K < 500: two regions of K steps each, the event-timed one behind a queued 256 MiB fill so that the "
+                       "host's first-launch latency after the idle fence is not counted as device time (bench.py: timed)"
+                       if args.steps < 500 else "; one region carries both clocks"),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"LLaVA-1.5 tanh-clamp attack, 336x336x3 image, {B}-prompt batch per GPU, "

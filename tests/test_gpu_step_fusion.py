@@ -29,7 +29,7 @@ def _opt(L, kind, t, lr=1e-2):
 GEOMS = [  # (H, W, kernel size, crop window of the NEXT step or None)
     (64, 50, 5, None), (46, 46, 9, None), (97, 130, 9, (5, 9, 80, 100)), (96, 160, 3, (0, 0, 96, 160)),
     (121, 67, 7, None), (336, 336, 5, (30, 20, 280, 300)), (512, 512, 9, (20, 30, 400, 420)), (200, 300, 9, None),
-    (45, 200, 7, None),       # exactly 32 + 3r + 2 rows
+    (43, 200, 7, None),       # exactly 32 + 3r + 2 rows (r = 3)
 ]
 
 
@@ -99,7 +99,7 @@ def test_image_step_equals_the_two_calls_it_replaces(H, W, k, next_crop, kind):
 def test_image_step_refuses_what_it_does_not_cover():
     from adversarialvlm_amd import _lib as L
     from adversarialvlm_amd import ops
-    assert not ops.image_step_supported(44, 200, 7)          # one row short of 32 + 3r + 2
+    assert not ops.image_step_supported(42, 200, 7)          # one row short of 32 + 3r + 2 (r = 3)
     assert not ops.image_step_supported(336, 336, 11)        # kernel sizes 3..9
     assert not ops.image_step_supported(336, 336, 4) and not ops.image_step_supported(336, 336, 0)
     with ops.generic_kernels():
@@ -139,7 +139,7 @@ def test_engine_with_and_without_the_fused_step_is_bit_identical(H, W, k, use_cr
             (4, 6, H - 8, W - 12), (1, 1, H - 2, W - 2)]
     sigmas = [1.3, 0.4, 1.9, 0.7, 1.1, 0.25, 1.5]
     engs = [PixelPGD(x0, plans(), lr=2e-2, mask=mask, blur_kernel=k, use_crop=use_crop, cross_mode=nplans > 1, seed=5,
-                     allow_fused=False) for _ in range(2)]
+                     allow_fused=False, step_fusion=True) for _ in range(2)]
     assert all(e.step_fusion for e in engs)
     outs = [[], []]
     for t in range(6):
@@ -175,10 +175,10 @@ def _gray(tmp, size):
 
 
 @pytest.mark.parametrize("use_crop", [False, True])
-def test_trainer_resume_with_blur_draws_the_same_windows(tmp_path, use_crop, monkeypatch):
+def test_trainer_resume_with_blur_draws_the_same_windows(tmp_path, use_crop):
     """The single trainer with blur 9 (+ a crop window per iteration) takes the fused step, drawing each window one iteration
     ahead; its checkpoints store the generator from before that draw, so 4 iterations + resume + 3 more equal 7 in one go,
-    bit for bit, and both equal a run that never fuses (the engine told that the geometry is not supported)."""
+    bit for bit, and both equal a run with the fusion off (the default)."""
     from adversarialvlm_amd import attack_model, ops
     tmp = str(tmp_path)
     img = _gray(tmp, 72)
@@ -188,15 +188,14 @@ def test_trainer_resume_with_blur_draws_the_same_windows(tmp_path, use_crop, mon
                  lr=1e-2, num_iterations=iters, save_steps=3, batch_size=3, grad_accum_steps=1, scheduler_step_size=2,
                  scheduler_gamma=0.8, restart_num=0, mask_type=None, mask_size=None, clamp_method="tanh", epsilon=0.5, sigma=1e-3,
                  start_from_white=False, target_text_random=False, base_path=tmp, seed=3, use_gaussian_blur=True,
-                 gblur_kernel_size=9, gblur_sigma=2.0, use_local_crop=use_crop)
+                 gblur_kernel_size=9, gblur_sigma=2.0, use_local_crop=use_crop, step_fusion=True)
         d.update(extra)
         return d
     eng, hist = attack_model.train(**kw("full", 7, return_engine=True))
     assert eng.step_fusion and eng.mode == "generic"
     attack_model.train(**kw("part", 4))
     attack_model.train(**kw("rest", 7, resume_from=os.path.join(tmp, "part", "state_iter_4.pt")))
-    monkeypatch.setattr(ops, "image_step_supported", lambda *a: False)
-    plain_eng, plain = attack_model.train(**kw("plain", 7, return_engine=True))
+    plain_eng, plain = attack_model.train(**kw("plain", 7, return_engine=True, step_fusion=False))
     assert not plain_eng.step_fusion
 
     def final(name):

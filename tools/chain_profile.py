@@ -32,7 +32,7 @@ def main():
                  "llava": lambda: [Plan.llava(H, W)]}[which]()
         B, kw = 64, {}
     x0 = torch.rand(3, H, W, device=dev)
-    eng = PixelPGD(x0, plans, allow_fused=(chain == "prepared"), **kw)
+    eng = PixelPGD(x0, plans, allow_fused=(chain == "prepared"), step_fusion=not os.environ.get("ADVX_NO_ANNOUNCE"), **kw)
     assert eng.mode == chain, eng.mode
     gs = [torch.randn(B, pl.out_numel, device=dev) for pl in plans]
     sig = 7.0 if "blur_kernel" in kw else None

@@ -17,7 +17,7 @@ def run(name, plans, H, W, B, blur=None, crop=None, steps=50, cross=False, pad_n
     dev = torch.device("cuda:0")
     x0 = torch.rand(3, H, W, device=dev)
     eng = PixelPGD(x0, plans, blur_kernel=blur, use_crop=crop is not None, cross_mode=cross, allow_fused=prepared,
-                   fused_mode="prepared" if prepared else "auto", noise_on_padding=pad_noise, io_dtype=io)
+                   fused_mode="prepared" if prepared else "auto", noise_on_padding=pad_noise, io_dtype=io, step_fusion=announce)
     name = f"{name} [{eng.mode}{'' if io == torch.float32 else ', ' + str(io).split('.')[-1]}]"
     gs = [torch.randn(B, pl.out_numel, device=dev).to(io) for pl in plans]
 
