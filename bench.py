@@ -146,8 +146,12 @@ def run_e2e_child(args):
     cmd = [sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--model", args.e2e_model, "--batch", str(args.e2e_batch),
            "--micro", str(args.e2e_micro), "--steps", str(args.e2e_steps), "--warmup", "1", "--image", str(args.e2e_image)]
     t0 = time.monotonic()
+    # MIOpen's default find mode searches convolution kernels the first time it meets the patch embedding (measured on a fresh
+    # box: first step 143 s, 7.7 s with FAST; the steps themselves 1.65 s either way for this architecture - profiles/r04)
+    env = dict(os.environ)
+    env.setdefault("MIOPEN_FIND_MODE", "FAST")
     try:
-        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, cwd=ROOT)     # stderr inherited: its progress lines
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, cwd=ROOT, env=env)     # stderr inherited: its progress lines
     except OSError as e:
         return {"skipped": f"could not start tools/e2e_bench.py: {e}"}
     try:
@@ -394,18 +398,41 @@ def main():
 
     from adversarialvlm_amd import ops
 
-    gate_buf = torch.empty(64 * 2 ** 20, dtype=torch.float32, device=dev)        # 256 MiB: see timed()
+    def make_gate(target_us=100.0):
+        """A launch that keeps the stream busy for ~target_us WITHOUT touching memory (torch's spin kernel, calibrated here with an
+        event pair): queued ahead of the first event of a short timed region - see timed().  None if the build has no such kernel."""
+        spin = getattr(torch.cuda, "_sleep", None)
+        if spin is None:
+            return None
+        try:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            spin(10000)
+            torch.cuda.synchronize()
+            probe = 400000
+            e0.record()
+            spin(probe)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3
+            if not (us > 0):
+                return None
+            cycles = max(1000, min(int(probe * target_us / us), 50 * probe))
+            return lambda: spin(cycles)
+        except RuntimeError:
+            return None
+
+    gate = make_gate()
 
     def timed(step, steps=None, warmup=None, profile=False, split=False):
         """W warm-up steps, then exactly K steps between two fences.  -> (device seconds, wall seconds, per-kernel profile | None),
         each the MAX over ranks.  Device seconds = a HIP event pair recorded on the launch stream (torch's current stream IS the
         stream every advx_* launch of the engine goes to) right before the first and right after the last launch.
         split=True (the K-step region of `value`, K small): TWO regions of exactly K steps each.  The first is bracketed by the
-        wall clock alone (fence, K steps, fence) -> wall seconds.  The second is the event-timed one: a 256 MiB fill is queued
-        ahead of the first event, so that the K steps' launches are already waiting in the queue when the device reaches the
-        event (the host's latency of the first launch after an idle fence, ~10-25 us, is not device time of the path; in the
-        trainers the VLM's kernels keep the queue busy) - the fill also leaves the caches cold.  Otherwise one region carries
-        both clocks.  profile=True: every stride-th launch of the B*P_out movers also carries its own start/stop event pair
+        wall clock alone (fence, K steps, fence) -> wall seconds.  The second is the event-timed one: a ~100 us spin kernel
+        (no memory traffic) is queued ahead of the first event, so that the K steps' launches are already waiting in the queue
+        when the device reaches the event - the host's latency of the first launch after an idle fence (~20 us here) is not
+        device time of the path; in the trainers the VLM's kernels keep the queue busy.  (A 256 MiB fill as the gate was tried
+        first: its write-back slowed the steps behind it, 0.0417 vs 0.0390 ms.)  Otherwise one region carries both clocks.  profile=True: every stride-th launch of the B*P_out movers also carries its own start/stop event pair
         (advx_profile_*, hipExtLaunchKernelGGL; at least 10 per kernel, 64 from K = 640 up) - used for the 1000-step region
         only, so that no event packet sits inside the K steps that `value` is computed from (a timed launch costs +0.6 us)."""
         steps = args.steps if steps is None else steps
@@ -424,8 +451,8 @@ def main():
         if profile:
             ops.profile_begin(max(steps, 1), stride=profile_stride(steps))
         t0 = time.perf_counter()
-        if split:
-            gate_buf.fill_(0.0)
+        if split and gate is not None:
+            gate()
         ev0.record()
         for _ in range(steps):
             step()
@@ -605,7 +632,7 @@ def main():
             "value_wall": round(args.steps / dt_wall * B * world, 1),
             "timing": "value / ms_per_step: HIP event pair on the launch stream around exactly K steps, max over ranks; "
                       "*_wall: time.perf_counter() around exactly K steps between two barrier + synchronize fences" +
-                      ("; K < 500: two regions of K steps each, the event-timed one behind a queued 256 MiB fill so that the "
+                      ("; K < 500: two regions of K steps each, the event-timed one behind a queued ~100 us spin kernel so that the "
                        "host's first-launch latency after the idle fence is not counted as device time (bench.py: timed)"
                        if args.steps < 500 else "; one region carries both clocks"),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,

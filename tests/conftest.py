@@ -33,6 +33,10 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
                                     + (f"; apart from these, {len(mod.ILL_LARGE)} on the 8 - 25 M-value images of test_trajectories_on_very_large_images "
                                        "(same rule, budget 1e-4 of the optimised values: at 4K the typical first gradient is 1e-4 and 4.5e-5 of the "
                                        "pixels sit at |g| ~ adam_eps)" if mod.ILL_LARGE else ""))
+        # who consumed the budgets: one line per test that vetted anything (test id -> pixel-steps of p accepted, level flips)
+        for test_id in sorted(set(mod.ILL_BY_TEST) | set(mod.FLIPS_BY_TEST)):
+            terminalreporter.write_line(f"   vetted: {test_id}: {mod.ILL_BY_TEST.get(test_id, 0)} pixel-step(s) of p, "
+                                        f"{mod.FLIPS_BY_TEST.get(test_id, 0)} quantiser-level flip(s)")
 
 
 def pytest_collection_modifyitems(config, items):

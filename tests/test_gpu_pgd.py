@@ -32,6 +32,8 @@ One more discontinuity is allowed for by a bound DERIVED from its instances, not
 quantise-error mean / std move by 1/(255 n) resp. 1/(255 sqrt(n-1)) per pixel whose uint8 level verifiably differs
 between the implementations (QUANTISER_FLIPS counts them)."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -48,6 +50,12 @@ FUZZ_MAX_ILL = 8            # the same for a RANDOM trajectory (tools/fuzz_pgd.p
 ILL_CONDITIONED = []        # (step, flat pixel index, p engine, p oracle, g engine, g oracle, max|g|) of accepted pixels
 ILL_LARGE = []              # the same for images of more than 2 M optimised values (test_gpu_fullsize's 4K / 6 MP cases), counted apart
 QUANTISER_FLIPS = [0]       # pixels whose uint8 level differed between the implementations (allowed for by a derived bound)
+ILL_BY_TEST = {}            # pytest node id -> vetted pixel-steps of p (who consumed the budgets: printed in the summary)
+FLIPS_BY_TEST = {}          # pytest node id -> quantiser-level flips allowed for
+
+
+def _current_test():
+    return os.environ.get("PYTEST_CURRENT_TEST", "(outside pytest)").split(" ")[0]
 
 
 def _check_p(step, p_eng, p_ref, g_eng, g_ref, always_tiny, excluded, budget, optimizer):
@@ -78,6 +86,7 @@ def _check_p(step, p_eng, p_ref, g_eng, g_ref, always_tiny, excluded, budget, op
         worst_g = max(abs(float(gr[k])) for k in off.tolist())
         print(f"ill-conditioned pixels accepted: step {step}, {off.numel()} of {p_ref.numel()} (largest |g| among them {worst_g:.3e}, max|g| {gmax:.3e})")
     excluded[off] = True
+    ILL_BY_TEST[_current_test()] = ILL_BY_TEST.get(_current_test(), 0) + int(off.numel())
     return int(off.numel())
 
 
@@ -154,6 +163,8 @@ def _trajectory(dev, x0, oracles, plans, batches, steps, blur_kernel=None, crop_
         flips = int((torch.trunc(s_eng.clamp(0, 1) * 255) != torch.trunc(s_ref.clamp(0, 1) * 255)).sum())
         assert flips <= max(2, s_ref.numel() // 20000), f"step {t}: {flips} pixels quantise to another level"
         QUANTISER_FLIPS[0] += flips
+        if flips:
+            FLIPS_BY_TEST[_current_test()] = FLIPS_BY_TEST.get(_current_test(), 0) + flips
         q_mean_slack = flips / (255.0 * s_ref.numel())
         q_std_slack = flips ** 0.5 / (255.0 * (s_ref.numel() - 1) ** 0.5)
         upd("sigma", max(0.0, abs(st["sigma_next"] - ref["sigma_next"]) - q_std_slack) / max(ref["sigma_next"], 1e-12))

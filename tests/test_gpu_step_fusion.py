@@ -202,4 +202,7 @@ def test_trainer_resume_with_blur_draws_the_same_windows(tmp_path, use_crop):
         return np.fromfile(os.path.join(tmp, name, "optimized_image_iter_final.bin"), dtype=np.float32)
     assert np.array_equal(final("full"), final("rest"))
     assert np.array_equal(final("full"), final("plain"))
-    assert [h["loss"] for h in hist] == [h["loss"] for h in plain]
+    # what the owned path logs is equal to the bit; the VLM's own loss (torch GEMMs and reductions on the GPU) only to rounding
+    for key in ("image_loss", "grad norm", "resave_error_std", "resave_error_mean", "adversarial_mean", "adversarial_std", "lr"):
+        assert [h[key] for h in hist] == [h[key] for h in plain], key
+    assert [h["ce_loss"] for h in hist] == pytest.approx([h["ce_loss"] for h in plain], rel=1e-5)
