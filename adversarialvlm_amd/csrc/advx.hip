@@ -48,6 +48,7 @@ static int32_t fail(int32_t code, const std::string& msg) {
 static int g_generic_kernels = 0;
 static int g_pair_nt_loads = 0;
 static int g_xcd_map = 2;        // ADVX_TUNE_XCD_MAP: 0 = grids as they come (rounds 1-3), 1 = gx padded to a multiple of 8, 2 = padded + a contiguous range of column blocks per XCD
+static int g_bwd_xcd = 1;        // ADVX_TUNE_BWD_XCD: the B x P_out READERS (k_fused_bwd, k_batch_reduce*) take the XCD-aware block map of the writers
 static int g_pair_lean = 0;      // ADVX_TUNE_PAIR_LEAN (experiment; the float32 Philox pair only)
 static int g_full_tap_rows = 0;
 static int g_separate_crop = 0;   // ADVX_TUNE_SEPARATE_CROP: 1 = never compose a crop window with stage 0; 2 = compose wherever the tables fit (tests)
@@ -56,6 +57,11 @@ extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
   if (what == ADVX_TUNE_RESET_ALL) {       // every switch back to its default (test fixtures' finaliser)
     g_generic_kernels = g_pair_nt_loads = g_pair_lean = g_full_tap_rows = g_separate_crop = 0;
     g_xcd_map = 2;
+    g_bwd_xcd = 1;
+    return ADVX_OK;
+  }
+  if (what == ADVX_TUNE_BWD_XCD) {
+    g_bwd_xcd = value ? 1 : 0;
     return ADVX_OK;
   }
   if (what == ADVX_TUNE_XCD_MAP) {
@@ -897,10 +903,12 @@ static int32_t launch_batch_reduce(const float* g, int batch, long long n, float
     // what is read here, B x (live columns) x 16 bytes: beyond the Infinity Cache it is streamed past it
     const double read_bytes = (double)batch * (double)(q_hi - q_lo) * (io == 0 ? 16.0 : 8.0);
     const int code = io + ((read_bytes > 256.0 * 1024 * 1024) ? 3 : 0);   // io_load4: +3 = non-temporal
+    const int rmap = g_bwd_xcd ? g_xcd_map : 0;                           // XCD-aware block map of the readers (xcd_block_of)
+    const int rgrid = (rmap == 2) ? 8 * ((blocks + 7) / 8) : blocks;
 #define ADVX_BR(T)                                                                                                             \
   do {                                                                                                                         \
-    if (plan) hipLaunchKernelGGL((k_batch_reduce<T, true>), dim3(blocks), dim3(kBlock), 0, st, (const void*)g, batch, n, out, q_lo, q_hi, pl); \
-    else hipLaunchKernelGGL((k_batch_reduce<T, false>), dim3(blocks), dim3(kBlock), 0, st, (const void*)g, batch, n, out, q_lo, q_hi, pl);     \
+    if (plan) hipLaunchKernelGGL((k_batch_reduce<T, true>), dim3(rgrid), dim3(kBlock), 0, st, (const void*)g, batch, n, out, q_lo, q_hi, pl, blocks, rmap); \
+    else hipLaunchKernelGGL((k_batch_reduce<T, false>), dim3(rgrid), dim3(kBlock), 0, st, (const void*)g, batch, n, out, q_lo, q_hi, pl, blocks, rmap);     \
   } while (0)
     switch (code) {
       case 0: ADVX_BR(0); break;
@@ -1249,7 +1257,8 @@ extern "C" int32_t advx_collect_multi(int32_t n, advx_plan* const* plans, const 
       max_blocks = std::max(max_blocks, a.blocks);
     }
     if (merge) {
-      dim3 grid(max_blocks, n);
+      mr.xmap = g_bwd_xcd ? g_xcd_map : 0;
+      dim3 grid(mr.xmap == 2 ? 8 * ((max_blocks + 7) / 8) : max_blocks, n);
       switch (code_all) {
         case 0: hipLaunchKernelGGL(k_batch_reduce_multi<0>, grid, dim3(kBlock), 0, st, mr); break;
         case 1: hipLaunchKernelGGL(k_batch_reduce_multi<1>, grid, dim3(kBlock), 0, st, mr); break;
@@ -2213,9 +2222,9 @@ static int32_t fused_bwd_impl(advx_plan* p, const void* g, int32_t io, int32_t b
     int32_t rc = check_opt(opt, m, v);
     if (rc) return rc;
 #define ADVX_FB_S(U, T, O, S)                                                                                     \
-  ADVX_LAUNCH_TIMED(PROF_BWD, (k_fused_bwd<U, T, S>), dim3(f.bwd_blocks), dim3(kBlock), st, g, batch, pp, x0, eps, \
-                    fused_geom(p), c_fit, mask, m, v, grad_p, O, s_next, v_buf, f.norm_partials, stats, f.hdr,     \
-                    (const double*)f.img_partials, sched)
+  ADVX_LAUNCH_TIMED(PROF_BWD, (k_fused_bwd<U, T, S>), dim3(g_bwd_xcd ? pad_xcd(f.bwd_blocks) : f.bwd_blocks), dim3(kBlock), st, g, \
+                    batch, pp, x0, eps, fused_geom(p), c_fit, mask, m, v, grad_p, O, s_next, v_buf, f.norm_partials, stats, f.hdr, \
+                    (const double*)f.img_partials, sched, g_bwd_xcd ? g_xcd_map : 0)
 #define ADVX_FB(U, T, O) do { if (sched) ADVX_FB_S(U, T, O, true); else ADVX_FB_S(U, T, O, false); } while (0)
 #define ADVX_FB_IO(U, O)                                                                                   \
   do {                                                                                                     \
@@ -2228,7 +2237,7 @@ static int32_t fused_bwd_impl(advx_plan* p, const void* g, int32_t io, int32_t b
     if (g_pair_lean && io == 0 && !sched) {
       ADVX_LAUNCH_TIMED(PROF_BWD, (k_fused_bwd<true, 0, false, true>), dim3(f.bwd_blocks), dim3(kBlock), st, g, batch, pp, x0, eps,
                         fused_geom(p), c_fit, mask, m, v, grad_p, to_dev(opt), s_next, v_buf, f.norm_partials, stats, f.hdr,
-                        (const double*)f.img_partials, sched);
+                        (const double*)f.img_partials, sched, 0);
     } else
     ADVX_FB_IO(true, to_dev(opt));
   } else {

@@ -899,6 +899,15 @@ __device__ inline unsigned xcd_column_block(unsigned bx, unsigned gx_padded, int
   const unsigned per = gx_padded >> 3;
   return (bx & 7u) * per + (bx >> 3);
 }
+// the same for a launch whose grid serves several block counts (k_batch_reduce_multi: one count per plan): the contiguous ranges
+// are cut from THIS count; -> column block, or -1 for a workgroup with nothing to do (grid.x >= 8 * ceil(nblocks / 8))
+__device__ inline int xcd_block_of(unsigned bx, int nblocks, int xmap) {
+  if (xmap != 2) return ((int)bx < nblocks) ? (int)bx : -1;
+  const unsigned per = ((unsigned)nblocks + 7u) >> 3, j = bx >> 3;
+  if (j >= per) return -1;
+  const unsigned cb = (bx & 7u) * per + j;
+  return ((int)cb < nblocks) ? (int)cb : -1;
+}
 
 // ================================================================================ emit
 // out[b, idx] = canvas value of flat index idx (+ sigma * N(0,1)); one thread = 4
@@ -1177,8 +1186,11 @@ __device__ inline void reduce_body(const void* __restrict__ g, int batch, long l
 
 template <int IO, bool CANVAS>
 __global__ void __launch_bounds__(kBlock) k_batch_reduce(const void* __restrict__ g, int batch, long long n,
-                                                         float* __restrict__ out, long long q_lo, long long q_hi, DPlan pl) {
-  reduce_body<IO, CANVAS>(g, batch, n, out, q_lo, q_hi, pl, blockIdx.x, gridDim.x);
+                                                         float* __restrict__ out, long long q_lo, long long q_hi, DPlan pl,
+                                                         int blocks, int xmap) {
+  const int bx = xcd_block_of(blockIdx.x, blocks, xmap);      // XCD k reads a contiguous range of 64-column blocks
+  if (bx < 0) return;
+  reduce_body<IO, CANVAS>(g, batch, n, out, q_lo, q_hi, pl, (unsigned)bx, (unsigned)blocks);
 }
 
 // Cross-model runs: the batch reductions of all plans in ONE launch (blockIdx.y = plan), as k_emit_multi does for the
@@ -1192,7 +1204,7 @@ struct ReduceArgs {
   int batch, blocks;
 };
 struct MultiReduce {
-  int n;
+  int n, xmap;
   ReduceArgs a[kMaxMulti];
 };
 template <int IO>
@@ -1201,8 +1213,9 @@ __global__ void __launch_bounds__(kBlock) k_batch_reduce_multi(MultiReduce mr) {
   for (int k = 0; k < kMaxMulti; ++k) {
     if (k != (int)blockIdx.y) continue;
     const ReduceArgs& a = mr.a[k];
-    if ((int)blockIdx.x >= a.blocks) return;
-    reduce_body<IO, true>(a.g, a.batch, a.n, a.out, a.q_lo, a.q_hi, a.pl, blockIdx.x, (unsigned)a.blocks);
+    const int bx = xcd_block_of(blockIdx.x, a.blocks, mr.xmap);
+    if (bx < 0) return;
+    reduce_body<IO, true>(a.g, a.batch, a.n, a.out, a.q_lo, a.q_hi, a.pl, (unsigned)bx, (unsigned)a.blocks);
   }
 }
 
@@ -1492,21 +1505,26 @@ __global__ void __launch_bounds__(kBlock) k_fused_bwd(const void* __restrict__ g
                                                       float* __restrict__ s_next, float* __restrict__ v_buf,
                                                       double* __restrict__ norm_partials, float* __restrict__ stats,
                                                       FusedHeader* __restrict__ hdr,
-                                                      const double* __restrict__ img_partials, SchedDev* sched) {
+                                                      const double* __restrict__ img_partials, SchedDev* sched, int xmap) {
   __shared__ float4 part4[kBlock / kWave][kWave];
+  // XCD-aware block -> column mapping (xcd_column_block; the grid may be padded to a multiple of 8): XCD k works on a
+  // contiguous range of 64-column blocks instead of every eighth one
+  const unsigned bx = xcd_column_block(blockIdx.x, gridDim.x, xmap);
+  const int col_blocks = (int)(((3LL * geo.plane >> 2) + kWave - 1) / kWave);
+  if ((int)bx >= col_blocks) return;
   if (SCHED) {
     const unsigned long long t = sched->bwd_step;
     long long k = (long long)(t - sched->first_step);
     if (k < 0) k = 0;
     if (k > sched->n_opt - 1) k = sched->n_opt - 1;
     o = reinterpret_cast<const OptScalars*>(sched + 1)[k];
-    if (blockIdx.x == 0 && threadIdx.x == 0) sched->fwd_step = t + 1;
+    if (bx == 0 && threadIdx.x == 0) sched->fwd_step = t + 1;
   }
   const long long n = 3LL * geo.plane;
   const long long n4 = n >> 2;
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  const long long q = (long long)blockIdx.x * kWave + lane;
-  const long long i = (long long)blockIdx.x * (kWave * 4) + threadIdx.x;
+  const long long q = (long long)bx * kWave + lane;
+  const long long i = (long long)bx * (kWave * 4) + threadIdx.x;
   // prefetch this thread's pixel state (latency hides under the batch stream)
   float pp = 0.f, xv = 0.f, mk = 0.f, mm = 0.f, vv = 0.f;
   if (i < n) {
@@ -1529,7 +1547,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_bwd(const void* __restrict__ g
   const float dtanh = 1.0f - t * t;
   float4 a = make_float4(0, 0, 0, 0);
   if (q < n4) a = batch_column_sum<IO>(g, batch, n, q << 2, wid, kBlock / kWave);
-  if (blockIdx.x == 0) {
+  if (bx == 0) {
     // statistics partials left by this step's forward: reduce them here, beside the other
     // blocks' streaming work (rotates SIGMA <- old QERR_STD, then QERR_STD <- new)
     int ib = hdr->image_blocks;
@@ -1537,7 +1555,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_bwd(const void* __restrict__ g
     if (ib > 0) finalize_image_block<true>(img_partials, ib, n, stats);
     if (threadIdx.x == 0) {
       hdr->image_blocks = 0;
-      if (UPDATE) hdr->norm_blocks = gridDim.x;
+      if (UPDATE) hdr->norm_blocks = col_blocks;
     }
   }
   part4[wid][lane] = a;
@@ -1572,7 +1590,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_bwd(const void* __restrict__ g
       grad_p[i] = gp;
     }
   }
-  if (UPDATE) block_sum_store<1>(nacc, norm_partials + blockIdx.x);
+  if (UPDATE) block_sum_store<1>(nacc, norm_partials + bx);
 }
 
 // data-parallel tail of the pair: after the all-reduce of grad_p every rank runs this ONE

@@ -286,6 +286,8 @@ def main():
     ap.add_argument("--xcd-map", type=int, default=None, choices=[0, 1, 2],
                     help="experiment (ADVX_TUNE_XCD_MAP): 0 = grids as in rounds 1-3, 1 = gx padded to a multiple of 8, "
                          "2 = padded + a contiguous range of column blocks per XCD (the library's default)")
+    ap.add_argument("--bwd-xcd", type=int, default=None, choices=[0, 1],
+                    help="experiment (ADVX_TUNE_BWD_XCD): XCD-aware block map in the pair's backward / the batch reductions (default 1)")
     ap.add_argument("--lean", action="store_true", help="experiment: the pair without the s / v / grad_p streams (ADVX_TUNE_PAIR_LEAN)")
     args = ap.parse_args()
     io_dtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.io]
@@ -343,6 +345,9 @@ def main():
     if args.xcd_map is not None:
         from adversarialvlm_amd import _lib
         _lib.check(_lib.load().advx_set_tuning(6, args.xcd_map), "advx_set_tuning")
+    if args.bwd_xcd is not None:
+        from adversarialvlm_amd import _lib
+        _lib.check(_lib.load().advx_set_tuning(7, args.bwd_xcd), "advx_set_tuning")
     if args.lean:
         from adversarialvlm_amd import _lib
         _lib.check(_lib.load().advx_set_tuning(5, 1), "advx_set_tuning")

@@ -52,6 +52,12 @@ def run(name, plans, H, W, B, blur=None, crop=None, steps=50, cross=False, pad_n
 
 
 if __name__ == "__main__":
+    if os.environ.get("ADVX_BWD_XCD") is not None:          # A/B of the readers' XCD-aware block map (ADVX_TUNE_BWD_XCD)
+        from adversarialvlm_amd import _lib
+        _lib.check(_lib.load().advx_set_tuning(7, int(os.environ["ADVX_BWD_XCD"])), "advx_set_tuning")
+    if os.environ.get("ADVX_XCD_MAP") is not None:          # ... and of the writers' (ADVX_TUNE_XCD_MAP)
+        from adversarialvlm_amd import _lib
+        _lib.check(_lib.load().advx_set_tuning(6, int(os.environ["ADVX_XCD_MAP"])), "advx_set_tuning")
     run("llava 336 identity (generic)", [Plan.llava(336, 336)], 336, 336, 64)
     run("llava 512->336", [Plan.llava(512, 512)], 512, 512, 64)
     run("llava 512->336", [Plan.llava(512, 512)], 512, 512, 64, prepared=True)
