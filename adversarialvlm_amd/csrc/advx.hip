@@ -48,6 +48,7 @@ static int32_t fail(int32_t code, const std::string& msg) {
 static int g_generic_kernels = 0;
 static int g_pair_nt_loads = 0;
 static int g_xcd_map = 2;        // ADVX_TUNE_XCD_MAP: 0 = grids as they come (rounds 1-3), 1 = gx padded to a multiple of 8, 2 = padded + a contiguous range of column blocks per XCD
+static int g_row_batch = 1;      // ADVX_TUNE_ROW_BATCH: the image-sized gathers load the taps of one window row together (gather_rows3, k_stage_bwd3_rb)
 static int g_bwd_xcd = 1;        // ADVX_TUNE_BWD_XCD: the B x P_out READERS (k_fused_bwd, k_batch_reduce*) take the XCD-aware block map of the writers
 static int g_pair_lean = 0;      // ADVX_TUNE_PAIR_LEAN (experiment; the float32 Philox pair only)
 static int g_full_tap_rows = 0;
@@ -58,6 +59,11 @@ extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
     g_generic_kernels = g_pair_nt_loads = g_pair_lean = g_full_tap_rows = g_separate_crop = 0;
     g_xcd_map = 2;
     g_bwd_xcd = 1;
+    g_row_batch = 1;
+    return ADVX_OK;
+  }
+  if (what == ADVX_TUNE_ROW_BATCH) {
+    g_row_batch = value ? 1 : 0;
     return ADVX_OK;
   }
   if (what == ADVX_TUNE_BWD_XCD) {
@@ -736,7 +742,7 @@ static void launch_stage_fwd(const DStage& D, const float* src, long long src_cs
     TapBuild none;
     std::memset(&none, 0, sizeof(none));
     hipLaunchKernelGGL(k_stage0_fwd_multi, dim3((D.can_w + kRowBlock - 1) / kRowBlock, D.can_h, 1), dim3(kRowBlock), 0, st, mf, src,
-                       src_cstride, src_rstride, img_partials, img_nblk, n_img, stats, norm_rows, norm_count, none, none, 0);
+                       src_cstride, src_rstride, img_partials, img_nblk, n_img, stats, norm_rows, norm_count, none, none, 0, g_row_batch);
     return;
   }
   if (img_nblk > 0)
@@ -948,9 +954,21 @@ static bool dgrad_into_gcan(const advx_plan* p, int k) {
 static void launch_stage_bwd(const DStage& D, const CanvasGrad& cg, float* gsrc, long long cstride, int rstride, int acc,
                              hipStream_t st) {
   const int rowblk = 128;   // two waves along x: little waste on the last chunk of a 336 / 512 / 672-wide row
-  if (!g_generic_kernels && (long long)D.src_h * D.src_w >= kRows3MinPositions)
-    hipLaunchKernelGGL(k_stage_bwd3, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h), dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc);
-  else
+  if (!g_generic_kernels && (long long)D.src_h * D.src_w >= kRows3MinPositions) {
+    // the taps of one canvas row loaded together where canvas_grad_at has one of the three shapes that occur (stage_bwd3_rows)
+    const int mode = (!g_row_batch || D.ttw.stride > 8) ? 0
+                     : (cg.copies == 1 && !cg.dgrad)    ? 1
+                     : (cg.copies == 1 && cg.dgrad)     ? 2
+                     : (cg.copies == 2 && !cg.dgrad)    ? 3
+                                                        : 0;
+    const dim3 grid((D.src_w + rowblk - 1) / rowblk, D.src_h);
+    switch (mode) {
+      case 1: hipLaunchKernelGGL(k_stage_bwd3_rb<1>, grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc); break;
+      case 2: hipLaunchKernelGGL(k_stage_bwd3_rb<2>, grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc); break;
+      case 3: hipLaunchKernelGGL(k_stage_bwd3_rb<3>, grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc); break;
+      default: hipLaunchKernelGGL(k_stage_bwd3, grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc); break;
+    }
+  } else
     hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc);
 }
 // where the backward of a stage that reads canvas `src_canvas` writes, and whether it accumulates there
@@ -1110,14 +1128,14 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
     if (tr_blocks > 0) {
       hipLaunchKernelGGL(k_stage0_fwd_multi, dim3(gx0, max_h, n + 1), dim3(kRowBlock), 0, st, mf, argument,
                          (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats,
-                         (const double*)nullptr, 0, rider.t[0], rider.t[1], tr_blocks);
+                         (const double*)nullptr, 0, rider.t[0], rider.t[1], tr_blocks, g_row_batch);
       rider = no_rider();
     } else {
       TapBuild none;
       std::memset(&none, 0, sizeof(none));
       hipLaunchKernelGGL(k_stage0_fwd_multi, dim3(gx0, max_h, n), dim3(kRowBlock), 0, st, mf, argument,
                          (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats,
-                         (const double*)nullptr, 0, none, none, 0);
+                         (const double*)nullptr, 0, none, none, 0, g_row_batch);
     }
   }
   LAUNCH_CHECK();

@@ -677,6 +677,87 @@ __global__ void __launch_bounds__(kBlock) k_stage_bwd3(DStage st, CanvasGrad cg,
   }
 }
 
+// k_stage_bwd3 with the taps of one canvas row loaded together (see gather_rows3 below: the same idea, here over the
+// canvas gradient; COPIES / DG fix canvas_grad_at's shape at compile time so that nothing sits between the loads).
+template <int TB, int COPIES, bool DG>
+__device__ inline void stage_bwd3_rows(const DStage& st, const CanvasGrad& cg, int ys, int xs, float (&v)[3]) {
+  const int oy = st.tth.start[ys], oyc = st.tth.count[ys];
+  const int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
+  const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
+  const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
+  const size_t plane = (size_t)st.can_h * st.can_w;
+  float wv[TB];
+  int off[TB];
+  const int last = max(oxc - 1, 0);
+#pragma unroll
+  for (int k = 0; k < TB; ++k) {
+    off[k] = min(k, last);
+    wv[k] = wx[off[k]];
+  }
+  v[0] = v[1] = v[2] = 0.0f;
+  for (int a = 0; a < oyc; ++a) {
+    const size_t row = (size_t)(st.off_y + oy + a) * st.can_w + st.off_x + ox;
+    const float wa = wy[a];
+    float r[3][TB][COPIES + (DG ? 1 : 0)];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int k = 0; k < TB; ++k) {
+        const size_t o = (size_t)c * plane + row + off[k];
+#pragma unroll
+        for (int t = 0; t < COPIES; ++t) r[c][k][t] = cg.g[(size_t)t * cg.copy_stride + o];
+        if (DG) r[c][k][COPIES] = cg.dgrad[o];
+      }
+    float h[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < TB; ++k) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float g = 0.0f;                                  // canvas_grad_at: the copies in order, then dgrad
+#pragma unroll
+        for (int t = 0; t < COPIES; ++t) g += r[c][k][t];
+        if (DG) g += r[c][k][COPIES];
+        h[c] = (k < oxc) ? h[c] + wv[k] * g : h[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] += wa * h[c];
+  }
+}
+template <int COPIES, bool DG>
+__device__ inline bool stage_bwd3_rows_any(const DStage& st, const CanvasGrad& cg, int ys, int xs, float (&v)[3]) {
+  const int T = st.ttw.stride;
+  if (T <= 2) stage_bwd3_rows<2, COPIES, DG>(st, cg, ys, xs, v);
+  else if (T <= 4) stage_bwd3_rows<4, COPIES, DG>(st, cg, ys, xs, v);
+  else if (T <= 6) stage_bwd3_rows<6, COPIES, DG>(st, cg, ys, xs, v);
+  else if (T <= 8) stage_bwd3_rows<8, COPIES, DG>(st, cg, ys, xs, v);
+  else return false;
+  return true;
+}
+// MODE: 1 = one copy, 2 = one copy + dgrad, 3 = two copies (Qwen2-VL's temporal pair)
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_stage_bwd3_rb(DStage st, CanvasGrad cg, float* __restrict__ gsrc, long long gsrc_cstride,
+                                                          int gsrc_rstride, int accumulate) {
+  const int ys = blockIdx.y;
+  const int xs = blockIdx.x * blockDim.x + threadIdx.x;
+  if (xs >= st.src_w) return;
+  const size_t o = (size_t)ys * gsrc_rstride + xs;
+  float before[3] = {0.0f, 0.0f, 0.0f};
+  if (accumulate) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) before[c] = gsrc[(size_t)c * gsrc_cstride + o];
+  }
+  float v[3];
+  if (MODE == 1) stage_bwd3_rows_any<1, false>(st, cg, ys, xs, v);
+  else if (MODE == 2) stage_bwd3_rows_any<1, true>(st, cg, ys, xs, v);
+  else stage_bwd3_rows_any<2, false>(st, cg, ys, xs, v);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float r = st.normalise ? v[c] / st.stdv[c] : v[c];
+    gsrc[(size_t)c * gsrc_cstride + o] = accumulate ? (before[c] + r) : r;
+  }
+}
+
 // Several plans over ONE image (cross-model runs, crossattack_models.py:352-391).  Their
 // stage-0 kernels are each too small to fill the device and a dependent launch costs ~5 us, so
 // the stage-0 work of all plans goes into one launch:
@@ -740,12 +821,77 @@ __device__ inline void stage_fwd_value3(const DStage& st, const float* __restric
   for (int c = 0; c < 3; ++c) out[c] = st.normalise ? (v[c] - st.mean[c]) / st.stdv[c] : v[c];
 }
 
+// ROW-BATCHED gathers (round 4, ADVX_TUNE_ROW_BATCH).  The run-time loops above wait for memory once per TAP: the inner loop
+// issues one weight and three source loads, `s_waitcnt vmcnt(0)`, three multiply-adds - a window of 6 x 6 taps is 36 round
+// trips behind one another in a launch that has two or three waves per SIMD to hide them.  Here the taps of ONE ROW of the
+// window (TB >= the table's row length, a compile-time bound) are loaded together for the three channels, the column weights
+// once per thread, and only the rows are walked at run time (their count is uniform: the row of a workgroup is): yc round
+// trips, no load of a row the window does not have (what the T x T windows of advx_resize.h pay from 5 x 5 on).  Taps beyond
+// a column's count are read from the last valid tap's address and never enter the sum; the in-range taps are accumulated by
+// the same operations in the same order as in the loops: bit-identical results.
+template <int TB>
+__device__ inline void gather_rows3(const float* __restrict__ base, long long cstride, int rstride, int y0, int yc, int x0, int xc,
+                                    const float* __restrict__ wy, const float* __restrict__ wx, float (&v)[3]) {
+  float wv[TB];
+  int off[TB];
+  const int last = max(xc - 1, 0);
+#pragma unroll
+  for (int k = 0; k < TB; ++k) {
+    off[k] = min(k, last);
+    wv[k] = wx[off[k]];
+  }
+  v[0] = v[1] = v[2] = 0.0f;
+  for (int a = 0; a < yc; ++a) {
+    const float* rowp = base + (size_t)(y0 + a) * rstride + x0;
+    const float wa = wy[a];
+    float r[3][TB];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int k = 0; k < TB; ++k) r[c][k] = rowp[(size_t)c * cstride + off[k]];
+    float h[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < TB; ++k) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) h[c] = (k < xc) ? h[c] + wv[k] * r[c][k] : h[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] += wa * h[c];
+  }
+}
+// -> false: the table's rows are longer than the largest compiled batch (the caller's loops take over)
+__device__ inline bool gather_rows3_any(int stride, const float* __restrict__ base, long long cstride, int rstride, int y0, int yc,
+                                        int x0, int xc, const float* __restrict__ wy, const float* __restrict__ wx, float (&v)[3]) {
+  if (stride <= 2) gather_rows3<2>(base, cstride, rstride, y0, yc, x0, xc, wy, wx, v);
+  else if (stride <= 4) gather_rows3<4>(base, cstride, rstride, y0, yc, x0, xc, wy, wx, v);
+  else if (stride <= 6) gather_rows3<6>(base, cstride, rstride, y0, yc, x0, xc, wy, wx, v);
+  else if (stride <= 8) gather_rows3<8>(base, cstride, rstride, y0, yc, x0, xc, wy, wx, v);
+  else return false;
+  return true;
+}
+
+// stage_fwd_value3 on the row-batched gather (column-inner nesting only; else, and for longer rows, the loops)
+__device__ inline void stage_fwd_value3_rb(const DStage& st, const float* __restrict__ src, long long src_cstride, int src_rstride,
+                                           int y, int x, float (&out)[3]) {
+  const int ry = y - st.off_y, rx = x - st.off_x;
+  if (st.inner_axis_h || st.tw.stride > 8 || !(ry >= 0 && ry < st.res_h && rx >= 0 && rx < st.res_w)) {
+    stage_fwd_value3(st, src, src_cstride, src_rstride, y, x, out);
+    return;
+  }
+  float v[3];
+  gather_rows3_any(st.tw.stride, src, src_cstride, src_rstride, st.th.start[ry], st.th.count[ry], st.tw.start[rx], st.tw.count[rx],
+                   st.th.w + (size_t)ry * st.th.stride, st.tw.w + (size_t)rx * st.tw.stride, v);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[c] = st.normalise ? (v[c] - st.mean[c]) / st.stdv[c] : v[c];
+}
+
 // grid = (column chunks of the widest canvas, rows of the tallest, plans)
 __global__ void __launch_bounds__(kBlock) k_stage0_fwd_multi(MultiFwd mf, const float* __restrict__ src, long long src_cstride,
                                                              int src_rstride, const double* __restrict__ img_partials, int nblk,
                                                              long long n_img, float* __restrict__ stats,
                                                              const double* __restrict__ norm_rows, int norm_count,
-                                                             TapBuild tr0 = TapBuild(), TapBuild tr1 = TapBuild(), int tr_blocks = 0) {
+                                                             TapBuild tr0 = TapBuild(), TapBuild tr1 = TapBuild(), int tr_blocks = 0,
+                                                             int row_batch = 0) {
   // nblk > 0: the image kernels of the same call left statistics partials; block (0,0,0) reduces them
   // here (k_emit, the consumer of sigma, is a later launch); norm_count > 0: the ||g|| partials of the prepared chain's tail
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
@@ -771,7 +917,8 @@ __global__ void __launch_bounds__(kBlock) k_stage0_fwd_multi(MultiFwd mf, const 
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (y < st.can_h && x < st.can_w) {
     float v[3];
-    stage_fwd_value3(st, src, src_cstride, src_rstride, y, x, v);
+    if (row_batch) stage_fwd_value3_rb(st, src, src_cstride, src_rstride, y, x, v);
+    else stage_fwd_value3(st, src, src_cstride, src_rstride, y, x, v);
     float* __restrict__ canvas = mf.canvas[k];
     const size_t plane = (size_t)st.can_h * st.can_w;
 #pragma unroll

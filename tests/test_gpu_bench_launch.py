@@ -41,7 +41,11 @@ def test_bench_launches_its_own_ranks():
         assert cfg["multi_gpu_hardware_evidence"].startswith("none")
     # (B) was measured once, by the parent, before the ranks were started (tiny model here)
     assert line["e2e"].get("s_per_step", 0) > 0 and line["e2e"]["model"] == "synthetic/tiny-llava", line["e2e"]
-    assert line["ms_per_step"] > 0 and line["ms_per_step_wall"] >= line["ms_per_step"] * 0.9
+    # for K < 500 the two clocks time a region of K steps EACH: with both ranks time-sliced on one device either region may be
+    # the slower one (seen: events 1.06 ms, wall 0.71 ms), so the order of the two is only asserted on distinct devices
+    assert line["ms_per_step"] > 0 and line["ms_per_step_wall"] > 0
+    if cfg["devices_distinct"]:
+        assert line["ms_per_step_wall"] >= line["ms_per_step"] * 0.9
     print("bench --gpus 2 (self-launched):", line["value"], line["unit"], "| strong", line["strong"]["value"],
           "|", line["config"]["exchange"])
 

@@ -14,6 +14,9 @@ from adversarialvlm_amd.plan import Plan  # noqa: E402
 
 
 def main():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from _tune import apply_env_tuning
+    apply_env_tuning()                                      # ADVX_TUNE="code=value,..." (tools/_tune.py)
     which = sys.argv[1] if len(sys.argv) > 1 else "mllama"
     chain = sys.argv[2] if len(sys.argv) > 2 else "prepared"
     dev = torch.device("cuda:0")

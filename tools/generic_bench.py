@@ -52,6 +52,9 @@ def run(name, plans, H, W, B, blur=None, crop=None, steps=50, cross=False, pad_n
 
 
 if __name__ == "__main__":
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from _tune import apply_env_tuning
+    apply_env_tuning()                                      # ADVX_TUNE="code=value,..." (tools/_tune.py)
     if os.environ.get("ADVX_BWD_XCD") is not None:          # A/B of the readers' XCD-aware block map (ADVX_TUNE_BWD_XCD)
         from adversarialvlm_amd import _lib
         _lib.check(_lib.load().advx_set_tuning(7, int(os.environ["ADVX_BWD_XCD"])), "advx_set_tuning")
