@@ -48,7 +48,9 @@ static int32_t fail(int32_t code, const std::string& msg) {
 static int g_generic_kernels = 0;
 static int g_pair_nt_loads = 0;
 static int g_xcd_map = 2;        // ADVX_TUNE_XCD_MAP: 0 = grids as they come (rounds 1-3), 1 = gx padded to a multiple of 8, 2 = padded + a contiguous range of column blocks per XCD
-static int g_row_batch = 1;      // ADVX_TUNE_ROW_BATCH: the image-sized gathers load the taps of one window row together (gather_rows3, k_stage_bwd3_rb)
+static int g_row_batch = 1;      // ADVX_TUNE_ROW_BATCH: the transposed resizes load the taps of one window row together (k_stage_bwd3_rb)
+constexpr int kImgXcdRows = 8;   // rows per group of the XCD-aware image grids (xcd_band_block)
+static int g_img_xcd = kImgXcdRows;   // ADVX_TUNE_IMG_XCD: rows per group; 0 = (column chunk, row, layer) grids dealt round-robin
 static int g_bwd_xcd = 1;        // ADVX_TUNE_BWD_XCD: the B x P_out READERS (k_fused_bwd, k_batch_reduce*) take the XCD-aware block map of the writers
 static int g_pair_lean = 0;      // ADVX_TUNE_PAIR_LEAN (experiment; the float32 Philox pair only)
 static int g_full_tap_rows = 0;
@@ -60,6 +62,11 @@ extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
     g_xcd_map = 2;
     g_bwd_xcd = 1;
     g_row_batch = 1;
+    g_img_xcd = kImgXcdRows;
+    return ADVX_OK;
+  }
+  if (what == ADVX_TUNE_IMG_XCD) {
+    g_img_xcd = value < 0 ? 0 : (value > 4096 ? 4096 : value);
     return ADVX_OK;
   }
   if (what == ADVX_TUNE_ROW_BATCH) {
@@ -693,6 +700,22 @@ static inline TapRider no_rider() {
   return r;
 }
 
+// the launch grid of an image-sized (column chunk, row, layer) kernel and what the kernel is told about it (xcd_band_block).
+// rider_blocks: table-builder blocks riding in the launch - a z layer of their own in front on the round-robin grid, appended
+// behind the body on the XCD-aware one.  allow = false: round robin whatever the switch says.
+static inline ImgGrid img_grid(unsigned gx, unsigned gy, unsigned gz, dim3* launch, unsigned rider_blocks = 0, bool allow = true) {
+  const int rows = allow ? g_img_xcd : 0;
+  ImgGrid g;
+  g.banded = rows ? 1 : 0;
+  g.gx = gx; g.gy = gy; g.gz = gz;
+  g.extra = rows ? rider_blocks : 0u;
+  g.group = gx * (unsigned)(rows ? rows : 1);
+  // every logical block must be some physical block's: whole rounds of 8 groups
+  const unsigned total = gx * gy * gz + g.extra, round = 8u * g.group;
+  *launch = rows ? dim3(round * ((total + round - 1u) / round)) : dim3(gx, gy, gz + (rider_blocks ? 1u : 0u));
+  return g;
+}
+
 // ---------------------------------------------------------- windowed resizes (advx_resize.h)
 // T = compiled window size that holds `need` taps per axis (0: none - the run-time-loop kernels take over)
 static inline int pick_window(int need) {
@@ -741,8 +764,10 @@ static void launch_stage_fwd(const DStage& D, const float* src, long long src_cs
     mf.canvas[0] = canvas;
     TapBuild none;
     std::memset(&none, 0, sizeof(none));
-    hipLaunchKernelGGL(k_stage0_fwd_multi, dim3((D.can_w + kRowBlock - 1) / kRowBlock, D.can_h, 1), dim3(kRowBlock), 0, st, mf, src,
-                       src_cstride, src_rstride, img_partials, img_nblk, n_img, stats, norm_rows, norm_count, none, none, 0, g_row_batch);
+    dim3 lg;
+    const ImgGrid ig = img_grid((D.can_w + kRowBlock - 1) / kRowBlock, D.can_h, 1, &lg);
+    hipLaunchKernelGGL(k_stage0_fwd_multi, lg, dim3(kRowBlock), 0, st, mf, src,
+                       src_cstride, src_rstride, img_partials, img_nblk, n_img, stats, norm_rows, norm_count, none, none, 0, ig);
     return;
   }
   if (img_nblk > 0)
@@ -956,17 +981,18 @@ static void launch_stage_bwd(const DStage& D, const CanvasGrad& cg, float* gsrc,
   const int rowblk = 128;   // two waves along x: little waste on the last chunk of a 336 / 512 / 672-wide row
   if (!g_generic_kernels && (long long)D.src_h * D.src_w >= kRows3MinPositions) {
     // the taps of one canvas row loaded together where canvas_grad_at has one of the three shapes that occur (stage_bwd3_rows)
-    const int mode = (!g_row_batch || D.ttw.stride > 8) ? 0
+    const int mode = (!g_row_batch || D.ttw.stride > 10) ? 0
                      : (cg.copies == 1 && !cg.dgrad)    ? 1
                      : (cg.copies == 1 && cg.dgrad)     ? 2
                      : (cg.copies == 2 && !cg.dgrad)    ? 3
                                                         : 0;
-    const dim3 grid((D.src_w + rowblk - 1) / rowblk, D.src_h);
+    dim3 grid;
+    const ImgGrid ig = img_grid((D.src_w + rowblk - 1) / rowblk, D.src_h, 1, &grid);
     switch (mode) {
-      case 1: hipLaunchKernelGGL(k_stage_bwd3_rb<1>, grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc); break;
-      case 2: hipLaunchKernelGGL(k_stage_bwd3_rb<2>, grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc); break;
-      case 3: hipLaunchKernelGGL(k_stage_bwd3_rb<3>, grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc); break;
-      default: hipLaunchKernelGGL(k_stage_bwd3, grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc); break;
+      case 1: hipLaunchKernelGGL(k_stage_bwd3_rb<1>, grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc, ig); break;
+      case 2: hipLaunchKernelGGL(k_stage_bwd3_rb<2>, grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc, ig); break;
+      case 3: hipLaunchKernelGGL(k_stage_bwd3_rb<3>, grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc, ig); break;
+      default: hipLaunchKernelGGL(k_stage_bwd3, grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc, ig); break;
     }
   } else
     hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc);
@@ -1125,17 +1151,22 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
       tr_blocks = (rows + kRowBlock - 1) / kRowBlock;
       if ((long long)gx0 * max_h < 2LL * tr_blocks) tr_blocks = 0;       // no room in one layer: the emit's fallback below
     }
+    // several plans: the grid is sized for the largest canvas and the smaller ones leave whole groups idle - round robin
+    // (measured on Phi-3.5 + Qwen2-VL + Mllama: 12.5 us, 13.3 with groups)
+    dim3 lg;
     if (tr_blocks > 0) {
-      hipLaunchKernelGGL(k_stage0_fwd_multi, dim3(gx0, max_h, n + 1), dim3(kRowBlock), 0, st, mf, argument,
+      const ImgGrid ig = img_grid(gx0, max_h, n, &lg, 2u * (unsigned)tr_blocks, n == 1);
+      hipLaunchKernelGGL(k_stage0_fwd_multi, lg, dim3(kRowBlock), 0, st, mf, argument,
                          (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats,
-                         (const double*)nullptr, 0, rider.t[0], rider.t[1], tr_blocks, g_row_batch);
+                         (const double*)nullptr, 0, rider.t[0], rider.t[1], tr_blocks, ig);
       rider = no_rider();
     } else {
       TapBuild none;
       std::memset(&none, 0, sizeof(none));
-      hipLaunchKernelGGL(k_stage0_fwd_multi, dim3(gx0, max_h, n), dim3(kRowBlock), 0, st, mf, argument,
+      const ImgGrid ig = img_grid(gx0, max_h, n, &lg, 0, n == 1);
+      hipLaunchKernelGGL(k_stage0_fwd_multi, lg, dim3(kRowBlock), 0, st, mf, argument,
                          (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats,
-                         (const double*)nullptr, 0, none, none, 0, g_row_batch);
+                         (const double*)nullptr, 0, none, none, 0, ig);
     }
   }
   LAUNCH_CHECK();

@@ -219,26 +219,32 @@ __device__ inline double wave_sum_to_last_lane(double v) {
   return s;
 }
 
-// Block-wide sum of NS doubles per thread; thread 0 writes the NS totals to dst.
+// Block-wide sum of NS doubles per thread -> dst[0..NS) (written by one lane; visible to the block after the call).
+// Order (fixed, so the totals are bitwise reproducible): per lane position the waves 0..nw-1 in turn, then the DPP tree
+// over the 64 positions.  Rounds 1-3 ran the tree in EVERY wave and added the four wave totals last: NS x 21 VALU
+// instructions in each wave of every workgroup of the image-sized launches, which are bound by the instructions their SIMDs
+// have to issue (k_plan_tail: ~150 of ~700 per thread).  Now the waves above 0 store their NS values and are done; wave 0
+// reads them, adds and runs the NS trees: (NS x 27 + 3 x NS) / 4 per wave on average.  (Blocks of 64..kBlock threads, a
+// multiple of 64.)
 template <int NS>
 __device__ inline void block_sum_store(const double (&acc)[NS], double* dst) {
-  __shared__ double red[16][NS];  // up to 1024 threads
-  int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  __shared__ double red[NS][kBlock];
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave, nw = (int)(blockDim.x / kWave);
+  if (wid > 0) {
 #pragma unroll
-  for (int k = 0; k < NS; ++k) {
-    double v = wave_sum_to_last_lane(acc[k]);
-    if (lane == kWave - 1) red[wid][k] = v;
+    for (int k = 0; k < NS; ++k) red[k][threadIdx.x] = acc[k];
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (wid == 0) {
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-      double t = 0.0;
-      for (int w = 0; w < (int)(blockDim.x / kWave); ++w) t += red[w][k];
-      dst[k] = t;
+      double v = acc[k];
+      for (int w = 1; w < nw; ++w) v += red[k][w * kWave + lane];
+      v = wave_sum_to_last_lane(v);
+      if (lane == kWave - 1) dst[k] = v;
     }
   }
-  __syncthreads();  // `red` may be reused by a following call
+  __syncthreads();  // dst may be shared memory; `red` may be reused by a following call
 }
 
 // ----------------------------------------------------------------------- Philox noise
@@ -304,6 +310,39 @@ __device__ inline float4 philox_normal4_pixel(unsigned long long i, unsigned bq,
                                               unsigned long long seed) {
   // distinct from philox_normal4's counter space through the key (seed high word is perturbed)
   return philox_normal4(i, (offset << 20) | (unsigned long long)(bq & 0xFFFFFu), seed ^ 0x9E3779B97F4A7C15ULL);
+}
+
+// XCD-aware block map of the image-sized (column chunk, row, layer) grids (ADVX_TUNE_IMG_XCD, round 4).  Dealt round-robin,
+// the workgroups of every row land on all 8 XCDs and each XCD's L2 fetches the WHOLE source of a resize (8 x 3.1 MB at
+// 512 x 512 where 3.1 MB are needed).  Launched 1-D with the grid padded to a multiple of 8, physical block b runs on XCD
+// b % 8 (guide: workgroup dispatch).  The logical blocks are cut into GROUPS of `group` consecutive ones (host: a few rows
+// of column chunks) that are dealt to the XCDs in turn: XCD k's i-th block is logical block ((i / group) * 8 + k) * group +
+// i % group.  One XCD then fetches the source rows of its row groups (+ the window's halo) only - and, unlike whole bands of
+// rows per XCD (measured: a crop window that leaves the first and last rows of the image empty, or a multi-plan grid sized
+// for its largest canvas, left some XCDs without work and cost 1-4 us), every XCD gets the same share of every region.
+struct BlockXYZ { unsigned x, y, z; };
+// the logical grid of a launch (host: img_grid).  extra: blocks appended behind the gx * gy * gz of the grid (riders: table
+// builders); they come back as z == gz, x = index
+struct ImgGrid { int banded; unsigned gx, gy, gz, extra, group; };
+__device__ inline bool xcd_band_block(const ImgGrid& ig, BlockXYZ& b) {
+  if (!ig.banded) {
+    b.x = blockIdx.x; b.y = blockIdx.y; b.z = blockIdx.z;
+    return true;
+  }
+  const unsigned gx = ig.gx, gy = ig.gy, gz = ig.gz;
+  const unsigned k = blockIdx.x & 7u, i = blockIdx.x >> 3;
+  const unsigned q = i / ig.group;
+  const unsigned L = (q * 8u + k) * ig.group + (i - q * ig.group);
+  const unsigned body = gx * gy * gz;
+  if (L >= body) {
+    b.x = L - body; b.y = 0; b.z = gz;
+    return L - body < ig.extra;
+  }
+  const unsigned t = L / gx;
+  b.x = L - t * gx;
+  b.z = t / gy;
+  b.y = t - b.z * gy;
+  return true;
 }
 
 }  // namespace advx

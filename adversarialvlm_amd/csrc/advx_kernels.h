@@ -48,13 +48,50 @@ __global__ void __launch_bounds__(kBlock) k_prep(const float* __restrict__ p, co
   if (WRITE_S) block_sum_store<kStatSlots>(acc, partials + (size_t)blockIdx.x * kStatSlots);
 }
 
+#ifndef ADVX_FINALIZE_U
+#define ADVX_FINALIZE_U 8      // rows in flight per thread in the ||g|| reductions that ride in block 0 of the image-sized launches (1: rounds 1-3)
+#endif
+#ifndef ADVX_FINALIZE_IMG_U
+#define ADVX_FINALIZE_IMG_U 4  // ... and in the statistics reductions there (six doubles per row)
+#endif
+constexpr int kFinU = ADVX_FINALIZE_U;
+constexpr int kFinImgU = ADVX_FINALIZE_IMG_U;
+
 // one whole block: reduce the per-block partials, [rotate SIGMA <- QERR_STD], write stats
-template <bool ROTATE>
+// The plain loop (U = 1) waits for memory once per row - and the rows were written by the launch before, on other XCDs: a
+// thread of the ONE block that reduces 768 rows of a 512 x 512 blur (3072 of the prepared chain, twice that at 128 threads)
+// waits 6 (12, 24) full memory latencies in a row while the launch's other workgroups have long finished: this block was a
+// large part of the "6-12 us whatever they move" of the image-sized launches (round 4: k_stage_fwd_t 10.9 -> 7.2 us,
+// Qwen2-VL's k_stage0_fwd_multi 8.7 -> 7.8; 6.7 without any reduction).  U > 1: U rows in flight per thread in registers
+// (from a clamped row where the thread has none), added in the loop's order: the same bits.  12 U VGPRs for the statistics'
+// six doubles per row: U = 4 keeps every launch at <= 64 VGPRs (8 waves per SIMD); at U = 8 the heavy launches lost more
+// occupancy than the reduction gave back (k_plan_tail 18.0 -> 22.2 us, Phi-3.5's k_stage0_fwd_multi 8.9 -> 9.9).
+template <bool ROTATE, int U = 1>
 __device__ inline void finalize_image_block(const double* __restrict__ partials, int nblk, long long n,
                                             float* __restrict__ stats) {
   double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
-  for (int b = threadIdx.x; b < nblk; b += blockDim.x)
-    for (int k = 0; k < kStatSlots; ++k) acc[k] += partials[(size_t)b * kStatSlots + k];
+  if (U > 1) {
+    const int step = (int)blockDim.x;
+    for (int b0 = threadIdx.x; b0 < nblk; b0 += U * step) {
+      double r[U][kStatSlots];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int b = min(b0 + u * step, nblk - 1);
+#pragma unroll
+        for (int k = 0; k < kStatSlots; ++k) r[u][k] = partials[(size_t)b * kStatSlots + k];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (b0 + u * step < nblk) {
+#pragma unroll
+          for (int k = 0; k < kStatSlots; ++k) acc[k] += r[u][k];
+        }
+      }
+    }
+  } else {
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x)
+      for (int k = 0; k < kStatSlots; ++k) acc[k] += partials[(size_t)b * kStatSlots + k];
+  }
   __shared__ double tot[kStatSlots];
   block_sum_store<kStatSlots>(acc, tot);
   if (threadIdx.x == 0) {
@@ -74,13 +111,26 @@ __device__ inline void finalize_image_block(const double* __restrict__ partials,
 }
 __global__ void __launch_bounds__(kBlock) k_finalize_image(const double* __restrict__ partials, int nblk,
                                                            long long n, float* __restrict__ stats) {
-  finalize_image_block<true>(partials, nblk, n, stats);
+  finalize_image_block<true, kFinImgU>(partials, nblk, n, stats);
 }
 
 // one whole block: ||g||_2 from per-block sums of squares -> stats[GRAD_NORM]
+template <int U = 1>   // as finalize_image_block's (one double per row: U = 8 is 16 VGPRs)
 __device__ inline void finalize_norm_block(const double* __restrict__ partials, int nblk, float* __restrict__ stats) {
   double acc[1] = {0.0};
-  for (int b = threadIdx.x; b < nblk; b += blockDim.x) acc[0] += partials[b];
+  if (U == 1) {
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) acc[0] += partials[b];
+  } else {
+    const int step = (int)blockDim.x;
+    for (int b0 = threadIdx.x; b0 < nblk; b0 += U * step) {
+      double r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) r[u] = partials[min(b0 + u * step, nblk - 1)];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (b0 + u * step < nblk) acc[0] += r[u];
+    }
+  }
   __shared__ double tot1[1];
   block_sum_store<1>(acc, tot1);
   if (threadIdx.x == 0) stats[7] = (float)sqrt(tot1[0]);
@@ -101,8 +151,8 @@ __global__ void __launch_bounds__(kBlock) k_fused_flush(FusedHeader* __restrict_
                                                         int image_too, float* __restrict__ stats) {
   int ib = image_too ? hdr->image_blocks : 0, nb = hdr->norm_blocks;
   __syncthreads();
-  if (ib > 0) finalize_image_block<true>(img_partials, ib, n, stats);
-  if (nb > 0) finalize_norm_block(norm_partials, nb, stats);
+  if (ib > 0) finalize_image_block<true, kFinImgU>(img_partials, ib, n, stats);
+  if (nb > 0) finalize_norm_block<kFinU>(norm_partials, nb, stats);
   if (threadIdx.x == 0) {
     if (image_too) hdr->image_blocks = 0;
     hdr->norm_blocks = 0;
@@ -567,7 +617,7 @@ __global__ void __launch_bounds__(kBlock) k_stage_fwd_img(DStage st, const float
                                                           int src_rstride, float* __restrict__ canvas,
                                                           const double* __restrict__ img_partials, int nblk, long long n_img,
                                                           float* __restrict__ stats) {
-  if (blockIdx.x == 0 && nblk > 0) finalize_image_block<true>(img_partials, nblk, n_img, stats);
+  if (blockIdx.x == 0 && nblk > 0) finalize_image_block<true, kFinImgU>(img_partials, nblk, n_img, stats);
   long long n = 3LL * st.can_h * st.can_w;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
@@ -642,9 +692,11 @@ __global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, CanvasGrad cg, 
 // flight.  For sources large enough that a third of the threads still fills the device (Phi-3.5's 672 x 672 hd canvas:
 // 12.5 -> see DESIGN.md 5); at 113 k positions the same form was slower (two waves per SIMD, k_stage0_bwd_multi below).
 __global__ void __launch_bounds__(kBlock) k_stage_bwd3(DStage st, CanvasGrad cg, float* __restrict__ gsrc,
-                                                       long long gsrc_cstride, int gsrc_rstride, int accumulate) {
-  const int ys = blockIdx.y;
-  const int xs = blockIdx.x * blockDim.x + threadIdx.x;
+                                                       long long gsrc_cstride, int gsrc_rstride, int accumulate, ImgGrid ig) {
+  BlockXYZ blk;
+  if (!xcd_band_block(ig, blk)) return;
+  const int ys = blk.y;
+  const int xs = blk.x * blockDim.x + threadIdx.x;
   if (xs >= st.src_w) return;
   const size_t o = (size_t)ys * gsrc_rstride + xs;
   float before[3] = {0.0f, 0.0f, 0.0f};
@@ -677,8 +729,18 @@ __global__ void __launch_bounds__(kBlock) k_stage_bwd3(DStage st, CanvasGrad cg,
   }
 }
 
-// k_stage_bwd3 with the taps of one canvas row loaded together (see gather_rows3 below: the same idea, here over the
-// canvas gradient; COPIES / DG fix canvas_grad_at's shape at compile time so that nothing sits between the loads).
+// k_stage_bwd3 with the taps of one canvas ROW loaded together (round 4, ADVX_TUNE_ROW_BATCH).  The run-time loops of
+// k_stage_bwd3 wait for memory once per TAP: the inner loop issues one weight and three gradient loads, `s_waitcnt vmcnt(0)`,
+// three multiply-adds - a window of 5 x 5 taps is 25 round trips behind one another in a launch that has a few waves per SIMD
+// to hide them.  Here the column weights are loaded once per thread, the taps of one row of the window (TB >= the table's row
+// length, a compile-time bound) together for the three channels, and only the rows are walked at run time (their count is
+// uniform: the row of a workgroup is): oyc round trips, and no load of a row the window does not have (what the T x T
+// windows of advx_resize.h pay from 5 x 5 on).  Taps beyond a column's count are read from the last valid tap's address and
+// never enter the sum; the in-range taps are accumulated by the same operations in the same order: bit-identical.
+// COPIES / DG fix canvas_grad_at's shape at compile time so that nothing sits between the loads.
+// Measured (profiles/r04): Qwen2-VL 512 10.3 -> 6.3 us, Phi-3.5 10.2 -> 8.6, cross 9.5 -> 7.8, the composed crop window's
+// 9-tap rows 11.8 -> 9.4.  The same form of the FORWARD gather (k_stage0_fwd_multi) was level at <= 4 taps and slower on
+// the composed crop's 8-tap rows (12.8 -> 13.6): not kept.
 template <int TB, int COPIES, bool DG>
 __device__ inline void stage_bwd3_rows(const DStage& st, const CanvasGrad& cg, int ys, int xs, float (&v)[3]) {
   const int oy = st.tth.start[ys], oyc = st.tth.count[ys];
@@ -698,7 +760,7 @@ __device__ inline void stage_bwd3_rows(const DStage& st, const CanvasGrad& cg, i
   for (int a = 0; a < oyc; ++a) {
     const size_t row = (size_t)(st.off_y + oy + a) * st.can_w + st.off_x + ox;
     const float wa = wy[a];
-    float r[3][TB][COPIES + (DG ? 1 : 0)];
+    float r[3][TB][COPIES + 1];     // [COPIES]: dgrad (DG)
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -731,15 +793,18 @@ __device__ inline bool stage_bwd3_rows_any(const DStage& st, const CanvasGrad& c
   else if (T <= 4) stage_bwd3_rows<4, COPIES, DG>(st, cg, ys, xs, v);
   else if (T <= 6) stage_bwd3_rows<6, COPIES, DG>(st, cg, ys, xs, v);
   else if (T <= 8) stage_bwd3_rows<8, COPIES, DG>(st, cg, ys, xs, v);
+  else if (T <= 10) stage_bwd3_rows<10, COPIES, DG>(st, cg, ys, xs, v);
   else return false;
   return true;
 }
 // MODE: 1 = one copy, 2 = one copy + dgrad, 3 = two copies (Qwen2-VL's temporal pair)
 template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_stage_bwd3_rb(DStage st, CanvasGrad cg, float* __restrict__ gsrc, long long gsrc_cstride,
-                                                          int gsrc_rstride, int accumulate) {
-  const int ys = blockIdx.y;
-  const int xs = blockIdx.x * blockDim.x + threadIdx.x;
+                                                          int gsrc_rstride, int accumulate, ImgGrid ig) {
+  BlockXYZ blk;
+  if (!xcd_band_block(ig, blk)) return;
+  const int ys = blk.y;
+  const int xs = blk.x * blockDim.x + threadIdx.x;
   if (xs >= st.src_w) return;
   const size_t o = (size_t)ys * gsrc_rstride + xs;
   float before[3] = {0.0f, 0.0f, 0.0f};
@@ -821,104 +886,42 @@ __device__ inline void stage_fwd_value3(const DStage& st, const float* __restric
   for (int c = 0; c < 3; ++c) out[c] = st.normalise ? (v[c] - st.mean[c]) / st.stdv[c] : v[c];
 }
 
-// ROW-BATCHED gathers (round 4, ADVX_TUNE_ROW_BATCH).  The run-time loops above wait for memory once per TAP: the inner loop
-// issues one weight and three source loads, `s_waitcnt vmcnt(0)`, three multiply-adds - a window of 6 x 6 taps is 36 round
-// trips behind one another in a launch that has two or three waves per SIMD to hide them.  Here the taps of ONE ROW of the
-// window (TB >= the table's row length, a compile-time bound) are loaded together for the three channels, the column weights
-// once per thread, and only the rows are walked at run time (their count is uniform: the row of a workgroup is): yc round
-// trips, no load of a row the window does not have (what the T x T windows of advx_resize.h pay from 5 x 5 on).  Taps beyond
-// a column's count are read from the last valid tap's address and never enter the sum; the in-range taps are accumulated by
-// the same operations in the same order as in the loops: bit-identical results.
-template <int TB>
-__device__ inline void gather_rows3(const float* __restrict__ base, long long cstride, int rstride, int y0, int yc, int x0, int xc,
-                                    const float* __restrict__ wy, const float* __restrict__ wx, float (&v)[3]) {
-  float wv[TB];
-  int off[TB];
-  const int last = max(xc - 1, 0);
-#pragma unroll
-  for (int k = 0; k < TB; ++k) {
-    off[k] = min(k, last);
-    wv[k] = wx[off[k]];
-  }
-  v[0] = v[1] = v[2] = 0.0f;
-  for (int a = 0; a < yc; ++a) {
-    const float* rowp = base + (size_t)(y0 + a) * rstride + x0;
-    const float wa = wy[a];
-    float r[3][TB];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int k = 0; k < TB; ++k) r[c][k] = rowp[(size_t)c * cstride + off[k]];
-    float h[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int k = 0; k < TB; ++k) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) h[c] = (k < xc) ? h[c] + wv[k] * r[c][k] : h[c];
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) v[c] += wa * h[c];
-  }
-}
-// -> false: the table's rows are longer than the largest compiled batch (the caller's loops take over)
-__device__ inline bool gather_rows3_any(int stride, const float* __restrict__ base, long long cstride, int rstride, int y0, int yc,
-                                        int x0, int xc, const float* __restrict__ wy, const float* __restrict__ wx, float (&v)[3]) {
-  if (stride <= 2) gather_rows3<2>(base, cstride, rstride, y0, yc, x0, xc, wy, wx, v);
-  else if (stride <= 4) gather_rows3<4>(base, cstride, rstride, y0, yc, x0, xc, wy, wx, v);
-  else if (stride <= 6) gather_rows3<6>(base, cstride, rstride, y0, yc, x0, xc, wy, wx, v);
-  else if (stride <= 8) gather_rows3<8>(base, cstride, rstride, y0, yc, x0, xc, wy, wx, v);
-  else return false;
-  return true;
-}
-
-// stage_fwd_value3 on the row-batched gather (column-inner nesting only; else, and for longer rows, the loops)
-__device__ inline void stage_fwd_value3_rb(const DStage& st, const float* __restrict__ src, long long src_cstride, int src_rstride,
-                                           int y, int x, float (&out)[3]) {
-  const int ry = y - st.off_y, rx = x - st.off_x;
-  if (st.inner_axis_h || st.tw.stride > 8 || !(ry >= 0 && ry < st.res_h && rx >= 0 && rx < st.res_w)) {
-    stage_fwd_value3(st, src, src_cstride, src_rstride, y, x, out);
-    return;
-  }
-  float v[3];
-  gather_rows3_any(st.tw.stride, src, src_cstride, src_rstride, st.th.start[ry], st.th.count[ry], st.tw.start[rx], st.tw.count[rx],
-                   st.th.w + (size_t)ry * st.th.stride, st.tw.w + (size_t)rx * st.tw.stride, v);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) out[c] = st.normalise ? (v[c] - st.mean[c]) / st.stdv[c] : v[c];
-}
-
 // grid = (column chunks of the widest canvas, rows of the tallest, plans)
 __global__ void __launch_bounds__(kBlock) k_stage0_fwd_multi(MultiFwd mf, const float* __restrict__ src, long long src_cstride,
                                                              int src_rstride, const double* __restrict__ img_partials, int nblk,
                                                              long long n_img, float* __restrict__ stats,
                                                              const double* __restrict__ norm_rows, int norm_count,
-                                                             TapBuild tr0 = TapBuild(), TapBuild tr1 = TapBuild(), int tr_blocks = 0,
-                                                             int row_batch = 0) {
+                                                             TapBuild tr0, TapBuild tr1, int tr_blocks, ImgGrid ig) {
+  BlockXYZ blk;
+  if (!xcd_band_block(ig, blk)) return;
   // nblk > 0: the image kernels of the same call left statistics partials; block (0,0,0) reduces them
   // here (k_emit, the consumer of sigma, is a later launch); norm_count > 0: the ||g|| partials of the prepared chain's tail
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-    if (nblk > 0) finalize_image_block<true>(img_partials, nblk, n_img, stats);
-    if (norm_count > 0) finalize_norm_block(norm_rows, norm_count, stats);
+  if (blk.x == 0 && blk.y == 0 && blk.z == 0) {
+    if (nblk > 0) finalize_image_block<true, kFinImgU>(img_partials, nblk, n_img, stats);
+    if (norm_count > 0) finalize_norm_block<kFinU>(norm_rows, norm_count, stats);
   }
   // tr_blocks > 0 (composed crop): the z == 0 layer of the grid - dispatched first - builds the TRANSPOSED rows of the
   // composed tables from the forward rows the image kernel before this launch finished (read only by the backward);
   // the plans follow at z - 1.  A latency-bound launch with a few waves per SIMD: the riders cost it nothing measurable.
-  int zplan = (int)blockIdx.z;
+  int zplan = (int)blk.z;
   if (tr_blocks > 0) {
-    if (blockIdx.z == 0) {
-      const int tb = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    // round-robin grid: the z == 0 layer; XCD-aware grid: 2 * tr_blocks blocks appended behind the plans' (a whole layer of
+    // mostly idle blocks in front would leave the first XCDs without work)
+    if (blk.z == (ig.banded ? ig.gz : 0u)) {
+      const int tb = ig.banded ? (int)blk.x : (int)(blk.y * ig.gx + blk.x);
       if (tb < tr_blocks) build_taps_row_c(tr0, tr0.row_lo + tb * (int)blockDim.x + (int)threadIdx.x);
       else if (tb < 2 * tr_blocks) build_taps_row_c(tr1, tr1.row_lo + (tb - tr_blocks) * (int)blockDim.x + (int)threadIdx.x);
       return;
     }
-    zplan -= 1;
+    if (!ig.banded) zplan -= 1;
   }
   const int k = zplan;
   const DStage& st = mf.st[k];
-  const int y = blockIdx.y;
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blk.y;
+  const int x = blk.x * blockDim.x + threadIdx.x;
   if (y < st.can_h && x < st.can_w) {
     float v[3];
-    if (row_batch) stage_fwd_value3_rb(st, src, src_cstride, src_rstride, y, x, v);
-    else stage_fwd_value3(st, src, src_cstride, src_rstride, y, x, v);
+    stage_fwd_value3(st, src, src_cstride, src_rstride, y, x, v);
     float* __restrict__ canvas = mf.canvas[k];
     const size_t plane = (size_t)st.can_h * st.can_w;
 #pragma unroll
@@ -1440,7 +1443,7 @@ constexpr int kNormCountSlot = 2048;
 __global__ void __launch_bounds__(kBlock) k_finalize_norm(const double* __restrict__ partials, int nblk,
                                                           float* __restrict__ stats) {
   if (nblk < 0) nblk = (int)partials[kNormCountSlot];
-  finalize_norm_block(partials, nblk, stats);
+  finalize_norm_block<kFinU>(partials, nblk, stats);
 }
 
 // Image-level backward tail and optimiser in ONE launch (no all-reduce in between): what
@@ -1810,7 +1813,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_tail(DStage st, CanvasGrad cg, 
   const unsigned plane = (unsigned)st.src_h * (unsigned)st.src_w;
   const long long n = 3LL * plane;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (blockIdx.x == 0 && img_rows_in_count > 0) finalize_image_block<true>(img_rows_in, img_rows_in_count, n, stats);
+  if (blockIdx.x == 0 && img_rows_in_count > 0) finalize_image_block<true, kFinImgU>(img_rows_in, img_rows_in_count, n, stats);
   double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
   double nacc[1] = {0.0};
   if (i < n) {
@@ -1860,7 +1863,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_tail_grad(DStage st, CanvasGrad
   const unsigned plane = (unsigned)st.src_h * (unsigned)st.src_w;
   const long long n = 3LL * plane;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (blockIdx.x == 0 && img_rows_in_count > 0) finalize_image_block<true>(img_rows_in, img_rows_in_count, n, stats);
+  if (blockIdx.x == 0 && img_rows_in_count > 0) finalize_image_block<true, kFinImgU>(img_rows_in, img_rows_in_count, n, stats);
   if (i < n) {
     const int c = (int)((unsigned)i / plane);
     const unsigned rem = (unsigned)i - (unsigned)c * plane;
@@ -1914,7 +1917,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_head(DStage st, const float* __
                                                       int src_rstride, float* __restrict__ canvas,
                                                       const double* __restrict__ norm_rows, int norm_count,
                                                       float* __restrict__ stats) {
-  if (blockIdx.x == 0 && norm_count > 0) finalize_norm_block(norm_rows, norm_count, stats);
+  if (blockIdx.x == 0 && norm_count > 0) finalize_norm_block<kFinU>(norm_rows, norm_count, stats);
   long long n = 3LL * st.can_h * st.can_w;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
@@ -2056,7 +2059,7 @@ __global__ void __launch_bounds__(kBlock) k_fused_step_wave(const float* __restr
 // finalise pending rows on demand (host reads stats)
 __global__ void __launch_bounds__(kBlock) k_step_flush(const double* __restrict__ norm_rows, int n_norm,
                                                        float* __restrict__ stats) {
-  if (n_norm > 0) finalize_norm_block(norm_rows, n_norm, stats);
+  if (n_norm > 0) finalize_norm_block<kFinU>(norm_rows, n_norm, stats);
 }
 
 // the generator on its own (tests, advx_philox_normal): batch row 0 of the stream k_emit uses

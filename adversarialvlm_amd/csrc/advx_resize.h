@@ -79,8 +79,8 @@ __global__ void __launch_bounds__(kRowBlock) k_stage_fwd_t(DStage st, const floa
                                                            long long n_img, const double* __restrict__ norm_rows,
                                                            int norm_count, float* __restrict__ stats) {
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-    if (img_nblk > 0) finalize_image_block<true>(img_partials, img_nblk, n_img, stats);
-    if (norm_count != 0) finalize_norm_block(norm_rows, norm_count < 0 ? (int)norm_rows[kNormCountSlot] : norm_count, stats);
+    if (img_nblk > 0) finalize_image_block<true, kFinImgU>(img_partials, img_nblk, n_img, stats);
+    if (norm_count != 0) finalize_norm_block<kFinU>(norm_rows, norm_count < 0 ? (int)norm_rows[kNormCountSlot] : norm_count, stats);
   }
   const int c = blockIdx.z, y = blockIdx.y;
   const int x = blockIdx.x * kRowBlock + threadIdx.x;

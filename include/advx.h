@@ -126,9 +126,11 @@ const char* advx_last_error(void);
                                      slices of a column block run on one XCD (one L2 fetches the shared canvas / v); 0: rounds 1-3 */
 #define ADVX_TUNE_BWD_XCD 7         /* 1 (default): the readers of B x P_out (advx_fused_bwd, the batch reductions) map their workgroups to column
                                      blocks as the writers do under ADVX_TUNE_XCD_MAP (measured: k_fused_bwd 21.0 -> 19.6 us); 0: rounds 1-3 */
-#define ADVX_TUNE_ROW_BATCH 8       /* 1 (default): the image-sized gathers (stage 0 forward of advx_emit_multi / advx_forward_multi, the transposed
-                                     resize of advx_collect*) load the taps of one window row together; 0: one memory round trip per tap (rounds 1-3).
-                                     Same results bit for bit */
+#define ADVX_TUNE_IMG_XCD 9         /* rows per group (default 8) of the XCD-aware grids of the image-sized gathers: launched 1-D, groups of that many
+                                     rows of workgroups are dealt to the 8 XCDs in turn, so that one XCD's L2 fetches the source rows of its groups only;
+                                     0: (column chunk, row, layer) grids dealt round-robin workgroup by workgroup (rounds 1-3).  Same results */
+#define ADVX_TUNE_ROW_BATCH 8       /* 1 (default): the transposed resize of advx_collect* loads the taps of one window row together;
+                                     0: one memory round trip per tap (rounds 1-3).  Same results bit for bit */
 #define ADVX_TUNE_PAIR_NT_LOADS 2   /* advx_fused_bwd reads grad_out with non-temporal loads (same results) */
 #define ADVX_TUNE_SEPARATE_CROP 4   /* 1: never compose a crop window with a plan's stage 0 (advx_forward_multi) - the window is resized
                                      * into `argument` and the plan resamples that, two launches each way, bit-identical to the
