@@ -236,10 +236,19 @@ __device__ inline void block_sum_store(const double (&acc)[NS], double* dst) {
   }
   __syncthreads();
   if (wid == 0) {
+    // every value of the other waves is read before the first addition (one LDS round trip, not one per wave and slot)
+    constexpr int MW = kBlock / kWave;
+    double o[NS][MW - 1];
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+#pragma unroll
+      for (int w = 1; w < MW; ++w) o[k][w - 1] = (w < nw) ? red[k][w * kWave + lane] : 0.0;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       double v = acc[k];
-      for (int w = 1; w < nw; ++w) v += red[k][w * kWave + lane];
+#pragma unroll
+      for (int w = 1; w < MW; ++w)
+        if (w < nw) v += o[k][w - 1];
       v = wave_sum_to_last_lane(v);
       if (lane == kWave - 1) dst[k] = v;
     }
