@@ -2901,9 +2901,24 @@ extern "C" int32_t advx_prepared_bwd(advx_plan* p, const float* grad_out, int32_
   if (rc) return rc;
   prepared_upper_bwd(p, ws, st);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_plan_tail, dim3(f.tail_blocks), dim3(kBlock), 0, st, D, stage_grad(p, 0, ws), pp, x0, eps,
-                     imgfit_scale / (float)n, mask, m, v, grad_p, to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows,
-                     (const double*)f.img_rows[parity], (int)rows_in, stats);
+  {
+    // the transposed gather as a compiled window where the tables' rows fit one (<= 4 taps) and the canvas gradient has one
+    // of the three shapes that occur; else the run-time loops
+    const CanvasGrad cg = stage_grad(p, 0, ws);
+    const int T = pick_window(std::max(D.tth.stride, D.ttw.stride));
+    const int mode = (cg.copies == 1 && !cg.dgrad) ? 1 : (cg.copies == 1 && cg.dgrad) ? 2 : (cg.copies == 2 && !cg.dgrad) ? 3 : 0;
+#define ADVX_TAIL(T_, M_)                                                                                              \
+  hipLaunchKernelGGL((k_plan_tail<T_, M_>), dim3(f.tail_blocks), dim3(kBlock), 0, st, D, cg, pp, x0, eps,               \
+                     imgfit_scale / (float)n, mask, m, v, grad_p, to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows, \
+                     (const double*)f.img_rows[parity], (int)rows_in, stats)
+#define ADVX_TAIL_M(T_) do { if (mode == 1) ADVX_TAIL(T_, 1); else if (mode == 2) ADVX_TAIL(T_, 2); else ADVX_TAIL(T_, 3); } while (0)
+    if (!T || !mode) ADVX_TAIL(0, 0);
+    else if (T == 2) ADVX_TAIL_M(2);
+    else if (T == 3) ADVX_TAIL_M(3);
+    else ADVX_TAIL_M(4);
+#undef ADVX_TAIL_M
+#undef ADVX_TAIL
+  }
   LAUNCH_CHECK();
   prepared_canvases(p, s_next, ws, f.norm_rows, f.tail_blocks, stats, st);
   LAUNCH_CHECK();

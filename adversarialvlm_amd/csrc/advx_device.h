@@ -256,6 +256,45 @@ __device__ inline void block_sum_store(const double (&acc)[NS], double* dst) {
   __syncthreads();  // dst may be shared memory; `red` may be reused by a following call
 }
 
+// Two block sums in one pass (the statistics partials and the ||g|| partial of the same workgroup): one LDS exchange and
+// one pair of barriers instead of two.  Per slot the additions are block_sum_store's, in its order.
+template <int NA, int NB>
+__device__ inline void block_sum_store2(const double (&a)[NA], double* dst_a, const double (&b)[NB], double* dst_b) {
+  constexpr int NS = NA + NB, MW = kBlock / kWave;
+  __shared__ double red[NS][kBlock];
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave, nw = (int)(blockDim.x / kWave);
+  double acc[NS];
+#pragma unroll
+  for (int k = 0; k < NA; ++k) acc[k] = a[k];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) acc[NA + k] = b[k];
+  if (wid > 0) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) red[k][threadIdx.x] = acc[k];
+  }
+  __syncthreads();
+  if (wid == 0) {
+    double o[NS][MW - 1];
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+#pragma unroll
+      for (int w = 1; w < MW; ++w) o[k][w - 1] = (w < nw) ? red[k][w * kWave + lane] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      double v = acc[k];
+#pragma unroll
+      for (int w = 1; w < MW; ++w)
+        if (w < nw) v += o[k][w - 1];
+      v = wave_sum_to_last_lane(v);
+      if (lane == kWave - 1) {
+        if (k < NA) dst_a[k] = v;
+        else dst_b[k - NA] = v;
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // ----------------------------------------------------------------------- Philox noise
 // Philox4x32 (Salmon et al., SC'11) with the standard 10 rounds
 #ifndef ADVX_PHILOX_ROUNDS

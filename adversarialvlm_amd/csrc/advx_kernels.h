@@ -1804,6 +1804,56 @@ __global__ void __launch_bounds__(kBlock) k_fused_update(float* __restrict__ p, 
 // A plan with a second stage fed by the first canvas (Phi-3.5: bicubic global view of the HD
 // canvas) adds k_stage_bwd of that stage before the tail (its gradient reaches the tail through
 // `dgrad`) and k_stage_fwd of it after the head.
+// stage_bwd_value with a T x T window (T >= the transposed tables' row length): every load of the gather is issued before
+// the first use, taps beyond a row's count come from the last valid tap's address and never enter the sum; the in-range
+// taps are accumulated by stage_bwd_value's operations in its order (bit-identical).  MODE fixes canvas_grad_at's shape:
+// 1 = one copy, 2 = one copy + dgrad, 3 = two copies.
+template <int T, int MODE>
+__device__ inline float stage_bwd_value_w(const DStage& st, const CanvasGrad& cg, int c, int ys, int xs) {
+  constexpr int COPIES = (MODE == 3) ? 2 : 1;
+  constexpr bool DG = MODE == 2;
+  const int oy = st.tth.start[ys], oyc = st.tth.count[ys];
+  const int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
+  const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
+  const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
+  const int ly = max(oyc - 1, 0), lx = max(oxc - 1, 0);
+  float wyv[T], wxv[T], r[T][T][COPIES + 1];
+#pragma unroll
+  for (int a = 0; a < T; ++a) {
+    wyv[a] = wy[min(a, ly)];
+    wxv[a] = wx[min(a, lx)];
+  }
+#pragma unroll
+  for (int a = 0; a < T; ++a) {
+    const size_t row = ((size_t)c * st.can_h + (st.off_y + oy + min(a, ly))) * st.can_w + st.off_x + ox;
+#pragma unroll
+    for (int b = 0; b < T; ++b) {
+      const size_t o = row + min(b, lx);
+#pragma unroll
+      for (int t = 0; t < COPIES; ++t) r[a][b][t] = cg.g[(size_t)t * cg.copy_stride + o];
+      if (DG) r[a][b][COPIES] = cg.dgrad[o];
+    }
+  }
+  float v = 0.0f;
+#pragma unroll
+  for (int a = 0; a < T; ++a) {
+    float h = 0.0f;
+#pragma unroll
+    for (int b = 0; b < T; ++b) {
+      float g = 0.0f;                                  // canvas_grad_at: the copies in order, then dgrad
+#pragma unroll
+      for (int t = 0; t < COPIES; ++t) g += r[a][b][t];
+      if (DG) g += r[a][b][COPIES];
+      h = (b < oxc) ? h + wxv[b] * g : h;
+    }
+    v = (a < oyc) ? v + wyv[a] * h : v;
+  }
+  if (st.normalise) v = v / st.stdv[c];
+  return v;
+}
+
+// T, MODE: the transposed gather as a compiled window (stage_bwd_value_w); T = 0: stage_bwd_value's run-time loops
+template <int T, int MODE>
 __global__ void __launch_bounds__(kBlock) k_plan_tail(DStage st, CanvasGrad cg, float* __restrict__ p, const float* __restrict__ x0, float eps,
                                                       float c_fit, const float* __restrict__ mask, float* __restrict__ m,
                                                       float* __restrict__ v, float* __restrict__ grad_p, OptScalars o,
@@ -1829,7 +1879,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_tail(DStage st, CanvasGrad cg, 
     const int ys = (int)(rem / (unsigned)st.src_w), xs = (int)(rem - (unsigned)ys * (unsigned)st.src_w);
     const float t = tanhf(pp);
     const float s = xv + eps * t;
-    const float gs = stage_bwd_value(st, cg, c, ys, xs);
+    const float gs = (T > 0) ? stage_bwd_value_w<(T > 0 ? T : 1), (MODE > 0 ? MODE : 1)>(st, cg, c, ys, xs) : stage_bwd_value(st, cg, c, ys, xs);
     float gp = ((gs + imgfit_grad(s, c_fit)) * eps) * (1.0f - t * t);
     gp = gp * mk;
     nacc[0] = (double)gp * (double)gp;
@@ -1847,8 +1897,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_tail(DStage st, CanvasGrad cg, 
     s_next[i] = sn;
     stat_accumulate(sn, xn, acc);
   }
-  block_sum_store<kStatSlots>(acc, img_rows_out + (size_t)blockIdx.x * kStatSlots);
-  block_sum_store<1>(nacc, norm_rows + blockIdx.x);
+  block_sum_store2<kStatSlots, 1>(acc, img_rows_out + (size_t)blockIdx.x * kStatSlots, nacc, norm_rows + blockIdx.x);
 }
 
 // Data parallelism splits the tail around the exchange of the image gradient:
@@ -1909,8 +1958,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_update(float* __restrict__ p, f
     s_next[i] = sn;
     stat_accumulate(sn, xn, acc);
   }
-  block_sum_store<kStatSlots>(acc, img_rows_out + (size_t)blockIdx.x * kStatSlots);
-  block_sum_store<1>(nacc, norm_rows + blockIdx.x);
+  block_sum_store2<kStatSlots, 1>(acc, img_rows_out + (size_t)blockIdx.x * kStatSlots, nacc, norm_rows + blockIdx.x);
 }
 
 __global__ void __launch_bounds__(kBlock) k_plan_head(DStage st, const float* __restrict__ src, long long src_cstride,
