@@ -767,7 +767,7 @@ static void launch_stage_fwd(const DStage& D, const float* src, long long src_cs
     dim3 lg;
     const ImgGrid ig = img_grid((D.can_w + kRowBlock - 1) / kRowBlock, D.can_h, 1, &lg);
     hipLaunchKernelGGL(k_stage0_fwd_multi, lg, dim3(kRowBlock), 0, st, mf, src,
-                       src_cstride, src_rstride, img_partials, img_nblk, n_img, stats, norm_rows, norm_count, none, none, 0, ig);
+                       src_cstride, src_rstride, img_partials, img_nblk, n_img, stats, norm_rows, norm_count, none, none, 0, ig, g_generic_kernels ? 0 : g_row_batch);
     return;
   }
   if (img_nblk > 0)
@@ -988,6 +988,18 @@ static void launch_stage_bwd(const DStage& D, const CanvasGrad& cg, float* gsrc,
                                                         : 0;
     dim3 grid;
     const ImgGrid ig = img_grid((D.src_w + rowblk - 1) / rowblk, D.src_h, 1, &grid);
+    const int T = mode ? pick_window(std::max(D.tth.stride, D.ttw.stride)) : 0;
+    if (T) {
+      // tables of <= 4 taps per row: the whole window in flight (k_stage_bwd3_w)
+#define ADVX_B3W(T_, M_) hipLaunchKernelGGL((k_stage_bwd3_w<T_, M_>), grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc, ig)
+#define ADVX_B3W_M(T_) do { if (mode == 1) ADVX_B3W(T_, 1); else if (mode == 2) ADVX_B3W(T_, 2); else ADVX_B3W(T_, 3); } while (0)
+      if (T == 2) ADVX_B3W_M(2);
+      else if (T == 3) ADVX_B3W_M(3);
+      else ADVX_B3W_M(4);
+#undef ADVX_B3W_M
+#undef ADVX_B3W
+      return;
+    }
     switch (mode) {
       case 1: hipLaunchKernelGGL(k_stage_bwd3_rb<1>, grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc, ig); break;
       case 2: hipLaunchKernelGGL(k_stage_bwd3_rb<2>, grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc, ig); break;
@@ -1158,7 +1170,7 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
       const ImgGrid ig = img_grid(gx0, max_h, n, &lg, 2u * (unsigned)tr_blocks, n == 1);
       hipLaunchKernelGGL(k_stage0_fwd_multi, lg, dim3(kRowBlock), 0, st, mf, argument,
                          (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats,
-                         (const double*)nullptr, 0, rider.t[0], rider.t[1], tr_blocks, ig);
+                         (const double*)nullptr, 0, rider.t[0], rider.t[1], tr_blocks, ig, g_generic_kernels ? 0 : g_row_batch);
       rider = no_rider();
     } else {
       TapBuild none;
@@ -1166,7 +1178,7 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
       const ImgGrid ig = img_grid(gx0, max_h, n, &lg, 0, n == 1);
       hipLaunchKernelGGL(k_stage0_fwd_multi, lg, dim3(kRowBlock), 0, st, mf, argument,
                          (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats,
-                         (const double*)nullptr, 0, none, none, 0, ig);
+                         (const double*)nullptr, 0, none, none, 0, ig, g_generic_kernels ? 0 : g_row_batch);
     }
   }
   LAUNCH_CHECK();

@@ -797,6 +797,72 @@ __device__ inline bool stage_bwd3_rows_any(const DStage& st, const CanvasGrad& c
   else return false;
   return true;
 }
+// ... and with the whole T x T window in flight (tables of <= 4 taps per row): as stage_bwd_value_w, three channels
+template <int T, int MODE>
+__global__ void __launch_bounds__(kBlock) k_stage_bwd3_w(DStage st, CanvasGrad cg, float* __restrict__ gsrc, long long gsrc_cstride,
+                                                         int gsrc_rstride, int accumulate, ImgGrid ig) {
+  constexpr int COPIES = (MODE == 3) ? 2 : 1;
+  constexpr bool DG = MODE == 2;
+  BlockXYZ blk;
+  if (!xcd_band_block(ig, blk)) return;
+  const int ys = blk.y;
+  const int xs = blk.x * blockDim.x + threadIdx.x;
+  if (xs >= st.src_w) return;
+  const size_t o = (size_t)ys * gsrc_rstride + xs;
+  float before[3] = {0.0f, 0.0f, 0.0f};
+  if (accumulate) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) before[c] = gsrc[(size_t)c * gsrc_cstride + o];
+  }
+  const int oy = st.tth.start[ys], oyc = st.tth.count[ys];
+  const int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
+  const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
+  const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
+  const size_t plane = (size_t)st.can_h * st.can_w;
+  const int ly = max(oyc - 1, 0), lx = max(oxc - 1, 0);
+  float wyv[T], wxv[T], r[3][T][T][COPIES + 1];
+#pragma unroll
+  for (int a = 0; a < T; ++a) {
+    wyv[a] = wy[min(a, ly)];
+    wxv[a] = wx[min(a, lx)];
+  }
+#pragma unroll
+  for (int a = 0; a < T; ++a) {
+    const size_t row = (size_t)(st.off_y + oy + min(a, ly)) * st.can_w + st.off_x + ox;
+#pragma unroll
+    for (int b = 0; b < T; ++b)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const size_t q = (size_t)c * plane + row + min(b, lx);
+#pragma unroll
+        for (int t = 0; t < COPIES; ++t) r[c][a][b][t] = cg.g[(size_t)t * cg.copy_stride + q];
+        if (DG) r[c][a][b][COPIES] = cg.dgrad[q];
+      }
+  }
+  float v[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int a = 0; a < T; ++a) {
+    float h[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int b = 0; b < T; ++b)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float g = 0.0f;                                  // canvas_grad_at: the copies in order, then dgrad
+#pragma unroll
+        for (int t = 0; t < COPIES; ++t) g += r[c][a][b][t];
+        if (DG) g += r[c][a][b][COPIES];
+        h[c] = (b < oxc) ? h[c] + wxv[b] * g : h[c];
+      }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = (a < oyc) ? v[c] + wyv[a] * h[c] : v[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float rr = st.normalise ? v[c] / st.stdv[c] : v[c];
+    gsrc[(size_t)c * gsrc_cstride + o] = accumulate ? (before[c] + rr) : rr;
+  }
+}
+
 // MODE: 1 = one copy, 2 = one copy + dgrad, 3 = two copies (Qwen2-VL's temporal pair)
 template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_stage_bwd3_rb(DStage st, CanvasGrad cg, float* __restrict__ gsrc, long long gsrc_cstride,
@@ -886,12 +952,70 @@ __device__ inline void stage_fwd_value3(const DStage& st, const float* __restric
   for (int c = 0; c < 3; ++c) out[c] = st.normalise ? (v[c] - st.mean[c]) / st.stdv[c] : v[c];
 }
 
+// stage_fwd_value3 with a T x T window (T >= the tables' row lengths): every load issued before the first use, taps beyond a
+// row's count read from the last valid tap's address and never summed; the same operations in the same order (bit-identical).
+template <int T>
+__device__ inline void stage_fwd_value3_w(const DStage& st, const float* __restrict__ src, long long src_cstride, int src_rstride,
+                                          int y, int x, float (&out)[3]) {
+  const int ry = y - st.off_y, rx = x - st.off_x;
+  float v[3];
+  if (ry >= 0 && ry < st.res_h && rx >= 0 && rx < st.res_w) {
+    const int ys = st.th.start[ry], yc = st.th.count[ry];
+    const int xs = st.tw.start[rx], xc = st.tw.count[rx];
+    const float* wy = st.th.w + (size_t)ry * st.th.stride;
+    const float* wx = st.tw.w + (size_t)rx * st.tw.stride;
+    const int ly = max(yc - 1, 0), lx = max(xc - 1, 0);
+    float wyv[T], wxv[T], r[3][T][T];
+#pragma unroll
+    for (int a = 0; a < T; ++a) {
+      wyv[a] = wy[min(a, ly)];
+      wxv[a] = wx[min(a, lx)];
+    }
+#pragma unroll
+    for (int a = 0; a < T; ++a) {
+      const float* rowp = src + (size_t)(ys + min(a, ly)) * src_rstride + xs;
+#pragma unroll
+      for (int b = 0; b < T; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r[c][a][b] = rowp[(size_t)c * src_cstride + min(b, lx)];
+    }
+    v[0] = v[1] = v[2] = 0.0f;
+    if (!st.inner_axis_h) {
+#pragma unroll
+      for (int a = 0; a < T; ++a) {
+        float h[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int b = 0; b < T; ++b)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) h[c] = (b < xc) ? h[c] + wxv[b] * r[c][a][b] : h[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (a < yc) ? v[c] + wyv[a] * h[c] : v[c];
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < T; ++b) {
+        float h[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int a = 0; a < T; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) h[c] = (a < yc) ? h[c] + wyv[a] * r[c][a][b] : h[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (b < xc) ? v[c] + wxv[b] * h[c] : v[c];
+      }
+    }
+  } else {
+    v[0] = v[1] = v[2] = st.pad_value;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[c] = st.normalise ? (v[c] - st.mean[c]) / st.stdv[c] : v[c];
+}
+
 // grid = (column chunks of the widest canvas, rows of the tallest, plans)
 __global__ void __launch_bounds__(kBlock) k_stage0_fwd_multi(MultiFwd mf, const float* __restrict__ src, long long src_cstride,
                                                              int src_rstride, const double* __restrict__ img_partials, int nblk,
                                                              long long n_img, float* __restrict__ stats,
                                                              const double* __restrict__ norm_rows, int norm_count,
-                                                             TapBuild tr0, TapBuild tr1, int tr_blocks, ImgGrid ig) {
+                                                             TapBuild tr0, TapBuild tr1, int tr_blocks, ImgGrid ig, int windowed) {
   BlockXYZ blk;
   if (!xcd_band_block(ig, blk)) return;
   // nblk > 0: the image kernels of the same call left statistics partials; block (0,0,0) reduces them
@@ -921,7 +1045,11 @@ __global__ void __launch_bounds__(kBlock) k_stage0_fwd_multi(MultiFwd mf, const 
   const int x = blk.x * blockDim.x + threadIdx.x;
   if (y < st.can_h && x < st.can_w) {
     float v[3];
-    stage_fwd_value3(st, src, src_cstride, src_rstride, y, x, v);
+    const int tm = windowed ? max(st.th.stride, st.tw.stride) : 99;      // uniform: one path per workgroup
+    if (tm <= 2) stage_fwd_value3_w<2>(st, src, src_cstride, src_rstride, y, x, v);
+    else if (tm <= 3) stage_fwd_value3_w<3>(st, src, src_cstride, src_rstride, y, x, v);
+    else if (tm <= 4) stage_fwd_value3_w<4>(st, src, src_cstride, src_rstride, y, x, v);
+    else stage_fwd_value3(st, src, src_cstride, src_rstride, y, x, v);
     float* __restrict__ canvas = mf.canvas[k];
     const size_t plane = (size_t)st.can_h * st.can_w;
 #pragma unroll
