@@ -1006,8 +1006,19 @@ static void launch_stage_bwd(const DStage& D, const CanvasGrad& cg, float* gsrc,
       case 3: hipLaunchKernelGGL(k_stage_bwd3_rb<3>, grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc, ig); break;
       default: hipLaunchKernelGGL(k_stage_bwd3, grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc, ig); break;
     }
-  } else
-    hipLaunchKernelGGL(k_stage_bwd, dim3((D.src_w + rowblk - 1) / rowblk, D.src_h, 3), dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc);
+  } else {
+    const int mode = !g_row_batch ? 0 : (cg.copies == 1 && !cg.dgrad) ? 1 : (cg.copies == 1 && cg.dgrad) ? 2 : (cg.copies == 2 && !cg.dgrad) ? 3 : 0;
+    const int T = mode ? pick_window(std::max(D.tth.stride, D.ttw.stride)) : 0;
+    const dim3 grid((D.src_w + rowblk - 1) / rowblk, D.src_h, 3);
+#define ADVX_SBW(T_, M_) hipLaunchKernelGGL((k_stage_bwd<T_, M_>), grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc)
+#define ADVX_SBW_M(T_) do { if (mode == 1) ADVX_SBW(T_, 1); else if (mode == 2) ADVX_SBW(T_, 2); else ADVX_SBW(T_, 3); } while (0)
+    if (!T) ADVX_SBW(0, 0);
+    else if (T == 2) ADVX_SBW_M(2);
+    else if (T == 3) ADVX_SBW_M(3);
+    else ADVX_SBW_M(4);
+#undef ADVX_SBW_M
+#undef ADVX_SBW
+  }
 }
 // where the backward of a stage that reads canvas `src_canvas` writes, and whether it accumulates there
 static float* dgrad_target(const advx_plan* p, int src_canvas, float* ws, int* accumulate) {
@@ -1291,6 +1302,12 @@ extern "C" int32_t advx_collect_multi(int32_t n, advx_plan* const* plans, const 
     if (rc) return rc;
     mb.st[i] = p->dstage[0];
     mb.cg[i] = stage_grad(p, 0, wss[i]);
+    {
+      const CanvasGrad& cg = mb.cg[i];
+      const int mode = !g_row_batch ? 0 : (cg.copies == 1 && !cg.dgrad) ? 1 : (cg.copies == 1 && cg.dgrad) ? 2 : (cg.copies == 2 && !cg.dgrad) ? 3 : 0;
+      const int T = mode ? pick_window(std::max(mb.st[i].tth.stride, mb.st[i].ttw.stride)) : 0;
+      mb.win[i] = T ? 4 * std::max(mb.st[i].tth.stride, mb.st[i].ttw.stride) + mode : 0;
+    }
   }
   // the batch reductions: one launch for all plans when they read the same way (same boundary dtype, all cached or
   // all streamed), else one per plan
@@ -2959,8 +2976,21 @@ static int32_t prepared_grad_impl(advx_plan* p, const float* grad_out, int32_t b
   if (rc) return rc;
   prepared_upper_bwd(p, ws, st);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_plan_tail_grad, dim3(f.tail_blocks), dim3(kBlock), 0, st, D, stage_grad(p, 0, ws), pp, x0, eps,
-                     imgfit_scale / (float)n, grad_p, (const double*)f.img_rows[parity], (int)rows_in, stats);
+  {
+    const CanvasGrad cg = stage_grad(p, 0, ws);
+    const int T = pick_window(std::max(D.tth.stride, D.ttw.stride));
+    const int mode = (cg.copies == 1 && !cg.dgrad) ? 1 : (cg.copies == 1 && cg.dgrad) ? 2 : (cg.copies == 2 && !cg.dgrad) ? 3 : 0;
+#define ADVX_TG(T_, M_)                                                                                                   \
+  hipLaunchKernelGGL((k_plan_tail_grad<T_, M_>), dim3(f.tail_blocks), dim3(kBlock), 0, st, D, cg, pp, x0, eps,             \
+                     imgfit_scale / (float)n, grad_p, (const double*)f.img_rows[parity], (int)rows_in, stats)
+#define ADVX_TG_M(T_) do { if (mode == 1) ADVX_TG(T_, 1); else if (mode == 2) ADVX_TG(T_, 2); else ADVX_TG(T_, 3); } while (0)
+    if (!T || !mode) ADVX_TG(0, 0);
+    else if (T == 2) ADVX_TG_M(2);
+    else if (T == 3) ADVX_TG_M(3);
+    else ADVX_TG_M(4);
+#undef ADVX_TG_M
+#undef ADVX_TG
+  }
   LAUNCH_CHECK();
   return ADVX_OK;
 }

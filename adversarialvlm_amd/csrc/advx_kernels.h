@@ -674,8 +674,114 @@ __device__ inline float stage_bwd_value(const DStage& st, const CanvasGrad& cg, 
   return v;
 }
 
+// stage_bwd_value with a T x T window (T >= the transposed tables' row length): every load of the gather is issued before
+// the first use, taps beyond a row's count come from the last valid tap's address and never enter the sum; the in-range
+// taps are accumulated by stage_bwd_value's operations in its order (bit-identical).  MODE fixes canvas_grad_at's shape:
+// 1 = one copy, 2 = one copy + dgrad, 3 = two copies.
+template <int T, int MODE>
+__device__ inline float stage_bwd_value_w(const DStage& st, const CanvasGrad& cg, int c, int ys, int xs) {
+  constexpr int COPIES = (MODE == 3) ? 2 : 1;
+  constexpr bool DG = MODE == 2;
+  const int oy = st.tth.start[ys], oyc = st.tth.count[ys];
+  const int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
+  const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
+  const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
+  const int ly = max(oyc - 1, 0), lx = max(oxc - 1, 0);
+  float wyv[T], wxv[T], r[T][T][COPIES + 1];
+#pragma unroll
+  for (int a = 0; a < T; ++a) {
+    wyv[a] = wy[min(a, ly)];
+    wxv[a] = wx[min(a, lx)];
+  }
+#pragma unroll
+  for (int a = 0; a < T; ++a) {
+    const size_t row = ((size_t)c * st.can_h + (st.off_y + oy + min(a, ly))) * st.can_w + st.off_x + ox;
+#pragma unroll
+    for (int b = 0; b < T; ++b) {
+      const size_t o = row + min(b, lx);
+#pragma unroll
+      for (int t = 0; t < COPIES; ++t) r[a][b][t] = cg.g[(size_t)t * cg.copy_stride + o];
+      if (DG) r[a][b][COPIES] = cg.dgrad[o];
+    }
+  }
+  float v = 0.0f;
+#pragma unroll
+  for (int a = 0; a < T; ++a) {
+    float h = 0.0f;
+#pragma unroll
+    for (int b = 0; b < T; ++b) {
+      float g = 0.0f;                                  // canvas_grad_at: the copies in order, then dgrad
+#pragma unroll
+      for (int t = 0; t < COPIES; ++t) g += r[a][b][t];
+      if (DG) g += r[a][b][COPIES];
+      h = (b < oxc) ? h + wxv[b] * g : h;
+    }
+    v = (a < oyc) ? v + wyv[a] * h : v;
+  }
+  if (st.normalise) v = v / st.stdv[c];
+  return v;
+}
+
+// stage_bwd_value_w with the window size a UNIFORM run-time value T <= 4 (several plans in one launch, each with its own
+// tables: one code path per plan position instead of one per size): loads of rows / columns beyond T are skipped by scalar
+// branches, the rest is in flight together as in the compiled windows; same operations, same order.
+template <int MODE>
+__device__ inline float stage_bwd_value_wu(const DStage& st, const CanvasGrad& cg, int T, int c, int ys, int xs) {
+  constexpr int COPIES = (MODE == 3) ? 2 : 1;
+  constexpr bool DG = MODE == 2;
+  constexpr int TM = 4;
+  const int oy = st.tth.start[ys], oyc = st.tth.count[ys];
+  const int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
+  const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
+  const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
+  const int ly = max(oyc - 1, 0), lx = max(oxc - 1, 0);
+  float wyv[TM], wxv[TM], r[TM][TM][COPIES + 1];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    wyv[a] = wxv[a] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int t = 0; t <= COPIES; ++t) r[a][b][t] = 0.0f;
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    if (a < T) {
+      wyv[a] = wy[min(a, ly)];
+      wxv[a] = wx[min(a, lx)];
+      const size_t row = ((size_t)c * st.can_h + (st.off_y + oy + min(a, ly))) * st.can_w + st.off_x + ox;
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        if (b < T) {
+          const size_t o = row + min(b, lx);
+#pragma unroll
+          for (int t = 0; t < COPIES; ++t) r[a][b][t] = cg.g[(size_t)t * cg.copy_stride + o];
+          if (DG) r[a][b][COPIES] = cg.dgrad[o];
+        }
+      }
+    }
+  }
+  float v = 0.0f;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    float h = 0.0f;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      float g = 0.0f;
+#pragma unroll
+      for (int t = 0; t < COPIES; ++t) g += r[a][b][t];
+      if (DG) g += r[a][b][COPIES];
+      h = (b < oxc) ? h + wxv[b] * g : h;
+    }
+    v = (a < oyc) ? v + wyv[a] * h : v;
+  }
+  if (st.normalise) v = v / st.stdv[c];
+  return v;
+}
+
 // one thread per SOURCE element.  Grid = (column chunks, source rows, channels): the row of a
 // workgroup is uniform, so its taps and weights are scalar work, and no thread divides to find its pixel.
+template <int T = 0, int MODE = 0>   // T > 0: the gather as a compiled window (stage_bwd_value_w)
 __global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, CanvasGrad cg, float* __restrict__ gsrc,
                                                       long long gsrc_cstride, int gsrc_rstride, int accumulate) {
   const int c = blockIdx.z, ys = blockIdx.y;
@@ -683,7 +789,7 @@ __global__ void __launch_bounds__(kBlock) k_stage_bwd(DStage st, CanvasGrad cg, 
   if (xs < st.src_w) {
     const size_t o = (size_t)c * gsrc_cstride + (size_t)ys * gsrc_rstride + xs;
     const float before = accumulate ? gsrc[o] : 0.0f;     // in flight while the taps are gathered
-    const float v = stage_bwd_value(st, cg, c, ys, xs);
+    const float v = (T > 0) ? stage_bwd_value_w<(T > 0 ? T : 1), (MODE > 0 ? MODE : 1)>(st, cg, c, ys, xs) : stage_bwd_value(st, cg, c, ys, xs);
     gsrc[o] = accumulate ? (before + v) : v;
   }
 }
@@ -906,6 +1012,7 @@ struct MultiBwd {
   int n;
   DStage st[kMaxMulti];
   CanvasGrad cg[kMaxMulti];
+  int win[kMaxMulti];     // per plan: 4 * T + MODE of the windowed gather (stage_bwd_value_wu), 0 = run-time loops
 };
 
 // canvas[c,y,x] for c = 0..2 of one position: taps and weights looked up once (stage_fwd_value per channel)
@@ -1068,7 +1175,12 @@ __global__ void __launch_bounds__(kBlock) k_stage0_bwd_multi(MultiBwd mb, float*
 #pragma unroll
     for (int k = 0; k < kMaxMulti; ++k) {
       if (k < mb.n) {
-        const float t = stage_bwd_value(mb.st[k], mb.cg[k], c, ys, xs);
+        const int w = mb.win[k];     // uniform
+        float t;
+        if ((w & 3) == 1) t = stage_bwd_value_wu<1>(mb.st[k], mb.cg[k], w >> 2, c, ys, xs);
+        else if ((w & 3) == 2) t = stage_bwd_value_wu<2>(mb.st[k], mb.cg[k], w >> 2, c, ys, xs);
+        else if ((w & 3) == 3) t = stage_bwd_value_wu<3>(mb.st[k], mb.cg[k], w >> 2, c, ys, xs);
+        else t = stage_bwd_value(mb.st[k], mb.cg[k], c, ys, xs);
         v = (k == 0) ? t : v + t;
       }
     }
@@ -1932,54 +2044,6 @@ __global__ void __launch_bounds__(kBlock) k_fused_update(float* __restrict__ p, 
 // A plan with a second stage fed by the first canvas (Phi-3.5: bicubic global view of the HD
 // canvas) adds k_stage_bwd of that stage before the tail (its gradient reaches the tail through
 // `dgrad`) and k_stage_fwd of it after the head.
-// stage_bwd_value with a T x T window (T >= the transposed tables' row length): every load of the gather is issued before
-// the first use, taps beyond a row's count come from the last valid tap's address and never enter the sum; the in-range
-// taps are accumulated by stage_bwd_value's operations in its order (bit-identical).  MODE fixes canvas_grad_at's shape:
-// 1 = one copy, 2 = one copy + dgrad, 3 = two copies.
-template <int T, int MODE>
-__device__ inline float stage_bwd_value_w(const DStage& st, const CanvasGrad& cg, int c, int ys, int xs) {
-  constexpr int COPIES = (MODE == 3) ? 2 : 1;
-  constexpr bool DG = MODE == 2;
-  const int oy = st.tth.start[ys], oyc = st.tth.count[ys];
-  const int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
-  const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
-  const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
-  const int ly = max(oyc - 1, 0), lx = max(oxc - 1, 0);
-  float wyv[T], wxv[T], r[T][T][COPIES + 1];
-#pragma unroll
-  for (int a = 0; a < T; ++a) {
-    wyv[a] = wy[min(a, ly)];
-    wxv[a] = wx[min(a, lx)];
-  }
-#pragma unroll
-  for (int a = 0; a < T; ++a) {
-    const size_t row = ((size_t)c * st.can_h + (st.off_y + oy + min(a, ly))) * st.can_w + st.off_x + ox;
-#pragma unroll
-    for (int b = 0; b < T; ++b) {
-      const size_t o = row + min(b, lx);
-#pragma unroll
-      for (int t = 0; t < COPIES; ++t) r[a][b][t] = cg.g[(size_t)t * cg.copy_stride + o];
-      if (DG) r[a][b][COPIES] = cg.dgrad[o];
-    }
-  }
-  float v = 0.0f;
-#pragma unroll
-  for (int a = 0; a < T; ++a) {
-    float h = 0.0f;
-#pragma unroll
-    for (int b = 0; b < T; ++b) {
-      float g = 0.0f;                                  // canvas_grad_at: the copies in order, then dgrad
-#pragma unroll
-      for (int t = 0; t < COPIES; ++t) g += r[a][b][t];
-      if (DG) g += r[a][b][COPIES];
-      h = (b < oxc) ? h + wxv[b] * g : h;
-    }
-    v = (a < oyc) ? v + wyv[a] * h : v;
-  }
-  if (st.normalise) v = v / st.stdv[c];
-  return v;
-}
-
 // T, MODE: the transposed gather as a compiled window (stage_bwd_value_w); T = 0: stage_bwd_value's run-time loops
 template <int T, int MODE>
 __global__ void __launch_bounds__(kBlock) k_plan_tail(DStage st, CanvasGrad cg, float* __restrict__ p, const float* __restrict__ x0, float eps,
@@ -2033,6 +2097,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_tail(DStage st, CanvasGrad cg, 
 //                      (block 0 still reduces the statistics of the current image);
 //   <all-reduce>
 //   k_plan_update    : mask, ||g|| partial, optimiser, s_next and its statistics partials.
+template <int T = 0, int MODE = 0>   // as k_plan_tail
 __global__ void __launch_bounds__(kBlock) k_plan_tail_grad(DStage st, CanvasGrad cg, const float* __restrict__ p, const float* __restrict__ x0,
                                                            float eps, float c_fit, float* __restrict__ grad_p,
                                                            const double* __restrict__ img_rows_in, int img_rows_in_count,
@@ -2047,7 +2112,7 @@ __global__ void __launch_bounds__(kBlock) k_plan_tail_grad(DStage st, CanvasGrad
     const int ys = (int)(rem / (unsigned)st.src_w), xs = (int)(rem - (unsigned)ys * (unsigned)st.src_w);
     const float t = tanhf(p[i]);
     const float s = x0[i] + eps * t;
-    const float gs = stage_bwd_value(st, cg, c, ys, xs);
+    const float gs = (T > 0) ? stage_bwd_value_w<(T > 0 ? T : 1), (MODE > 0 ? MODE : 1)>(st, cg, c, ys, xs) : stage_bwd_value(st, cg, c, ys, xs);
     grad_p[i] = ((gs + imgfit_grad(s, c_fit)) * eps) * (1.0f - t * t);
   }
 }
