@@ -208,8 +208,15 @@ def test_accumulated_loss_never_mixes_accumulation_windows(tmp_path):
     # iteration 3 steps, but its window (2, 3) was logged in part; iteration 7's window (6, 7) was logged in full
     assert "accumulated_loss" not in sparse[1] and "accumulated_loss" not in sparse[0] and "accumulated_loss" not in sparse[2]
     assert sparse[3]["accumulated_loss"] == pytest.approx(sparse[2]["loss"] + sparse[3]["loss"], rel=1e-12)
-    # same run, same numbers: the log cadence changes what is written, not what is computed
-    assert sparse[3]["loss"] == dense[7]["loss"] and sparse[1]["loss"] == dense[3]["loss"]
+    # same run, same numbers: the log cadence changes what is written, not what is computed.  Everything this package
+    # computes is compared exactly; the scalar `loss` comes out of torch's F.cross_entropy, whose mean reduction on ROCm is not
+    # reproducible to the last bit (300 calls on identical logits: 243 x 6.235054016, 57 x 6.235054493 - tools/diag_flaky.py,
+    # round 4), so it gets one part in a million
+    for a, b in ((sparse[3], dense[7]), (sparse[1], dense[3])):
+        assert a["loss"] == pytest.approx(b["loss"], rel=1e-6) and a["ce_loss"] == pytest.approx(b["ce_loss"], rel=1e-6)
+        for key in ("image_loss", "grad norm", "lr", "resave_error_std", "resave_error_mean", "resave_error_l1",
+                    "adversarial_mean", "adversarial_std", "noise_sigma"):
+            assert a[key] == b[key], key
 
 
 def test_generation_probe_writes_reference_csv(tmp_path):
