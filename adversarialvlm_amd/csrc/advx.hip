@@ -48,6 +48,7 @@ static int32_t fail(int32_t code, const std::string& msg) {
 static int g_generic_kernels = 0;
 static int g_pair_nt_loads = 0;
 static int g_xcd_map = 2;        // ADVX_TUNE_XCD_MAP: 0 = grids as they come (rounds 1-3), 1 = gx padded to a multiple of 8, 2 = padded + a contiguous range of column blocks per XCD
+static int g_head3 = 50;         // ADVX_TUNE_HEAD3: canvases of >= value * 1000 positions take the three-channel windowed forward (0: never)
 static int g_row_batch = 1;      // ADVX_TUNE_ROW_BATCH: the transposed resizes load the taps of one window row together (k_stage_bwd3_rb)
 constexpr int kImgXcdRows = 8;   // rows per group of the XCD-aware image grids (xcd_band_block)
 static int g_img_xcd = kImgXcdRows;   // ADVX_TUNE_IMG_XCD: rows per group; 0 = (column chunk, row, layer) grids dealt round-robin
@@ -55,7 +56,7 @@ static int g_bwd_xcd = 1;        // ADVX_TUNE_BWD_XCD: the B x P_out READERS (k_
 static int g_pair_lean = 0;      // ADVX_TUNE_PAIR_LEAN (experiment; the float32 Philox pair only)
 static int g_full_tap_rows = 0;
 static int g_separate_crop = 0;   // ADVX_TUNE_SEPARATE_CROP: 1 = never compose a crop window with stage 0; 2 = compose wherever the tables fit (tests)
-static long long kRows3MinPositions = 250000;   // three channels per thread (k_stage_bwd3, k_crop_bwd_rows3) from here up (measured)
+static const long long kRows3MinPositions = 250000;   // three channels per thread (k_stage_bwd3*, k_crop_bwd_rows3) from here up (measured again in round 4 with the windowed forms: 50 k is level or slower)
 extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
   if (what == ADVX_TUNE_RESET_ALL) {       // every switch back to its default (test fixtures' finaliser)
     g_generic_kernels = g_pair_nt_loads = g_pair_lean = g_full_tap_rows = g_separate_crop = 0;
@@ -63,6 +64,11 @@ extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
     g_bwd_xcd = 1;
     g_row_batch = 1;
     g_img_xcd = kImgXcdRows;
+    g_head3 = 50;
+    return ADVX_OK;
+  }
+  if (what == ADVX_TUNE_HEAD3) {
+    g_head3 = value < 0 ? 0 : value;
     return ADVX_OK;
   }
   if (what == ADVX_TUNE_IMG_XCD) {
@@ -742,9 +748,12 @@ static void launch_stage_fwd(const DStage& D, const float* src, long long src_cs
                              const double* img_partials, int img_nblk, long long n_img, const double* norm_rows, int norm_count,
                              float* stats, hipStream_t st) {
   const int T = pick_window(std::max(D.th.stride, D.tw.stride));
-  if (T) {
-    // (three channels per thread, as k_stage_bwd3 / k_crop_bwd_rows3: SLOWER here - 6.4 -> 7.4 us on the crop's resize,
-    // 10.9 -> 11.7 on Qwen2-VL's - the windows of one channel already keep the loads in flight)
+  // canvases of 50 k positions and more: k_stage0_fwd_multi for one plan - three channels per thread, taps and weights looked
+  // up once, the whole window in flight (stage_fwd_value3_w).  Measured against k_stage_fwd_t once both reduce their riding
+  // partials with rows in flight (round 4): LLaVA 512 -> 336 7.8 -> 7.5 us, Qwen2-VL 9.1 -> 7.3, Mllama 9.8 -> 7.8, Phi-3.5's two
+  // stages 20.5 -> 16.9 (rounds 2-3 had measured the three-channel form slower; the reduction in block 0 hid the difference)
+  const bool head3 = g_head3 && T && norm_count >= 0 && (long long)D.can_h * D.can_w >= (long long)g_head3 * 1000;
+  if (T && !head3) {
     dim3 grid((D.can_w + kRowBlock - 1) / kRowBlock, D.can_h, 3);
 #define ADVX_SF(T_)                                                                                                     \
   hipLaunchKernelGGL((k_stage_fwd_t<T_>), grid, dim3(kRowBlock), 0, st, D, src, src_cstride, src_rstride, canvas, img_partials, \

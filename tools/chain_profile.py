@@ -27,6 +27,11 @@ def main():
         plans, B = [Plan.llava(H, W)], 64
         kw = dict(use_crop=True, **(dict(blur_kernel=9) if "blur" in which else {}))
         crop = (40, 30, 400, 420)
+    elif which == "llava336-blur5-crop":                # native resolution + blur 5 + window (tools/generic_bench.py's row)
+        H = W = 336
+        plans, B = [Plan.llava(H, W)], 64
+        kw = dict(use_crop=True, blur_kernel=5)
+        crop = (20, 30, 280, 300)
     elif which == "cross":                       # BASELINE configs 4/5 in the shape tools/generic_bench.py times
         H = W = 336
         plans, B, kw = [Plan.phi3(H, W), Plan.qwen2vl(H, W), Plan.mllama(H, W)], 16, dict(blur_kernel=5, cross_mode=True)
