@@ -1,0 +1,89 @@
+"""GPU tier: the round-4 forms of the image-sized launches against the forms they replaced, bit for bit.
+
+Each `ADVX_TUNE_*` switch of round 4 (include/advx.h) selects between two ways of running the SAME arithmetic in the same order:
+the transposed resizes as compiled windows / a window row at a time or with one memory round trip per tap (ROW_BATCH), the gathers'
+grids dealt to the XCDs in row groups or workgroup by workgroup (IMG_XCD), canvases resized three channels per thread or one
+(HEAD3), the readers of B x P_out mapped to the XCDs like the writers or not (BWD_XCD).  Whole chains are stepped with every switch
+off in turn and with all of them off; every tensor they leave must be IDENTICAL to the default build's.  (That the specialised
+kernels equal the general ones is tests/test_gpu_fastpaths.py; parity with the oracle is the other GPU tests'.)"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+ROW_BATCH, IMG_XCD, HEAD3, BWD_XCD, RESET_ALL = 8, 9, 10, 7, 0
+
+
+def _chains():
+    from adversarialvlm_amd.plan import Plan
+    q = dict(min_pixels=28 * 28, max_pixels=28 * 28 * 1280)
+    return {
+        # (H, W, plans, batches, engine keywords, crop window)
+        "llava512_prepared": (512, 512, lambda: [Plan.llava(512, 512)], [3], dict(fused_mode="prepared"), None),
+        "llava512_generic": (512, 512, lambda: [Plan.llava(512, 512)], [3], dict(allow_fused=False), None),
+        "llava512_blur_crop": (512, 512, lambda: [Plan.llava(512, 512)], [2], dict(allow_fused=False, blur_kernel=9, use_crop=True),
+                               (40, 30, 400, 420)),
+        "llava_odd_crop": (97, 130, lambda: [Plan.llava(97, 130, 56, 72)], [3], dict(allow_fused=False, use_crop=True), (3, 5, 80, 101)),
+        "qwen512_prepared": (512, 512, lambda: [Plan.qwen2vl(512, 512, **q)], [2], dict(fused_mode="prepared"), None),
+        "qwen512_generic": (512, 512, lambda: [Plan.qwen2vl(512, 512, **q)], [2], dict(allow_fused=False), None),
+        "phi3_512_prepared": (512, 512, lambda: [Plan.phi3(512, 512)], [2], dict(fused_mode="prepared"), None),
+        "phi3_512_generic": (512, 512, lambda: [Plan.phi3(512, 512)], [2], dict(allow_fused=False), None),
+        "mllama336_prepared": (336, 336, lambda: [Plan.mllama(336, 336)], [2], dict(fused_mode="prepared"), None),
+        "mllama_wide_generic": (300, 1000, lambda: [Plan.mllama(300, 1000, tile=64)], [2], dict(allow_fused=False), None),
+        "cross_blur": (336, 336, lambda: [Plan.phi3(336, 336), Plan.qwen2vl(336, 336, **q), Plan.mllama(336, 336)], [2, 2, 2],
+                       dict(allow_fused=False, blur_kernel=5, cross_mode=True), None),
+        "llava336_pair": (336, 336, lambda: [Plan.llava(336, 336)], [20], dict(fused_mode="pair"), None),
+    }
+
+
+def _run(name, tuning):
+    from adversarialvlm_amd import _lib as L
+    from adversarialvlm_amd.pgd import PixelPGD
+    H, W, plans_fn, batches, kw, crop = _chains()[name]
+    lib = L.load()
+    L.check(lib.advx_set_tuning(RESET_ALL, 0), "advx_set_tuning")
+    for what, value in tuning:
+        L.check(lib.advx_set_tuning(what, value), "advx_set_tuning")
+    try:
+        gen = torch.Generator().manual_seed(11)
+        plans = plans_fn()
+        x0 = torch.rand(3, H, W, generator=gen).to(DEV)
+        mask = (torch.rand(3, H, W, generator=gen) > 0.2).float().to(DEV)
+        eng = PixelPGD(x0, plans, lr=1e-2, mask=mask, seed=5, **kw)
+        gs = [[(torch.randn(b, pl.out_numel, generator=gen) * 0.05).to(DEV) for pl, b in zip(plans, batches)] for _ in range(3)]
+        outs = []
+        for t in range(3):
+            pvs = eng.forward(batches, blur_sigma=1.3 if "blur_kernel" in kw else None, crop=crop)
+            outs += [pv.clone() for pv in pvs]
+            eng.backward_update(gs[t])
+            outs += [eng.p.clone(), eng.m.clone(), eng.v.clone(), eng.grad.clone(), eng.image().clone()]
+        stats = eng.stats_dict()
+        torch.cuda.synchronize()
+        return outs, stats
+    finally:
+        L.check(lib.advx_set_tuning(RESET_ALL, 0), "advx_set_tuning")
+
+
+VARIANTS = {
+    "row_batch_off": [(ROW_BATCH, 0)],
+    "img_xcd_off": [(IMG_XCD, 0)],
+    "img_xcd_3_rows": [(IMG_XCD, 3)],
+    "img_xcd_whole_bands": [(IMG_XCD, 4096)],
+    "head3_off": [(HEAD3, 0)],
+    "head3_everywhere": [(HEAD3, 1)],
+    "bwd_xcd_off": [(BWD_XCD, 0)],
+    "all_off": [(ROW_BATCH, 0), (IMG_XCD, 0), (HEAD3, 0), (BWD_XCD, 0)],
+}
+
+
+@pytest.mark.parametrize("name", sorted(_chains()))
+def test_round4_forms_leave_the_bits_of_the_forms_they_replaced(name):
+    ref, st_ref = _run(name, [])
+    for variant, tuning in VARIANTS.items():
+        got, st = _run(name, tuning)
+        assert len(got) == len(ref)
+        for k, (a, b) in enumerate(zip(got, ref)):
+            assert torch.equal(a, b), (name, variant, k, float((a.float() - b.float()).abs().max()))
+        for key in st_ref:
+            assert st[key] == st_ref[key], (name, variant, key)
