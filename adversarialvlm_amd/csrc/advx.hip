@@ -265,6 +265,9 @@ struct advx_plan {
   bool uploaded = false;
   int device = -1;
   void* dev_block = nullptr;
+  // stage 0's forward rows as they stand on the device (start, count per output row / column; trimmed of zero taps unless
+  // ADVX_TUNE_FULL_TAP_ROWS): what compose_exact walks to find the composed tables' real row lengths
+  std::vector<int> dev0_start[2], dev0_count[2];
   int io = 0;                  // boundary dtype of pixel_values / grad_out (ADVX_IO_*), advx_plan_set_io
 };
 
@@ -672,6 +675,10 @@ extern "C" int32_t advx_plan_upload(advx_plan* p, void* stream) {
       total += taps_bytes(dev_taps[k][a]);
     }
   }
+  for (int a = 0; a < 2; ++a) {
+    p->dev0_start[a] = dev_taps[0][a].start;
+    p->dev0_count[a] = dev_taps[0][a].count;
+  }
   std::vector<char> host(total, 0);
   void* block = nullptr;
   HIP_TRY(hipMalloc(&block, total));
@@ -775,7 +782,7 @@ static void launch_stage_fwd(const DStage& D, const float* src, long long src_cs
     std::memset(&none, 0, sizeof(none));
     dim3 lg;
     const ImgGrid ig = img_grid((D.can_w + kRowBlock - 1) / kRowBlock, D.can_h, 1, &lg);
-    hipLaunchKernelGGL(k_stage0_fwd_multi, lg, dim3(kRowBlock), 0, st, mf, src,
+    hipLaunchKernelGGL(k_stage0_fwd_multi<4>, lg, dim3(kRowBlock), 0, st, mf, src,
                        src_cstride, src_rstride, img_partials, img_nblk, n_img, stats, norm_rows, norm_count, none, none, 0, ig, g_generic_kernels ? 0 : g_row_batch);
     return;
   }
@@ -985,26 +992,30 @@ static bool dgrad_into_gcan(const advx_plan* p, int k) {
     if (p->dplan.e[j].stage == k) covered += p->dplan.e[j].out_count;
   return covered == 3LL * p->st[k].info.can_h * p->st[k].info.can_w;
 }
+// rows: the transposed tables' REAL longest row where the caller knows it (composed crop window), else 0 = their row length
 static void launch_stage_bwd(const DStage& D, const CanvasGrad& cg, float* gsrc, long long cstride, int rstride, int acc,
-                             hipStream_t st) {
+                             hipStream_t st, int rows = 0) {
   const int rowblk = 128;   // two waves along x: little waste on the last chunk of a 336 / 512 / 672-wide row
   if (!g_generic_kernels && (long long)D.src_h * D.src_w >= kRows3MinPositions) {
     // the taps of one canvas row loaded together where canvas_grad_at has one of the three shapes that occur (stage_bwd3_rows)
-    const int mode = (!g_row_batch || D.ttw.stride > 10) ? 0
+    const int need = rows > 0 ? rows : std::max(D.tth.stride, D.ttw.stride);
+    const int mode = (!g_row_batch || (rows > 0 ? rows : D.ttw.stride) > 10) ? 0
                      : (cg.copies == 1 && !cg.dgrad)    ? 1
                      : (cg.copies == 1 && cg.dgrad)     ? 2
                      : (cg.copies == 2 && !cg.dgrad)    ? 3
                                                         : 0;
     dim3 grid;
     const ImgGrid ig = img_grid((D.src_w + rowblk - 1) / rowblk, D.src_h, 1, &grid);
-    const int T = mode ? pick_window(std::max(D.tth.stride, D.ttw.stride)) : 0;
+    const int T = mode ? (need <= 4 ? pick_window(need) : (need <= 6 && mode == 1 ? need : 0)) : 0;
     if (T) {
-      // tables of <= 4 taps per row: the whole window in flight (k_stage_bwd3_w)
+      // rows of <= 4 taps (<= 6 for the one-copy gradient: the composed crop window): the whole window in flight (k_stage_bwd3_w)
 #define ADVX_B3W(T_, M_) hipLaunchKernelGGL((k_stage_bwd3_w<T_, M_>), grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc, ig)
 #define ADVX_B3W_M(T_) do { if (mode == 1) ADVX_B3W(T_, 1); else if (mode == 2) ADVX_B3W(T_, 2); else ADVX_B3W(T_, 3); } while (0)
       if (T == 2) ADVX_B3W_M(2);
       else if (T == 3) ADVX_B3W_M(3);
-      else ADVX_B3W_M(4);
+      else if (T == 4) ADVX_B3W_M(4);
+      else if (T == 5) ADVX_B3W(5, 1);
+      else ADVX_B3W(6, 1);
 #undef ADVX_B3W_M
 #undef ADVX_B3W
       return;
@@ -1017,7 +1028,7 @@ static void launch_stage_bwd(const DStage& D, const CanvasGrad& cg, float* gsrc,
     }
   } else {
     const int mode = !g_row_batch ? 0 : (cg.copies == 1 && !cg.dgrad) ? 1 : (cg.copies == 1 && cg.dgrad) ? 2 : (cg.copies == 2 && !cg.dgrad) ? 3 : 0;
-    const int T = mode ? pick_window(std::max(D.tth.stride, D.ttw.stride)) : 0;
+    const int T = mode ? pick_window(rows > 0 ? rows : std::max(D.tth.stride, D.ttw.stride)) : 0;
     const dim3 grid((D.src_w + rowblk - 1) / rowblk, D.src_h, 3);
 #define ADVX_SBW(T_, M_) hipLaunchKernelGGL((k_stage_bwd<T_, M_>), grid, dim3(rowblk), 0, st, D, cg, gsrc, cstride, rstride, acc)
 #define ADVX_SBW_M(T_) do { if (mode == 1) ADVX_SBW(T_, 1); else if (mode == 2) ADVX_SBW(T_, 2); else ADVX_SBW(T_, 3); } while (0)
@@ -1143,7 +1154,7 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
                                const float* sigma_dev, const float* const* unit_noises, int32_t use_philox, uint64_t seed,
                                const uint64_t* offsets, void* const* outs, float* const* wss, const int64_t* ws_floats,
                                int32_t pad_mode, const PendingImageStats& pend, void* stream,
-                               const DStage* stage0_override = nullptr) {
+                               const DStage* stage0_override = nullptr, int stage0_window = 0) {
   int32_t rc = check_multi(n, plans, batches, wss, ws_floats, "advx_emit_multi");
   if (rc) return rc;
   REQUIRE(argument && outs && offsets, ADVX_E_BADARG, "advx_emit_multi: null argument");
@@ -1183,22 +1194,35 @@ static int32_t emit_multi_impl(int32_t n, advx_plan* const* plans, const float* 
       tr_blocks = (rows + kRowBlock - 1) / kRowBlock;
       if ((long long)gx0 * max_h < 2LL * tr_blocks) tr_blocks = 0;       // no room in one layer: the emit's fallback below
     }
+    // window of the gather: 0 = run-time loops, 1 = compiled window by the tables' row lengths (<= 4), > 1 = this size (the
+    // composed crop window's REAL longest row, compose_exact)
+    const int fwd_window = (g_generic_kernels || !g_row_batch) ? 0 : ((stage0_override && stage0_window > 1) ? stage0_window : 1);
     // several plans: the grid is sized for the largest canvas and the smaller ones leave whole groups idle - round robin
     // (measured on Phi-3.5 + Qwen2-VL + Mllama: 12.5 us, 13.3 with groups)
     dim3 lg;
     if (tr_blocks > 0) {
       const ImgGrid ig = img_grid(gx0, max_h, n, &lg, 2u * (unsigned)tr_blocks, n == 1);
-      hipLaunchKernelGGL(k_stage0_fwd_multi, lg, dim3(kRowBlock), 0, st, mf, argument,
-                         (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats,
-                         (const double*)nullptr, 0, rider.t[0], rider.t[1], tr_blocks, ig, g_generic_kernels ? 0 : g_row_batch);
+      if (fwd_window > 4 && fwd_window <= 6)
+        hipLaunchKernelGGL(k_stage0_fwd_multi<6>, lg, dim3(kRowBlock), 0, st, mf, argument,
+                           (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats,
+                           (const double*)nullptr, 0, rider.t[0], rider.t[1], tr_blocks, ig, fwd_window);
+      else
+        hipLaunchKernelGGL(k_stage0_fwd_multi<4>, lg, dim3(kRowBlock), 0, st, mf, argument,
+                           (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats,
+                           (const double*)nullptr, 0, rider.t[0], rider.t[1], tr_blocks, ig, fwd_window);
       rider = no_rider();
     } else {
       TapBuild none;
       std::memset(&none, 0, sizeof(none));
       const ImgGrid ig = img_grid(gx0, max_h, n, &lg, 0, n == 1);
-      hipLaunchKernelGGL(k_stage0_fwd_multi, lg, dim3(kRowBlock), 0, st, mf, argument,
-                         (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats,
-                         (const double*)nullptr, 0, none, none, 0, ig, g_generic_kernels ? 0 : g_row_batch);
+      if (fwd_window > 4 && fwd_window <= 6)
+        hipLaunchKernelGGL(k_stage0_fwd_multi<6>, lg, dim3(kRowBlock), 0, st, mf, argument,
+                           (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats,
+                           (const double*)nullptr, 0, none, none, 0, ig, fwd_window);
+      else
+        hipLaunchKernelGGL(k_stage0_fwd_multi<4>, lg, dim3(kRowBlock), 0, st, mf, argument,
+                           (long long)D0.src_h * D0.src_w, D0.src_w, pend.partials, pend.nblk, pend.n_img, pend.stats,
+                           (const double*)nullptr, 0, none, none, 0, ig, fwd_window);
     }
   }
   LAUNCH_CHECK();
@@ -1531,6 +1555,49 @@ bool compose_geom(const advx_plan* p, int H, int W, const int32_t* crop, Compose
 }
 
 // carve the composed tables out of scratch (the crop tables' place) and launch - or hand over, `deferred` - their construction
+// The REAL longest rows of the composed tables (forward, transposed; the larger of the two axes each) for this window, by
+// walking what build_composed_row walks: composed row i spans the window's rows from A.start(B.start[i]) to A.end(B.start[i] +
+// B.count[i] - 1) (both non-decreasing), and image row r is read by the canvas rows whose span holds it.  compose_geom's
+// strides are analytic BOUNDS (8 and 9 at 512 -> 336 with a 400-pixel window) that size the tables; the rows themselves are
+// 5-6 long, short enough for the gathers' compiled windows.  ~700 tap_bounds evaluations per call (a few microseconds).
+struct ComposedExact { int fwd = 0, tr = 0; };
+ComposedExact compose_exact(const advx_plan* p, int H, int W, const int32_t* crop, const ComposeGeom& g) {
+  ComposedExact e;
+  const advx_stage_info& D = p->st[0].info;
+  const int ins[2] = {crop[2], crop[3]}, mids[2] = {H, W}, outs[2] = {D.res_h, D.res_w};
+  for (int ax = 0; ax < 2; ++ax) {
+    std::vector<int> hs, hc;
+    if (!p->uploaded) {
+      // not uploaded yet (host-side tests): the rows as advx_plan_upload would store them now
+      const HostTaps& full = (ax == 0) ? p->st[0].th : p->st[0].tw;
+      const HostTaps t = g_full_tap_rows ? full : trim_zero_taps(full);
+      hs = t.start; hc = t.count;
+    }
+    const std::vector<int>& bs = p->uploaded ? p->dev0_start[ax] : hs;
+    const std::vector<int>& bc = p->uploaded ? p->dev0_count[ax] : hc;
+    if ((int)bs.size() != outs[ax]) return ComposedExact();          // no hint
+    std::vector<int> diff((size_t)ins[ax] + 2, 0);                   // +1 at a row's first source index, -1 behind its last
+    for (int i = 0; i < outs[ax]; ++i) {
+      int lo = 0, hi = 0;
+      if (bc[i] > 0) {
+        const TapRow a0 = tap_bounds(ADVX_MODE_AA_BILINEAR, ins[ax], mids[ax], bs[i]);
+        const TapRow a1 = tap_bounds(ADVX_MODE_AA_BILINEAR, ins[ax], mids[ax], bs[i] + bc[i] - 1);
+        lo = a0.start;
+        hi = std::max(a0.start + a0.count, a1.start + a1.count);
+      }
+      const int n = std::min(hi - lo, g.s[ax]);
+      e.fwd = std::max(e.fwd, n);
+      if (n > 0) { diff[lo] += 1; diff[lo + n] -= 1; }
+    }
+    int run = 0;
+    for (int r = 0; r < ins[ax]; ++r) {
+      run += diff[r];
+      e.tr = std::max(e.tr, std::min(run, g.ts[ax]));
+    }
+  }
+  return e;
+}
+
 int32_t build_composed_stage(const advx_plan* p, int H, int W, const int32_t* crop, Bump& b, hipStream_t stq, DStage* out,
                              bool may_reuse = false, TapBuild* deferred = nullptr, PendingTables* pending = nullptr) {
   ComposeGeom g;
@@ -1609,6 +1676,19 @@ extern "C" int32_t advx_crop_compose_strides(const advx_plan* p, int32_t H, int3
   return ADVX_OK;
 }
 
+// the composed tables' REAL longest rows for this window (forward, transposed; over both axes): what the gathers' compiled
+// windows are picked by (<= 6), where the strides above only size the tables
+extern "C" int32_t advx_crop_compose_rows(const advx_plan* p, int32_t H, int32_t W, const int32_t* crop, int32_t* forward,
+                                          int32_t* transposed) {
+  REQUIRE(p && crop && forward && transposed, ADVX_E_BADARG, "advx_crop_compose_rows: null argument");
+  ComposeGeom g;
+  REQUIRE(compose_geom(p, H, W, crop, &g), ADVX_E_UNSUPPORTED, "this crop window does not compose with the plan's stage 0");
+  const ComposedExact e = compose_exact(p, H, W, crop, g);
+  *forward = e.fwd;
+  *transposed = e.tr;
+  return ADVX_OK;
+}
+
 // Backward of a step whose advx_forward_multi composed the crop window with stage 0: batch reduction, the upper stages,
 // then ONE transposed gather canvas -> IMAGE through the composed table (exact zeros outside the window).  grad_s is the
 // gradient w.r.t. s = x0 + x: hand it to advx_image_bwd* WITHOUT a crop window.
@@ -1638,7 +1718,9 @@ extern "C" int32_t advx_collect_crop(advx_plan* p, const void* grad_out, int32_t
     launch_stage_bwd(Dk, stage_grad(p, k, ws), gsrc, (long long)Dk.src_h * Dk.src_w, Dk.src_w, acc, st);
     LAUNCH_CHECK();
   }
-  launch_stage_bwd(D, stage_grad(p, 0, ws), grad_s, (long long)H * W, W, accumulate, st);
+  ComposeGeom cgeo;
+  const int tr_rows = compose_geom(p, H, W, crop, &cgeo) ? compose_exact(p, H, W, crop, cgeo).tr : 0;
+  launch_stage_bwd(D, stage_grad(p, 0, ws), grad_s, (long long)H * W, W, accumulate, st, tr_rows);
   LAUNCH_CHECK();
   // the tables have served their step: the image-level backward that follows carves its buffers over them, so a later call
   // with the same window must rebuild, not trust the record
@@ -1813,8 +1895,9 @@ static int32_t forward_multi_impl(const float* p, const float* x0, int32_t H, in
                       compose ? plans[0] : nullptr, compose ? &composed : nullptr, image_ready);
   if (rc) return rc;
   const float* arg = compose ? s : ((crop || (argument && argument != s)) ? argument : s);
+  const int fwd_rows = compose ? compose_exact(plans[0], H, W, crop, cg_unused).fwd : 0;
   rc = emit_multi_impl(n, plans, arg, batches, stats + ADVX_STAT_SIGMA, unit_noises, use_philox, seed, offsets, outs, wss,
-                       ws_floats, pad_mode, pend, stream, compose ? &composed : nullptr);
+                       ws_floats, pad_mode, pend, stream, compose ? &composed : nullptr, fwd_rows);
   if (rc && pend.nblk > 0) {
     // the emit was refused after the image kernels ran: do not leave the statistics unreduced
     hipLaunchKernelGGL(k_finalize_image, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, pend.partials, pend.nblk, pend.n_img,

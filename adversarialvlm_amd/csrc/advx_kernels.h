@@ -1118,6 +1118,9 @@ __device__ inline void stage_fwd_value3_w(const DStage& st, const float* __restr
 }
 
 // grid = (column chunks of the widest canvas, rows of the tallest, plans)
+// MAXW: the largest compiled window of this instantiation - 4 for the plans' own tables (58 VGPRs), 6 for the composed crop
+// window's rows (146 VGPRs: a launch of its own, so that every other use keeps its occupancy)
+template <int MAXW>
 __global__ void __launch_bounds__(kBlock) k_stage0_fwd_multi(MultiFwd mf, const float* __restrict__ src, long long src_cstride,
                                                              int src_rstride, const double* __restrict__ img_partials, int nblk,
                                                              long long n_img, float* __restrict__ stats,
@@ -1152,10 +1155,14 @@ __global__ void __launch_bounds__(kBlock) k_stage0_fwd_multi(MultiFwd mf, const 
   const int x = blk.x * blockDim.x + threadIdx.x;
   if (y < st.can_h && x < st.can_w) {
     float v[3];
-    const int tm = windowed ? max(st.th.stride, st.tw.stride) : 99;      // uniform: one path per workgroup
+    // windowed: 0 = loops, 1 = by the tables' row lengths, > 1 = the rows' real length (host: compose_exact).  Uniform: one
+    // path per workgroup
+    const int tm = !windowed ? 99 : (windowed > 1 ? windowed : max(st.th.stride, st.tw.stride));
     if (tm <= 2) stage_fwd_value3_w<2>(st, src, src_cstride, src_rstride, y, x, v);
     else if (tm <= 3) stage_fwd_value3_w<3>(st, src, src_cstride, src_rstride, y, x, v);
     else if (tm <= 4) stage_fwd_value3_w<4>(st, src, src_cstride, src_rstride, y, x, v);
+    else if (MAXW >= 6 && tm <= 5) stage_fwd_value3_w<(MAXW >= 6 ? 5 : 1)>(st, src, src_cstride, src_rstride, y, x, v);
+    else if (MAXW >= 6 && tm <= 6) stage_fwd_value3_w<(MAXW >= 6 ? 6 : 1)>(st, src, src_cstride, src_rstride, y, x, v);
     else stage_fwd_value3(st, src, src_cstride, src_rstride, y, x, v);
     float* __restrict__ canvas = mf.canvas[k];
     const size_t plane = (size_t)st.can_h * st.can_w;

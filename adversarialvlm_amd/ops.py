@@ -152,6 +152,14 @@ def crop_compose_strides(plan, H, W, crop):
     return (int(f[0]), int(f[1])), (int(t[0]), int(t[1]))
 
 
+def crop_compose_rows(plan, H, W, crop):
+    """(forward, transposed): the composed tables' real longest rows for this window (over both axes)."""
+    _keep, cp = _crop_arg(crop)
+    f, t = C.c_int32(), C.c_int32()
+    L.check(L.load().advx_crop_compose_rows(plan.handle, int(H), int(W), cp, C.byref(f), C.byref(t)), "advx_crop_compose_rows")
+    return int(f.value), int(t.value)
+
+
 def collect_crop(plan, grad_out, batch, crop, image_scratch, grad_s, accumulate=False, workspace=None):
     """Backward of a forward_multi that composed: grad_out [batch, out_numel] -> gradient w.r.t. the IMAGE s [3,H,W]
     (exact zeros outside the window)."""

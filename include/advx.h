@@ -253,6 +253,10 @@ int32_t advx_crop_composes(const advx_plan* plan, int32_t H, int32_t W, const in
 /* row lengths (upper bounds) of the composed tables per axis (0 = H, 1 = W); host only, for the tests */
 int32_t advx_crop_compose_strides(const advx_plan* plan, int32_t H, int32_t W, const int32_t* crop_ijhw, int32_t forward[2],
                                   int32_t transposed[2]);
+/* The composed tables' REAL longest rows for this window (forward, transposed; the larger of the two axes each): the gathers
+ * pick their compiled windows by these (rows of up to 6 taps), the strides above only size the tables.  Host arithmetic. */
+int32_t advx_crop_compose_rows(const advx_plan* plan, int32_t H, int32_t W, const int32_t* crop_ijhw, int32_t* forward,
+                               int32_t* transposed);
 int32_t advx_collect_crop(advx_plan* plan, const void* grad_out, int32_t batch, float* grad_s, int32_t accumulate,
                           float* workspace, int64_t workspace_floats, int32_t H, int32_t W, const int32_t* crop_ijhw,
                           float* image_scratch, void* stream);

@@ -226,6 +226,51 @@ def test_composed_table_row_lengths_are_upper_bounds():
     assert checked > 300
 
 
+def test_composed_table_real_row_lengths_are_exact():
+    """advx_crop_compose_rows (round 4): the gathers of a composed window pick their compiled windows by the tables' REAL longest
+    rows, which the host finds by walking the plan's device rows (zero taps trimmed) against the window's antialiased rows.  A
+    value too small would drop taps silently: brute force over the same sweep - composed from the two host tables, the longest
+    forward row and the largest number of canvas rows that reach one window row must EQUAL what the library reports."""
+    import numpy as np
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.plan import Plan, taps_compute
+    rng = np.random.default_rng(12)
+    plans = [(512, 512, Plan.llava(512, 512)), (336, 336, Plan.llava(336, 336)), (97, 130, Plan.llava(97, 130, 56, 72)),
+             (700, 520, Plan.llava(700, 520)), (512, 512, Plan.mllama(512, 512)), (512, 512, Plan.qwen2vl(512, 512)),
+             (300, 200, Plan.phi3(300, 200))]
+    checked = 0
+    with ops.compose_crop_everywhere():
+        for H, W, plan in plans:
+            windows = [(0, 0, H, W), (40 % H, 30 % W, H - 112 if H > 200 else H // 2, W - 92 if W > 200 else W // 2)]
+            for _ in range(25):
+                h, w = int(rng.integers(max(4, H // 4), H + 1)), int(rng.integers(max(4, W // 4), W + 1))
+                windows.append((int(rng.integers(0, H - h + 1)), int(rng.integers(0, W - w + 1)), h, w))
+            mode = plan.stage(0).mode
+            for win in windows:
+                if not ops.crop_composes(plan, H, W, win):
+                    continue
+                fwd_bound, tr_bound = ops.crop_compose_strides(plan, H, W, win)
+                got_f, got_t = ops.crop_compose_rows(plan, H, W, win)
+                want_f = want_t = 0
+                for axis, (size, ext, res) in enumerate(((H, win[2], plan.stage(0).res_h), (W, win[3], plan.stage(0).res_w))):
+                    bs, bc, _ = taps_compute(mode, size, res, device_rows=True)        # the plan's rows as uploaded
+                    as_, ac, _ = taps_compute(0, ext, size)                             # window: ext -> size
+                    cover = np.zeros(ext + 1, np.int64)
+                    for s0, c0 in zip(bs, bc):
+                        if c0 <= 0:
+                            continue
+                        lo = int(as_[s0])
+                        hi = max(int(as_[k] + ac[k]) for k in range(s0, s0 + c0))
+                        n = min(hi - lo, fwd_bound[axis])
+                        want_f = max(want_f, n)
+                        cover[lo:lo + n] += 1
+                    want_t = max(want_t, min(int(cover.max()), tr_bound[axis]))
+                assert (got_f, got_t) == (want_f, want_t), (H, W, win, (got_f, got_t), (want_f, want_t))
+                assert got_f <= max(fwd_bound) and got_t <= max(tr_bound)
+                checked += 1
+    assert checked > 100
+
+
 @pytest.mark.parametrize("which", ["attack_model", "crossattack_models"])
 def test_every_reference_flag_exists_with_the_reference_default(which):
     """SURVEY App. C from the reference itself: tests/golden/cli_flags_reference.json is read off the parser objects the
