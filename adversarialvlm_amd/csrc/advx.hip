@@ -796,9 +796,37 @@ static void launch_stage_fwd(const DStage& D, const float* src, long long src_cs
     hipLaunchKernelGGL(k_stage_fwd, dim3(grid_for(n)), dim3(kBlock), 0, st, D, src, src_cstride, src_rstride, canvas);
 }
 
+// The REAL longest row of the transposed table of one antialiased resize in_size -> out_size (how many outputs read one source
+// index, at most): the tables are sized by an analytic bound (ceil(2 / scale) + 2: five at 400 -> 512), their rows are
+// shorter (four), and the compiled windows of k_crop_bwd_t go up to four.  A walk over the outputs' tap_bounds, remembered
+// per calling thread for the last sizes asked (the trainers draw a new window every step: a few microseconds each).
+static int aa_transposed_rows_exact(int in_size, int out_size) {
+  thread_local int key_in[4] = {0, 0, 0, 0}, key_out[4] = {0, 0, 0, 0}, val[4] = {0, 0, 0, 0}, next = 0;
+  for (int k = 0; k < 4; ++k)
+    if (key_in[k] == in_size && key_out[k] == out_size) return val[k];
+  std::vector<int> diff((size_t)in_size + 2, 0);
+  for (int i = 0; i < out_size; ++i) {
+    const TapRow r = tap_bounds(ADVX_MODE_AA_BILINEAR, in_size, out_size, i);
+    if (r.count > 0) { diff[r.start] += 1; diff[r.start + r.count] -= 1; }
+  }
+  int run = 0, mx = 0;
+  for (int j = 0; j < in_size; ++j) { run += diff[j]; mx = std::max(mx, run); }
+  key_in[next] = in_size; key_out[next] = out_size; val[next] = mx;
+  next = (next + 1) & 3;
+  return mx;
+}
+
 // gradient of the whole image from the gradient of the crop window's resize (zeros outside the window)
+// compiled window (2..4, 0 = none) of the transposed gather of a crop window's resize D: src (window) -> res (image)
+static int crop_window(const DStage& D) {
+  const int rows = (D.mode == ADVX_MODE_AA_BILINEAR && g_row_batch)
+                       ? std::min(std::max(aa_transposed_rows_exact(D.src_h, D.res_h), aa_transposed_rows_exact(D.src_w, D.res_w)),
+                                  std::max(D.tth.stride, D.ttw.stride))
+                       : std::max(D.tth.stride, D.ttw.stride);
+  return pick_window(rows);
+}
 static void launch_crop_bwd(const DStage& D, const float* gcan, float* gimg, int H, int W, int ci, int cj, hipStream_t st) {
-  const int T = pick_window(std::max(D.tth.stride, D.ttw.stride));
+  const int T = crop_window(D);
   if (T) {
     dim3 grid((W + kRowBlock - 1) / kRowBlock, H, 3);
 #define ADVX_CB(T_) hipLaunchKernelGGL((k_crop_bwd_t<T_>), grid, dim3(kRowBlock), 0, st, D, gcan, gimg, H, W, ci, cj)
@@ -2133,8 +2161,15 @@ extern "C" int32_t advx_image_bwd_update(float* p, const float* s, const float* 
     hipLaunchKernelGGL(k_bwd_update<1>, dim3(nblk), dim3(kBlock), 0, st, s, gs, (const float*)c2, D, 0, 0, H, W, r, eps, c_fit,
                        accumulate, p, m, v, grad_p, mask, o, partials);
   } else if (crop) {
-    hipLaunchKernelGGL(k_bwd_update<2>, dim3(nblk), dim3(kBlock), 0, st, s, garg, (const float*)nullptr, D, crop[0], crop[1], H,
-                       W, 0, eps, c_fit, accumulate, p, m, v, grad_p, mask, o, partials);
+    const int T = (g_generic_kernels || !g_row_batch) ? 0 : crop_window(D);
+#define ADVX_BU2(T_)                                                                                                          \
+  hipLaunchKernelGGL((k_bwd_update<2, T_>), dim3(nblk), dim3(kBlock), 0, st, s, garg, (const float*)nullptr, D, crop[0], crop[1], H, \
+                     W, 0, eps, c_fit, accumulate, p, m, v, grad_p, mask, o, partials)
+    if (T == 2) ADVX_BU2(2);
+    else if (T == 3) ADVX_BU2(3);
+    else if (T == 4) ADVX_BU2(4);
+    else ADVX_BU2(0);
+#undef ADVX_BU2
   } else {
     hipLaunchKernelGGL(k_bwd_update<0>, dim3(nblk), dim3(kBlock), 0, st, s, garg, (const float*)nullptr, D, 0, 0, H, W, 0, eps,
                        c_fit, accumulate, p, m, v, grad_p, mask, o, partials);

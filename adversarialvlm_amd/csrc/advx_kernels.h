@@ -1693,11 +1693,46 @@ __global__ void __launch_bounds__(kBlock) k_finalize_norm(const double* __restri
   finalize_norm_block<kFinU>(partials, nblk, stats);
 }
 
+// crop_bwd_value with a T x T window (T >= the transposed tables' REAL longest row, host: aa_transposed_rows_exact): every load
+// issued before the first use, taps beyond a row's count from the last valid tap's address and never summed; crop_bwd_value's
+// operations in its order (bit-identical)
+template <int T>
+__device__ inline float crop_bwd_value_w(const DStage& st, const float* __restrict__ gcan, int ci, int cj, int c, int y, int x) {
+  const int ys = y - ci, xs = x - cj;
+  float v = 0.0f;
+  if (ys >= 0 && ys < st.src_h && xs >= 0 && xs < st.src_w) {
+    const int oy = st.tth.start[ys], oyc = st.tth.count[ys];
+    const int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
+    const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
+    const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
+    const float* gp = gcan + (size_t)c * st.can_h * st.can_w;
+    const int ly = max(oyc - 1, 0), lx = max(oxc - 1, 0);
+    float wyv[T], wxv[T], r[T][T];
+#pragma unroll
+    for (int a = 0; a < T; ++a) {
+      wyv[a] = wy[min(a, ly)];
+      wxv[a] = wx[min(a, lx)];
+    }
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+      for (int b = 0; b < T; ++b) r[a][b] = gp[(size_t)(oy + min(a, ly)) * st.can_w + ox + min(b, lx)];
+#pragma unroll
+    for (int a = 0; a < T; ++a) {
+      float h = 0.0f;
+#pragma unroll
+      for (int b = 0; b < T; ++b) h = (b < oxc) ? h + wxv[b] * r[a][b] : h;
+      v = (a < oyc) ? v + wyv[a] * h : v;
+    }
+  }
+  return v;
+}
+
 // Image-level backward tail and optimiser in ONE launch (no all-reduce in between): what
 // [k_crop_bwd,] k_tanh_bwd and k_update do per element, in their order, on values kept in
 // registers.  MODE 0: gradient of the image given (gs); 1: folded blur adjoint (c2); 2: gs is
 // the gradient of the crop window's resize, gathered here (exact zeros outside the window).
-template <int MODE>
+template <int MODE, int T = 0>   // T > 0 (MODE 2): the window's transposed gather as a compiled window (crop_bwd_value_w)
 __global__ void __launch_bounds__(kBlock) k_bwd_update(const float* __restrict__ s, const float* __restrict__ gs,
                                                        const float* __restrict__ c2, DStage crop_st, int ci, int cj, int H, int W,
                                                        int r, float eps, float c_fit, int accumulate, float* __restrict__ p,
@@ -1717,7 +1752,8 @@ __global__ void __launch_bounds__(kBlock) k_bwd_update(const float* __restrict__
       const unsigned rem = (unsigned)i - (unsigned)c * plane;
       const int y = (int)(rem / (unsigned)W), x = (int)(rem - (unsigned)y * (unsigned)W);
       if (MODE == 1) gx = blur_fold(c2 + (size_t)c * (H + 2 * r) * (W + 2 * r), H, W, r, y, x);
-      else gx = crop_bwd_value(crop_st, gs, ci, cj, c, y, x) + imgfit_grad(s[i], c_fit);
+      else gx = ((T > 0) ? crop_bwd_value_w<(T > 0 ? T : 1)>(crop_st, gs, ci, cj, c, y, x) : crop_bwd_value(crop_st, gs, ci, cj, c, y, x)) +
+                imgfit_grad(s[i], c_fit);
     }
     float pp = p[i];
     const float t = tanhf(pp);

@@ -32,6 +32,12 @@ def main():
         plans, B = [Plan.llava(H, W)], 64
         kw = dict(use_crop=True, blur_kernel=5)
         crop = (20, 30, 280, 300)
+    elif which in ("mllama-crop", "qwen2vl-crop", "phi3-crop"):      # a window the plan's stage 0 does not compose with: two launches each way
+        H = W = 336 if which == "mllama-crop" else 512
+        mk = {"mllama-crop": Plan.mllama, "qwen2vl-crop": Plan.qwen2vl, "phi3-crop": Plan.phi3}[which]
+        plans, B = [mk(H, W)], 64
+        kw = dict(use_crop=True)
+        crop = (20, 30, H - 56, H - 36)
     elif which == "cross":                       # BASELINE configs 4/5 in the shape tools/generic_bench.py times
         H = W = 336
         plans, B, kw = [Plan.phi3(H, W), Plan.qwen2vl(H, W), Plan.mllama(H, W)], 16, dict(blur_kernel=5, cross_mode=True)
