@@ -48,6 +48,7 @@ static int32_t fail(int32_t code, const std::string& msg) {
 static int g_generic_kernels = 0;
 static int g_pair_nt_loads = 0;
 static int g_xcd_map = 2;        // ADVX_TUNE_XCD_MAP: 0 = grids as they come (rounds 1-3), 1 = gx padded to a multiple of 8, 2 = padded + a contiguous range of column blocks per XCD
+static int g_blur_threads = 512; // ADVX_TUNE_BLUR_THREADS: threads per 32 x 32 tile of the merged blur backward (256: rounds 1-3)
 static int g_head3 = 50;         // ADVX_TUNE_HEAD3: canvases of >= value * 1000 positions take the three-channel windowed forward (0: never)
 static int g_row_batch = 1;      // ADVX_TUNE_ROW_BATCH: the transposed resizes load the taps of one window row together (k_stage_bwd3_rb)
 constexpr int kImgXcdRows = 8;   // rows per group of the XCD-aware image grids (xcd_band_block)
@@ -65,6 +66,11 @@ extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
     g_row_batch = 1;
     g_img_xcd = kImgXcdRows;
     g_head3 = 50;
+    g_blur_threads = 512;
+    return ADVX_OK;
+  }
+  if (what == ADVX_TUNE_BLUR_THREADS) {
+    g_blur_threads = (value == 256) ? 256 : 512;
     return ADVX_OK;
   }
   if (what == ADVX_TUNE_HEAD3) {
@@ -1981,8 +1987,14 @@ static void launch_blur_bwd_fused(int r, const float* gsrc, const float* s, int 
                                   const OptScalars& o, double* partials, hipStream_t st) {
   dim3 grid((W + kBlurTile - 1) / kBlurTile, (H + kBlurTile - 1) / kBlurTile, 3);
 #define ADVX_BWD_R(R_)                                                                                                  \
-  hipLaunchKernelGGL((k_blur_bwd_fused<R_, UPDATE>), grid, dim3(kBlock), 0, st, gsrc, s, H, W, sigma, eps, c_fit, accumulate, p, \
-                     m, v, grad, mask, o, partials)
+  do {                                                                                                                  \
+    if (g_blur_threads == 512 && R_ <= 4)                                                                               \
+      hipLaunchKernelGGL((k_blur_bwd_fused<(R_ <= 4 ? R_ : 1), UPDATE, 512>), grid, dim3(512), 0, st, gsrc, s, H, W, sigma, eps, c_fit, \
+                         accumulate, p, m, v, grad, mask, o, partials);                                                  \
+    else                                                                                                                \
+      hipLaunchKernelGGL((k_blur_bwd_fused<R_, UPDATE>), grid, dim3(kBlock), 0, st, gsrc, s, H, W, sigma, eps, c_fit, accumulate, p, \
+                         m, v, grad, mask, o, partials);                                                                 \
+  } while (0)
   switch (r) {
     case 1: ADVX_BWD_R(1); break;
     case 2: ADVX_BWD_R(2); break;

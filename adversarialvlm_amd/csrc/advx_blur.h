@@ -59,8 +59,8 @@ __device__ inline void blur_weights_fetch(const float* __restrict__ wn, float (&
 // ------------------------------------------------------------------------------ forward
 // k_blur<0, IN> with x0 epilogue: s = x0 + blur(IN == 1 ? eps*tanh(in) : in), statistics partials per tile.
 // blockIdx.z == 3: tap-table builder blocks riding in the launch (as in k_blur<0, 1>).
-template <int IN, int R>
-__global__ void __launch_bounds__(kBlock) k_blur_fwd_r(const float* __restrict__ in, int H, int W, float sigma,
+template <int IN, int R, int BT = kBlock>   // BT: threads per workgroup; 512 measured SLOWER here at radius 4 (10.7 -> 13.7 us: 3.1 / 2.5 elements per thread leave a quarter of the slots idle), level at radius 2
+__global__ void __launch_bounds__(BT) k_blur_fwd_r(const float* __restrict__ in, int H, int W, float sigma,
                                                        const float* __restrict__ x0, float* __restrict__ out,
                                                        double* __restrict__ partials, float scalar, TapBuild taps0,
                                                        TapBuild taps1, int tap_blocks) {
@@ -74,8 +74,8 @@ __global__ void __launch_bounds__(kBlock) k_blur_fwd_r(const float* __restrict__
     }
     return;
   }
-  constexpr int K = 2 * R + 1, TS = kBlurTile + 2 * R, NE = TS * TS, NL = (NE + kBlock - 1) / kBlock;
-  constexpr int NR = (TS * kBlurTile + kBlock - 1) / kBlock, NO = kBlurTile * kBlurTile / kBlock;
+  constexpr int K = 2 * R + 1, TS = kBlurTile + 2 * R, NE = TS * TS, NL = (NE + BT - 1) / BT;
+  constexpr int NR = (TS * kBlurTile + BT - 1) / BT, NO = kBlurTile * kBlurTile / BT;
   __shared__ float tile[TS][TS + 1];
   __shared__ float tmp[TS][kBlurTile + 1];
   __shared__ float wn[K];
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(kBlock) k_blur_fwd_r(const float* __restrict__
   float v[NL];
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
-    const int e = (int)threadIdx.x + j * kBlock;
+    const int e = (int)threadIdx.x + j * BT;
     v[j] = 0.0f;
     if (e < NE) {
       const int ty = e / TS, tx = e - ty * TS;
@@ -97,13 +97,13 @@ __global__ void __launch_bounds__(kBlock) k_blur_fwd_r(const float* __restrict__
   float xv[NO];
 #pragma unroll
   for (int j = 0; j < NO; ++j) {
-    const int e = (int)threadIdx.x + j * kBlock;
+    const int e = (int)threadIdx.x + j * BT;
     const int oy = oy0 + e / kBlurTile, ox = ox0 + (e & (kBlurTile - 1));
     xv[j] = (x0 != nullptr && oy < H && ox < W) ? x0[((size_t)c * H + oy) * W + ox] : 0.0f;
   }
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
-    const int e = (int)threadIdx.x + j * kBlock;
+    const int e = (int)threadIdx.x + j * BT;
     if (e < NE) {
       const int ty = e / TS, tx = e - ty * TS;
       float t = v[j];
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(kBlock) k_blur_fwd_r(const float* __restrict__
   blur_weights_fetch<R>(wn, w);
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
-    const int e = (int)threadIdx.x + j * kBlock;
+    const int e = (int)threadIdx.x + j * BT;
     if (e < TS * kBlurTile) {
       const int ty = e / kBlurTile, x = e & (kBlurTile - 1);
       float a = 0.0f;
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(kBlock) k_blur_fwd_r(const float* __restrict__
   double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int j = 0; j < NO; ++j) {
-    const int e = (int)threadIdx.x + j * kBlock;
+    const int e = (int)threadIdx.x + j * BT;
     const int y = e / kBlurTile, x = e & (kBlurTile - 1);
     const int oy = oy0 + y, ox = ox0 + x;
     if (oy < H && ox < W) {
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(kBlock) k_blur_fwd_r(const float* __restrict__
   }
   if (partials != nullptr) {
     const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    block_sum_store<kStatSlots>(acc, partials + blk * kStatSlots);
+    block_sum_store<kStatSlots, BT>(acc, partials + blk * kStatSlots);
   }
 }
 
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(kBlock) k_blur_fwd_r(const float* __restrict__
 // folds (77 % of the tiles at 512^2, k = 9): the window is the tile itself, 32 + 2R inputs per side with a compile-time
 // row length, no bounds tests, seven loads per thread instead of eleven slots, one c2 term per pixel.  Same operations
 // per element as the general form.
-template <int R, bool UPDATE, bool INTERIOR>
+template <int R, bool UPDATE, bool INTERIOR, int BT>
 __device__ inline void blur_bwd_body(const float* __restrict__ gsrc, const float* __restrict__ s, int H, int W, float eps,
                                      float c_fit, int accumulate, float* __restrict__ p, float* __restrict__ m,
                                      float* __restrict__ v, float* __restrict__ grad, const float* __restrict__ mask,
@@ -177,8 +177,8 @@ __device__ inline void blur_bwd_body(const float* __restrict__ gsrc, const float
                                      float (*c2t)[kBlurTile + 3 * R + 1]) {
   constexpr int K = 2 * R + 1, TI = kBlurTile + 5 * R;
   constexpr int TC = kBlurTile + 2 * R;                       // interior: inputs per side
-  constexpr int NL = INTERIOR ? (TC * TC + kBlock - 1) / kBlock : (TI * TI + kBlock - 1) / kBlock;
-  constexpr int NO = kBlurTile * kBlurTile / kBlock;
+  constexpr int NL = INTERIOR ? (TC * TC + BT - 1) / BT : (TI * TI + BT - 1) / BT;
+  constexpr int NO = kBlurTile * kBlurTile / BT;
   const int c = blockIdx.z;
   const int oy0 = blockIdx.y * kBlurTile, ox0 = blockIdx.x * kBlurTile;
   const int ty_hi = min(oy0 + kBlurTile, H) - 1, tx_hi = min(ox0 + kBlurTile, W) - 1;
@@ -196,7 +196,7 @@ __device__ inline void blur_bwd_body(const float* __restrict__ gsrc, const float
   float pp[NO], mk[NO], mm[NO], vv[NO], g0[NO];
 #pragma unroll
   for (int j = 0; j < NO; ++j) {
-    const int e = (int)threadIdx.x + j * kBlock;
+    const int e = (int)threadIdx.x + j * BT;
     const int y = oy0 + e / kBlurTile, x = ox0 + (e & (kBlurTile - 1));
     pp[j] = mk[j] = mm[j] = vv[j] = g0[j] = 0.0f;
     if (INTERIOR || (y < H && x < W)) {
@@ -218,7 +218,7 @@ __device__ inline void blur_bwd_body(const float* __restrict__ gsrc, const float
   float gv[NL], sv[NL];
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
-    const int e = (int)threadIdx.x + j * kBlock;
+    const int e = (int)threadIdx.x + j * BT;
     gv[j] = 0.0f;
     sv[j] = 0.0f;
     if (e < ne) {
@@ -233,7 +233,7 @@ __device__ inline void blur_bwd_body(const float* __restrict__ gsrc, const float
   }
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
-    const int e = (int)threadIdx.x + j * kBlock;
+    const int e = (int)threadIdx.x + j * BT;
     if (e < ne) {
       const int iy = INTERIOR ? e / TC : (int)__umulhi((unsigned)e, magic), ix = e - iy * iw;
       const int gy = wy0 - R + iy, gx = wx0 - R + ix;
@@ -248,7 +248,7 @@ __device__ inline void blur_bwd_body(const float* __restrict__ gsrc, const float
   {
     // e / ww by multiplication (exact for e < 2^16); a one-column window divides by one
     const unsigned mw = (!INTERIOR && ww > 1) ? (unsigned)((0x100000000ULL + (unsigned)ww - 1) / (unsigned)ww) : 0u;
-    for (int e = threadIdx.x; e < ih * ww; e += kBlock) {
+    for (int e = threadIdx.x; e < ih * ww; e += BT) {
       const int iy = INTERIOR ? e / kBlurTile : ((ww > 1) ? (int)__umulhi((unsigned)e, mw) : e), x = e - iy * ww;
       float a = 0.0f;
 #pragma unroll
@@ -256,7 +256,7 @@ __device__ inline void blur_bwd_body(const float* __restrict__ gsrc, const float
       tmp[iy][x] = a;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < wh * ww; e += kBlock) {
+    for (int e = threadIdx.x; e < wh * ww; e += BT) {
       const int y = INTERIOR ? e / kBlurTile : ((ww > 1) ? (int)__umulhi((unsigned)e, mw) : e), x = e - y * ww;
       float a = 0.0f;
 #pragma unroll
@@ -268,7 +268,7 @@ __device__ inline void blur_bwd_body(const float* __restrict__ gsrc, const float
   double nacc[1] = {0.0};
 #pragma unroll
   for (int j = 0; j < NO; ++j) {
-    const int e = (int)threadIdx.x + j * kBlock;
+    const int e = (int)threadIdx.x + j * BT;
     const int y = oy0 + e / kBlurTile, x = ox0 + (e & (kBlurTile - 1));
     if (INTERIOR || (y < H && x < W)) {
       float gx = 0.0f;
@@ -312,13 +312,15 @@ __device__ inline void blur_bwd_body(const float* __restrict__ gsrc, const float
   }
   if (UPDATE) {
     const int blk = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    block_sum_store<1>(nacc, partials + blk);
+    block_sum_store<1, BT>(nacc, partials + blk);
     if (blk == 0 && threadIdx.x == 0) partials[kNormCountSlot] = (double)(gridDim.x * gridDim.y * gridDim.z);
   }
 }
 
-template <int R, bool UPDATE>
-__global__ void __launch_bounds__(kBlock) k_blur_bwd_fused(const float* __restrict__ gsrc, const float* __restrict__ s,
+// BT: threads per tile.  512 (eight waves: half the serial work per thread, 72 instead of 90 VGPRs) is the host's default for
+// radius <= 4: 14.5 -> 13.3-14.1 us at radius 4, 10.5 -> 9.0-9.5 at radius 2 (round 4)
+template <int R, bool UPDATE, int BT = kBlock>
+__global__ void __launch_bounds__(BT) k_blur_bwd_fused(const float* __restrict__ gsrc, const float* __restrict__ s,
                                                            int H, int W, float sigma,
                                                            float eps, float c_fit, int accumulate, float* __restrict__ p,
                                                            float* __restrict__ m, float* __restrict__ v,
@@ -336,9 +338,9 @@ __global__ void __launch_bounds__(kBlock) k_blur_bwd_fused(const float* __restri
   const bool interior = oy0 >= kBlurTile && ox0 >= kBlurTile && oy0 + kBlurTile - 1 + 2 * R < H - 1 &&
                         ox0 + kBlurTile - 1 + 2 * R < W - 1;
   if (interior)
-    blur_bwd_body<R, UPDATE, true>(gsrc, s, H, W, eps, c_fit, accumulate, p, m, v, grad, mask, o, partials, wn, tile, tmp, c2t);
+    blur_bwd_body<R, UPDATE, true, BT>(gsrc, s, H, W, eps, c_fit, accumulate, p, m, v, grad, mask, o, partials, wn, tile, tmp, c2t);
   else
-    blur_bwd_body<R, UPDATE, false>(gsrc, s, H, W, eps, c_fit, accumulate, p, m, v, grad, mask, o, partials, wn, tile, tmp, c2t);
+    blur_bwd_body<R, UPDATE, false, BT>(gsrc, s, H, W, eps, c_fit, accumulate, p, m, v, grad, mask, o, partials, wn, tile, tmp, c2t);
 }
 
 // ------------------------------------------------------- backward of step t + forward blur of step t+1

@@ -224,11 +224,11 @@ __device__ inline double wave_sum_to_last_lane(double v) {
 // over the 64 positions.  Rounds 1-3 ran the tree in EVERY wave and added the four wave totals last: NS x 21 VALU
 // instructions in each wave of every workgroup of the image-sized launches, which are bound by the instructions their SIMDs
 // have to issue (k_plan_tail: ~150 of ~700 per thread).  Now the waves above 0 store their NS values and are done; wave 0
-// reads them, adds and runs the NS trees: (NS x 27 + 3 x NS) / 4 per wave on average.  (Blocks of 64..kBlock threads, a
+// reads them, adds and runs the NS trees: (NS x 27 + 3 x NS) / 4 per wave on average.  (Blocks of 64..MAXT threads, a
 // multiple of 64.)
-template <int NS>
+template <int NS, int MAXT = kBlock>
 __device__ inline void block_sum_store(const double (&acc)[NS], double* dst) {
-  __shared__ double red[NS][kBlock];
+  __shared__ double red[NS][MAXT];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave, nw = (int)(blockDim.x / kWave);
   if (wid > 0) {
 #pragma unroll
@@ -237,20 +237,36 @@ __device__ inline void block_sum_store(const double (&acc)[NS], double* dst) {
   __syncthreads();
   if (wid == 0) {
     // every value of the other waves is read before the first addition (one LDS round trip, not one per wave and slot)
-    constexpr int MW = kBlock / kWave;
-    double o[NS][MW - 1];
+    constexpr int MW = MAXT / kWave;
+    if (MW <= 4) {
+      double o[NS][MW - 1];
 #pragma unroll
-    for (int k = 0; k < NS; ++k)
+      for (int k = 0; k < NS; ++k)
 #pragma unroll
-      for (int w = 1; w < MW; ++w) o[k][w - 1] = (w < nw) ? red[k][w * kWave + lane] : 0.0;
+        for (int w = 1; w < MW; ++w) o[k][w - 1] = (w < nw) ? red[k][w * kWave + lane] : 0.0;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      double v = acc[k];
+      for (int k = 0; k < NS; ++k) {
+        double v = acc[k];
 #pragma unroll
-      for (int w = 1; w < MW; ++w)
-        if (w < nw) v += o[k][w - 1];
-      v = wave_sum_to_last_lane(v);
-      if (lane == kWave - 1) dst[k] = v;
+        for (int w = 1; w < MW; ++w)
+          if (w < nw) v += o[k][w - 1];
+        v = wave_sum_to_last_lane(v);
+        if (lane == kWave - 1) dst[k] = v;
+      }
+    } else {
+      // eight waves: one slot's values at a time (all slots at once would be 14 (MW - 1) NS registers)
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        double o[MW - 1];
+#pragma unroll
+        for (int w = 1; w < MW; ++w) o[w - 1] = (w < nw) ? red[k][w * kWave + lane] : 0.0;
+        double v = acc[k];
+#pragma unroll
+        for (int w = 1; w < MW; ++w)
+          if (w < nw) v += o[w - 1];
+        v = wave_sum_to_last_lane(v);
+        if (lane == kWave - 1) dst[k] = v;
+      }
     }
   }
   __syncthreads();  // dst may be shared memory; `red` may be reused by a following call
