@@ -82,6 +82,7 @@ SIGNATURES = {
     "advx_crop_composes": (_I32, [_P, _I32, _I32, _P]),
     "advx_crop_compose_strides": (_I32, [_P, _I32, _I32, _P, _PI32, _PI32]),
     "advx_crop_compose_rows": (_I32, [_P, _I32, _I32, _P, _PI32, _PI32]),
+    "advx_image_grid_map": (_I32, [_I32, _I32, _I32, _I32, _PI32, _PI32]),
     "advx_collect_crop": (_I32, [_P, _P, _I32, _P, _I32, _P, _I64, _I32, _I32, _P, _P, _P]),
     "advx_emit_multi": (_I32, [_I32, _P, _P, _P, _P, _P, _I32, _U64, _P, _P, _P, _P, _I32, _P]),
     "advx_collect_multi": (_I32, [_I32, _P, _P, _P, _P, _I32, _P, _P, _P]),

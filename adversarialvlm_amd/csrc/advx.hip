@@ -735,6 +735,32 @@ static inline ImgGrid img_grid(unsigned gx, unsigned gy, unsigned gz, dim3* laun
   return g;
 }
 
+// The XCD-aware grid of an image-sized launch, for host-side tests: how many workgroups a (gx, gy, gz) grid with `riders`
+// extra blocks is launched with under the current ADVX_TUNE_IMG_XCD, and (logical != NULL, room for that many) the logical
+// block each physical block takes: 0 .. gx*gy*gz-1 = (x fastest, then y, then z), gx*gy*gz .. +riders-1 = rider blocks, -1 = padding.
+extern "C" int32_t advx_image_grid_map(int32_t gx, int32_t gy, int32_t gz, int32_t riders, int32_t* launch_blocks, int32_t* logical) {
+  REQUIRE(gx > 0 && gy > 0 && gz > 0 && riders >= 0 && launch_blocks, ADVX_E_BADARG, "advx_image_grid_map: bad argument");
+  REQUIRE((long long)gx * gy * gz + riders < (1LL << 30), ADVX_E_BADARG, "advx_image_grid_map: grid too large");
+  dim3 launch;
+  const ImgGrid ig = img_grid((unsigned)gx, (unsigned)gy, (unsigned)gz, &launch, (unsigned)riders);
+  const unsigned body = (unsigned)gx * gy * gz;
+  *launch_blocks = (int32_t)(launch.x * launch.y * launch.z);
+  if (logical) {
+    for (unsigned b = 0; b < launch.x * launch.y * launch.z; ++b) {
+      if (!ig.banded) {
+        // (x, y, z) grid: the rider layer is z == 0, the plans follow
+        const unsigned per = (unsigned)gx * gy, z = b / per, r = b - z * per;
+        if (riders > 0) logical[b] = (z == 0) ? ((r < (unsigned)riders) ? (int32_t)(body + r) : -1) : (int32_t)((z - 1) * per + r);
+        else logical[b] = (int32_t)b;
+      } else {
+        const unsigned L = xcd_group_logical(b, ig.group);
+        logical[b] = (L < body + ig.extra) ? (int32_t)L : -1;
+      }
+    }
+  }
+  return ADVX_OK;
+}
+
 // ---------------------------------------------------------- windowed resizes (advx_resize.h)
 // T = compiled window size that holds `need` taps per axis (0: none - the run-time-loop kernels take over)
 static inline int pick_window(int need) {

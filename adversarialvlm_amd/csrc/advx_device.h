@@ -384,6 +384,12 @@ __device__ inline float4 philox_normal4_pixel(unsigned long long i, unsigned bq,
 // i % group.  One XCD then fetches the source rows of its row groups (+ the window's halo) only - and, unlike whole bands of
 // rows per XCD (measured: a crop window that leaves the first and last rows of the image empty, or a multi-plan grid sized
 // for its largest canvas, left some XCDs without work and cost 1-4 us), every XCD gets the same share of every region.
+// logical block of physical block b (XCD b % 8's (b / 8)-th block) for groups of `group` logical blocks dealt to the XCDs in turn
+__host__ __device__ inline unsigned xcd_group_logical(unsigned b, unsigned group) {
+  const unsigned k = b & 7u, i = b >> 3;
+  const unsigned q = i / group;
+  return (q * 8u + k) * group + (i - q * group);
+}
 struct BlockXYZ { unsigned x, y, z; };
 // the logical grid of a launch (host: img_grid).  extra: blocks appended behind the gx * gy * gz of the grid (riders: table
 // builders); they come back as z == gz, x = index
@@ -394,9 +400,7 @@ __device__ inline bool xcd_band_block(const ImgGrid& ig, BlockXYZ& b) {
     return true;
   }
   const unsigned gx = ig.gx, gy = ig.gy, gz = ig.gz;
-  const unsigned k = blockIdx.x & 7u, i = blockIdx.x >> 3;
-  const unsigned q = i / ig.group;
-  const unsigned L = (q * 8u + k) * ig.group + (i - q * ig.group);
+  const unsigned L = xcd_group_logical(blockIdx.x, ig.group);
   const unsigned body = gx * gy * gz;
   if (L >= body) {
     b.x = L - body; b.y = 0; b.z = gz;

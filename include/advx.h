@@ -255,6 +255,11 @@ int32_t advx_crop_composes(const advx_plan* plan, int32_t H, int32_t W, const in
 /* row lengths (upper bounds) of the composed tables per axis (0 = H, 1 = W); host only, for the tests */
 int32_t advx_crop_compose_strides(const advx_plan* plan, int32_t H, int32_t W, const int32_t* crop_ijhw, int32_t forward[2],
                                   int32_t transposed[2]);
+/* Host-side view of the XCD-aware grids of the image-sized launches (tests): the number of workgroups a (gx, gy, gz) grid with
+ * `riders` extra blocks is launched with under the current ADVX_TUNE_IMG_XCD and, if `logical` is given (room for that many), the
+ * logical block of every physical one: x fastest, then y, then z; riders behind them; -1 = padding. */
+int32_t advx_image_grid_map(int32_t gx, int32_t gy, int32_t gz, int32_t riders, int32_t* launch_blocks, int32_t* logical);
+
 /* The composed tables' REAL longest rows for this window (forward, transposed; the larger of the two axes each): the gathers
  * pick their compiled windows by these (rows of up to 6 taps), the strides above only size the tables.  Host arithmetic. */
 int32_t advx_crop_compose_rows(const advx_plan* plan, int32_t H, int32_t W, const int32_t* crop_ijhw, int32_t* forward,

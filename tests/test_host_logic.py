@@ -405,3 +405,46 @@ def test_product_registry_has_no_test_models_until_a_plugin_module_brings_them()
     env["ADVX_PLUGIN_MODULES"] = "adversarialvlm_amd.testing"
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=env, timeout=120)
     assert res.returncode == 0 and res.stdout.strip() == "found", res.stderr[-2000:]
+
+
+def test_xcd_aware_image_grids_are_a_bijection():
+    """Round 4: the image-sized gathers run 1-D grids on which groups of rows of workgroups are dealt to the 8 XCDs in turn
+    (xcd_band_block).  Whatever the grid, the number of riders and the group size: every logical block is some physical block's,
+    exactly once; the rest is padding; and XCD k (physical blocks = k mod 8) works on whole groups."""
+    import ctypes as C
+    import numpy as np
+    from adversarialvlm_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(5)
+    cases = [(3, 336, 1, 0), (3, 336, 1, 8), (4, 512, 1, 0), (1, 1, 1, 0), (1, 56, 1, 2), (6, 672, 3, 0), (2, 7, 2, 5), (32, 4096, 1, 64)]
+    cases += [tuple(int(v) for v in (rng.integers(1, 9), rng.integers(1, 700), rng.integers(1, 4), rng.integers(0, 20))) for _ in range(40)]
+    try:
+        for rows in (8, 1, 3, 16, 4096, 0):
+            L.check(lib.advx_set_tuning(9, rows), "advx_set_tuning")          # ADVX_TUNE_IMG_XCD
+            for gx, gy, gz, riders in cases:
+                n = C.c_int32()
+                L.check(lib.advx_image_grid_map(gx, gy, gz, riders, C.byref(n), None), "advx_image_grid_map")
+                logical = np.zeros(n.value, np.int32)
+                L.check(lib.advx_image_grid_map(gx, gy, gz, riders, C.byref(n), logical.ctypes.data_as(C.POINTER(C.c_int32))),
+                        "advx_image_grid_map")
+                body = gx * gy * gz
+                live = logical[logical >= 0]
+                assert sorted(live.tolist()) == list(range(body + riders)), (rows, gx, gy, gz, riders)
+                if rows:
+                    assert n.value % 8 == 0
+                    group = gx * rows
+                    for k in range(8):                                          # XCD k: whole groups, each contiguous
+                        mine = logical[k::8]
+                        for g0 in range(0, len(mine), group):
+                            blk = mine[g0:g0 + group]
+                            first = int(xcd_first(k, g0 // group, group))
+                            want = np.arange(first, first + len(blk))
+                            want = np.where(want < body + riders, want, -1)
+                            assert np.array_equal(blk, want), (rows, gx, gy, gz, riders, k, g0)
+    finally:
+        L.check(lib.advx_set_tuning(0, 0), "advx_set_tuning")
+
+
+def xcd_first(k, q, group):
+    """first logical block of XCD k's q-th group"""
+    return (q * 8 + k) * group
