@@ -2155,7 +2155,11 @@ extern "C" int32_t advx_image_bwd_update(float* p, const float* s, const float* 
   (void)b.take(partial_floats(H, W));
   if (!crop) tables_forget(b.base + b.used);      // the buffers below are carved where a window's tables would sit
   double* partials = reinterpret_cast<double*>(update_scratch);
-  const int nblk = grid_for(n, 2048);
+  // workgroups of k_bwd_update: at most 2048 (the ||g|| partials' room), and when the image needs more than that at one
+  // element per thread, as many as give EVERY thread the same number of elements (786 432 elements: 1536 x 256 x 2, not 2048
+  // workgroups of which half the threads take a second turn)
+  const int per = (int)((((n + kBlock - 1) / kBlock) + 2047) / 2048);
+  const int nblk = (int)std::min<long long>(2048, (n + (long long)kBlock * per - 1) / ((long long)kBlock * per));
   const OptScalars o = to_dev(opt);
   DStage D;
   std::memset(&D, 0, sizeof(D));
