@@ -133,8 +133,10 @@ const char* advx_last_error(void);
                                      results are the same; the ||g|| partial of a tile is summed in another order */
 #define ADVX_TUNE_HEAD3 10          /* canvases of >= value * 1000 positions (default 50) are resized by the three-channel windowed forward;
                                      0: one thread per (channel, position) whatever the size (rounds 1-3).  Same results */
-#define ADVX_TUNE_ROW_BATCH 8       /* 1 (default): the transposed resize of advx_collect* loads the taps of one window row together;
-                                     0: one memory round trip per tap (rounds 1-3).  Same results bit for bit */
+#define ADVX_TUNE_ROW_BATCH 8       /* 1 (default): the gathers of the plans' resizes (advx_emit_multi / advx_forward_multi, advx_collect*, the prepared
+                                     chain's tail, the crop window's adjoint) run as compiled windows - every load of a thread in flight before the
+                                     first use - where their tables' rows have <= 4 taps (<= 6: the composed crop window), a window row at a time
+                                     up to 10; 0: one memory round trip per tap (rounds 1-3).  Same results bit for bit */
 #define ADVX_TUNE_PAIR_NT_LOADS 2   /* advx_fused_bwd reads grad_out with non-temporal loads (same results) */
 #define ADVX_TUNE_SEPARATE_CROP 4   /* 1: never compose a crop window with a plan's stage 0 (advx_forward_multi) - the window is resized
                                      * into `argument` and the plan resamples that, two launches each way, bit-identical to the
