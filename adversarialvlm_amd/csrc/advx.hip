@@ -3103,7 +3103,7 @@ extern "C" int32_t advx_prepared_bwd(advx_plan* p, const float* grad_out, int32_
     // the transposed gather as a compiled window where the tables' rows fit one (<= 4 taps) and the canvas gradient has one
     // of the three shapes that occur; else the run-time loops
     const CanvasGrad cg = stage_grad(p, 0, ws);
-    const int T = pick_window(std::max(D.tth.stride, D.ttw.stride));
+    const int T = g_row_batch ? pick_window(std::max(D.tth.stride, D.ttw.stride)) : 0;
     const int mode = (cg.copies == 1 && !cg.dgrad) ? 1 : (cg.copies == 1 && cg.dgrad) ? 2 : (cg.copies == 2 && !cg.dgrad) ? 3 : 0;
 #define ADVX_TAIL(T_, M_)                                                                                              \
   hipLaunchKernelGGL((k_plan_tail<T_, M_>), dim3(f.tail_blocks), dim3(kBlock), 0, st, D, cg, pp, x0, eps,               \
@@ -3147,7 +3147,7 @@ static int32_t prepared_grad_impl(advx_plan* p, const float* grad_out, int32_t b
   LAUNCH_CHECK();
   {
     const CanvasGrad cg = stage_grad(p, 0, ws);
-    const int T = pick_window(std::max(D.tth.stride, D.ttw.stride));
+    const int T = g_row_batch ? pick_window(std::max(D.tth.stride, D.ttw.stride)) : 0;
     const int mode = (cg.copies == 1 && !cg.dgrad) ? 1 : (cg.copies == 1 && cg.dgrad) ? 2 : (cg.copies == 2 && !cg.dgrad) ? 3 : 0;
 #define ADVX_TG(T_, M_)                                                                                                   \
   hipLaunchKernelGGL((k_plan_tail_grad<T_, M_>), dim3(f.tail_blocks), dim3(kBlock), 0, st, D, cg, pp, x0, eps,             \
