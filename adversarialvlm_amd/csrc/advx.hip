@@ -48,6 +48,7 @@ static int32_t fail(int32_t code, const std::string& msg) {
 static int g_generic_kernels = 0;
 static int g_pair_nt_loads = 0;
 static int g_xcd_map = 2;        // ADVX_TUNE_XCD_MAP: 0 = grids as they come (rounds 1-3), 1 = gx padded to a multiple of 8, 2 = padded + a contiguous range of column blocks per XCD
+static int g_tail3 = 1;          // ADVX_TUNE_TAIL3: the prepared chain's image kernels on the three-channel partition from kRows3MinPositions up
 static int g_blur_threads = 512; // ADVX_TUNE_BLUR_THREADS: threads per 32 x 32 tile of the merged blur backward (256: rounds 1-3)
 static int g_head3 = 50;         // ADVX_TUNE_HEAD3: canvases of >= value * 1000 positions take the three-channel windowed forward (0: never)
 static int g_row_batch = 1;      // ADVX_TUNE_ROW_BATCH: the transposed resizes load the taps of one window row together (k_stage_bwd3_rb)
@@ -67,6 +68,11 @@ extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
     g_img_xcd = kImgXcdRows;
     g_head3 = 50;
     g_blur_threads = 512;
+    g_tail3 = 1;
+    return ADVX_OK;
+  }
+  if (what == ADVX_TUNE_TAIL3) {
+    g_tail3 = value ? 1 : 0;
     return ADVX_OK;
   }
   if (what == ADVX_TUNE_BLUR_THREADS) {
@@ -2962,15 +2968,27 @@ struct PreparedScratch {
   double* img_rows[2];
   double* norm_rows;
   int tail_blocks, prep_blocks;
+  bool three;          // the three-channel partition (k_prep_rows3 / k_plan_tail3 / k_plan_update3): large images
+  dim3 grid3;
 };
+// large images: workgroup = (chunk of 256 pixels of a row, row), three channels per thread (measured: pays from 250 k positions)
+bool prepared_three(const advx_plan* p) {
+  return !g_generic_kernels && g_tail3 && (long long)p->info.in_h * p->info.in_w >= kRows3MinPositions;
+}
+long long prepared_flat_rows(const advx_plan* p) { return (3LL * p->info.in_h * p->info.in_w + kBlock - 1) / kBlock; }
+long long prepared_rows_now(const advx_plan* p) {
+  return prepared_three(p) ? (long long)((p->info.in_w + kBlock - 1) / kBlock) * p->info.in_h : prepared_flat_rows(p);
+}
 PreparedScratch carve_prepared(const advx_plan* p, float* scratch) {
   PreparedScratch f;
-  const long long n = 3LL * p->info.in_h * p->info.in_w;
-  f.tail_blocks = (int)((n + kBlock - 1) / kBlock);
-  // the preparing launch uses the row partition of k_plan_tail (one row per 256 pixels): a run
-  // that re-prepares (first step, resume) then sums exactly what an uninterrupted run sums
+  f.three = prepared_three(p);
+  f.grid3 = dim3((p->info.in_w + kBlock - 1) / kBlock, p->info.in_h);
+  f.tail_blocks = (int)prepared_rows_now(p);
+  // the preparing launch uses the row partition of the tail: a run that re-prepares (first step, resume) then sums exactly
+  // what an uninterrupted run sums
   f.prep_blocks = f.tail_blocks;
-  const size_t rows = (size_t)std::max(f.tail_blocks, f.prep_blocks);
+  // the scratch is carved for the flat partition (the larger one) whichever is in use
+  const size_t rows = (size_t)std::max<long long>(prepared_flat_rows(p), f.tail_blocks);
   double* d = reinterpret_cast<double*>(scratch);
   f.img_rows[0] = d;
   f.img_rows[1] = d + rows * kStatSlots;
@@ -2996,9 +3014,8 @@ extern "C" int64_t advx_prepared_scratch_floats(const advx_plan* p) {
 
 extern "C" int32_t advx_prepared_rows(const advx_plan* p, int32_t* rows_after_prepare, int32_t* rows_after_bwd) {
   REQUIRE(p && rows_after_prepare && rows_after_bwd, ADVX_E_BADARG, "advx_prepared_rows: null argument");
-  const long long n = 3LL * p->info.in_h * p->info.in_w;
-  *rows_after_prepare = (int32_t)((n + kBlock - 1) / kBlock);
-  *rows_after_bwd = (int32_t)((n + kBlock - 1) / kBlock);
+  *rows_after_prepare = (int32_t)prepared_rows_now(p);
+  *rows_after_bwd = (int32_t)prepared_rows_now(p);
   return ADVX_OK;
 }
 
@@ -3048,7 +3065,10 @@ extern "C" int32_t advx_prepared_fwd(advx_plan* p, const float* pp, const float*
   const long long n = 3LL * p->info.in_h * p->info.in_w;
   if (!prepared) {
     // first step, or p was changed elsewhere: s, its statistics partials and the canvas
-    hipLaunchKernelGGL(k_prep<true>, dim3(f.prep_blocks), dim3(kBlock), 0, st, pp, x0, eps, n, s_buf, f.img_rows[parity]);
+    if (f.three)
+      hipLaunchKernelGGL(k_prep_rows3, f.grid3, dim3(kBlock), 0, st, pp, x0, eps, p->info.in_h, p->info.in_w, s_buf, f.img_rows[parity]);
+    else
+      hipLaunchKernelGGL(k_prep<true>, dim3(f.prep_blocks), dim3(kBlock), 0, st, pp, x0, eps, n, s_buf, f.img_rows[parity]);
     LAUNCH_CHECK();
     prepared_canvases(p, s_buf, ws, nullptr, 0, stats, st);
     LAUNCH_CHECK();
@@ -3092,7 +3112,7 @@ extern "C" int32_t advx_prepared_bwd(advx_plan* p, const float* grad_out, int32_
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   PreparedScratch f = carve_prepared(p, scratch);
-  REQUIRE(rows_in >= 0 && rows_in <= std::max(f.tail_blocks, f.prep_blocks), ADVX_E_BADARG, "advx_prepared_bwd: rows_in out of range");
+  REQUIRE(rows_in >= 0 && rows_in <= std::max<long long>(prepared_flat_rows(p), f.tail_blocks), ADVX_E_BADARG, "advx_prepared_bwd: rows_in out of range");
   const DStage& D = p->dstage[0];
   const long long n = 3LL * p->info.in_h * p->info.in_w;
   rc = reduce_to_canvas(p, grad_out, batch, ws, st);
@@ -3110,10 +3130,22 @@ extern "C" int32_t advx_prepared_bwd(advx_plan* p, const float* grad_out, int32_
                      imgfit_scale / (float)n, mask, m, v, grad_p, to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows, \
                      (const double*)f.img_rows[parity], (int)rows_in, stats)
 #define ADVX_TAIL_M(T_) do { if (mode == 1) ADVX_TAIL(T_, 1); else if (mode == 2) ADVX_TAIL(T_, 2); else ADVX_TAIL(T_, 3); } while (0)
-    if (!T || !mode) ADVX_TAIL(0, 0);
+#define ADVX_TAIL3(T_, M_)                                                                                             \
+  hipLaunchKernelGGL((k_plan_tail3<T_, M_>), f.grid3, dim3(kBlock), 0, st, D, cg, pp, x0, eps,                           \
+                     imgfit_scale / (float)n, mask, m, v, grad_p, to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows, \
+                     (const double*)f.img_rows[parity], (int)rows_in, stats)
+#define ADVX_TAIL3_M(T_) do { if (mode == 1) ADVX_TAIL3(T_, 1); else if (mode == 2) ADVX_TAIL3(T_, 2); else ADVX_TAIL3(T_, 3); } while (0)
+    if (f.three) {
+      if (!T || !mode) ADVX_TAIL3(0, 0);
+      else if (T == 2) ADVX_TAIL3_M(2);
+      else if (T == 3) ADVX_TAIL3_M(3);
+      else ADVX_TAIL3_M(4);
+    } else if (!T || !mode) ADVX_TAIL(0, 0);
     else if (T == 2) ADVX_TAIL_M(2);
     else if (T == 3) ADVX_TAIL_M(3);
     else ADVX_TAIL_M(4);
+#undef ADVX_TAIL3_M
+#undef ADVX_TAIL3
 #undef ADVX_TAIL_M
 #undef ADVX_TAIL
   }
@@ -3137,7 +3169,7 @@ static int32_t prepared_grad_impl(advx_plan* p, const float* grad_out, int32_t b
   REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_prepared_bwd_grad: batch out of range");
   REQUIRE(ws_floats >= p->info.workspace_floats, ADVX_E_SHAPE, "advx_prepared_bwd_grad: workspace too small");
   PreparedScratch f = carve_prepared(p, scratch);
-  REQUIRE(rows_in >= 0 && rows_in <= std::max(f.tail_blocks, f.prep_blocks), ADVX_E_BADARG,
+  REQUIRE(rows_in >= 0 && rows_in <= std::max<long long>(prepared_flat_rows(p), f.tail_blocks), ADVX_E_BADARG,
           "advx_prepared_bwd_grad: rows_in out of range");
   const DStage& D = p->dstage[0];
   const long long n = 3LL * p->info.in_h * p->info.in_w;
@@ -3150,7 +3182,7 @@ static int32_t prepared_grad_impl(advx_plan* p, const float* grad_out, int32_t b
     const int T = g_row_batch ? pick_window(std::max(D.tth.stride, D.ttw.stride)) : 0;
     const int mode = (cg.copies == 1 && !cg.dgrad) ? 1 : (cg.copies == 1 && cg.dgrad) ? 2 : (cg.copies == 2 && !cg.dgrad) ? 3 : 0;
 #define ADVX_TG(T_, M_)                                                                                                   \
-  hipLaunchKernelGGL((k_plan_tail_grad<T_, M_>), dim3(f.tail_blocks), dim3(kBlock), 0, st, D, cg, pp, x0, eps,             \
+  hipLaunchKernelGGL((k_plan_tail_grad<T_, M_>), dim3((unsigned)prepared_flat_rows(p)), dim3(kBlock), 0, st, D, cg, pp, x0, eps, \
                      imgfit_scale / (float)n, grad_p, (const double*)f.img_rows[parity], (int)rows_in, stats)
 #define ADVX_TG_M(T_) do { if (mode == 1) ADVX_TG(T_, 1); else if (mode == 2) ADVX_TG(T_, 2); else ADVX_TG(T_, 3); } while (0)
     if (!T || !mode) ADVX_TG(0, 0);
@@ -3179,13 +3211,21 @@ static int32_t prepared_update_impl(advx_plan* p, float* pp, float* m, float* v,
   PreparedScratch f = carve_prepared(p, scratch);
   const long long n = 3LL * p->info.in_h * p->info.in_w;
   if (comm) {
-    hipLaunchKernelGGL(k_plan_update<true>, dim3(f.tail_blocks), dim3(kBlock), 0, st, pp, m, v, grad_p, mask, x0, eps, n,
-                       to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows, *comm);
+    if (f.three)
+      hipLaunchKernelGGL(k_plan_update3<true>, f.grid3, dim3(kBlock), 0, st, pp, m, v, grad_p, mask, x0, eps, p->info.in_h, p->info.in_w,
+                         to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows, *comm);
+    else
+      hipLaunchKernelGGL(k_plan_update<true>, dim3(f.tail_blocks), dim3(kBlock), 0, st, pp, m, v, grad_p, mask, x0, eps, n,
+                         to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows, *comm);
   } else {
     CommDev none;
     std::memset(&none, 0, sizeof(none));
-    hipLaunchKernelGGL(k_plan_update<false>, dim3(f.tail_blocks), dim3(kBlock), 0, st, pp, m, v, grad_p, mask, x0, eps, n,
-                       to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows, none);
+    if (f.three)
+      hipLaunchKernelGGL(k_plan_update3<false>, f.grid3, dim3(kBlock), 0, st, pp, m, v, grad_p, mask, x0, eps, p->info.in_h, p->info.in_w,
+                         to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows, none);
+    else
+      hipLaunchKernelGGL(k_plan_update<false>, dim3(f.tail_blocks), dim3(kBlock), 0, st, pp, m, v, grad_p, mask, x0, eps, n,
+                         to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows, none);
   }
   LAUNCH_CHECK();
   prepared_canvases(p, s_next, ws, f.norm_rows, f.tail_blocks, stats, st);

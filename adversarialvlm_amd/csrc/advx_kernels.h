@@ -2209,6 +2209,185 @@ __global__ void __launch_bounds__(kBlock) k_plan_update(float* __restrict__ p, f
   block_sum_store2<kStatSlots, 1>(acc, img_rows_out + (size_t)blockIdx.x * kStatSlots, nacc, norm_rows + blockIdx.x);
 }
 
+// ---- the prepared chain's image kernels for LARGE images (host: 250 k positions and more), three channels per thread
+// workgroup = (chunk of kBlock pixels of one row, row), thread = the three channels of one pixel, partial row = chunk + chunks * row.
+// The taps and weights of the transposed resize are looked up once for the three channels, no thread divides to find its pixel
+// and a workgroup's block sums serve three elements per thread: k_plan_tail 11.4 -> 9.8 us at 512 x 512, 36 -> 26 at 1024 x 1024
+// (tools/exp_tail3.hip; at 336 x 336 the flat form is faster, as for the plain transposed resizes).  k_prep_rows3 and
+// k_plan_update3 run on the SAME partition, so a run that re-prepares (first step, resume) or splits the tail around an all-reduce
+// sums exactly what an uninterrupted single-rank run sums.  Per element the arithmetic is the flat kernels'.
+__global__ void __launch_bounds__(kBlock) k_prep_rows3(const float* __restrict__ p, const float* __restrict__ x0, float eps, int H,
+                                                       int W, float* __restrict__ out, double* __restrict__ partials) {
+  const int ys = blockIdx.y, xs = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned row = blockIdx.x + gridDim.x * blockIdx.y;
+  double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
+  if (xs < W) {
+    const size_t plane = (size_t)H * W, o0 = (size_t)ys * W + xs;
+    float pv[3], xv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { pv[c] = p[(size_t)c * plane + o0]; xv[c] = x0[(size_t)c * plane + o0]; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float x = eps * tanhf(pv[c]);
+      const float sv = xv[c] + x;
+      out[(size_t)c * plane + o0] = sv;
+      stat_accumulate(sv, x, acc);
+    }
+  }
+  block_sum_store<kStatSlots>(acc, partials + (size_t)row * kStatSlots);
+}
+
+// T, MODE as k_plan_tail's (T = 0: stage_bwd_value's loops, channel by channel)
+template <int T, int MODE>
+__global__ void __launch_bounds__(kBlock) k_plan_tail3(DStage st, CanvasGrad cg, float* __restrict__ p, const float* __restrict__ x0, float eps,
+                                                       float c_fit, const float* __restrict__ mask, float* __restrict__ m,
+                                                       float* __restrict__ v, float* __restrict__ grad_p, OptScalars o,
+                                                       float* __restrict__ s_next, double* __restrict__ img_rows_out,
+                                                       double* __restrict__ norm_rows, const double* __restrict__ img_rows_in,
+                                                       int img_rows_in_count, float* __restrict__ stats) {
+  constexpr int TT = (T > 0) ? T : 1;
+  constexpr int COPIES = (MODE == 3) ? 2 : 1;
+  constexpr bool DG = MODE == 2;
+  const int ys = blockIdx.y;
+  const int xs = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned row = blockIdx.x + gridDim.x * blockIdx.y;
+  if (row == 0 && img_rows_in_count > 0)
+    finalize_image_block<true, kFinImgU>(img_rows_in, img_rows_in_count, 3LL * st.src_h * st.src_w, stats);
+  double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
+  double nacc[1] = {0.0};
+  if (xs < st.src_w) {
+    const size_t plane_s = (size_t)st.src_h * st.src_w, o0 = (size_t)ys * st.src_w + xs;
+    float pp[3], xv[3], mk[3], mm[3], vv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const size_t i = (size_t)c * plane_s + o0;
+      pp[c] = p[i]; xv[c] = x0[i]; mk[c] = mask[i];
+      mm[c] = (o.kind == 0) ? m[i] : 0.0f;
+      vv[c] = (o.kind == 0) ? v[i] : 0.0f;
+    }
+    float gsum[3];
+    if (T > 0) {
+      // the transposed gather of k_stage_bwd3_w: the whole window of the three channels in flight
+      const int oy = st.tth.start[ys], oyc = st.tth.count[ys];
+      const int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
+      const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
+      const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
+      const size_t plane = (size_t)st.can_h * st.can_w;
+      const int ly = max(oyc - 1, 0), lx = max(oxc - 1, 0);
+      float wyv[TT], wxv[TT], r[3][TT][TT][COPIES + 1];
+#pragma unroll
+      for (int a = 0; a < TT; ++a) { wyv[a] = wy[min(a, ly)]; wxv[a] = wx[min(a, lx)]; }
+#pragma unroll
+      for (int a = 0; a < TT; ++a) {
+        const size_t rowc = (size_t)(st.off_y + oy + min(a, ly)) * st.can_w + st.off_x + ox;
+#pragma unroll
+        for (int b = 0; b < TT; ++b)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const size_t q = (size_t)c * plane + rowc + min(b, lx);
+#pragma unroll
+            for (int t = 0; t < COPIES; ++t) r[c][a][b][t] = cg.g[(size_t)t * cg.copy_stride + q];
+            if (DG) r[c][a][b][COPIES] = cg.dgrad[q];
+          }
+      }
+      gsum[0] = gsum[1] = gsum[2] = 0.0f;
+#pragma unroll
+      for (int a = 0; a < TT; ++a) {
+        float h[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int b = 0; b < TT; ++b)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            float g = 0.0f;                                // canvas_grad_at: the copies in order, then dgrad
+#pragma unroll
+            for (int t = 0; t < COPIES; ++t) g += r[c][a][b][t];
+            if (DG) g += r[c][a][b][COPIES];
+            h[c] = (b < oxc) ? h[c] + wxv[b] * g : h[c];
+          }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gsum[c] = (a < oyc) ? gsum[c] + wyv[a] * h[c] : gsum[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gsum[c] = st.normalise ? gsum[c] / st.stdv[c] : gsum[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gsum[c] = stage_bwd_value(st, cg, c, ys, xs);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const size_t i = (size_t)c * plane_s + o0;
+      float pv = pp[c];
+      const float t = tanhf(pv);
+      const float sv = xv[c] + eps * t;
+      float gp = ((gsum[c] + imgfit_grad(sv, c_fit)) * eps) * (1.0f - t * t);
+      gp = gp * mk[c];
+      nacc[0] += (double)gp * (double)gp;
+      grad_p[i] = gp;
+      if (o.kind == 0) {
+        float m1 = mm[c], v1 = vv[c];
+        adamw_element(pv, m1, v1, gp, o);
+        p[i] = pv; m[i] = m1; v[i] = v1;
+      } else {
+        float sg = sign_direction(gp);
+        pv = pv - o.lr * sg;
+        p[i] = pv;
+      }
+      const float xn = eps * tanhf(pv);
+      const float sn = xv[c] + xn;
+      s_next[i] = sn;
+      stat_accumulate(sn, xn, acc);
+    }
+  }
+  block_sum_store2<kStatSlots, 1>(acc, img_rows_out + (size_t)row * kStatSlots, nacc, norm_rows + row);
+}
+
+template <bool COMM>   // k_plan_update on the three-channel partition
+__global__ void __launch_bounds__(kBlock) k_plan_update3(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                         float* __restrict__ grad, const float* __restrict__ mask,
+                                                         const float* __restrict__ x0, float eps, int H, int W, OptScalars o,
+                                                         float* __restrict__ s_next, double* __restrict__ img_rows_out,
+                                                         double* __restrict__ norm_rows, CommDev comm) {
+  const int ys = blockIdx.y, xs = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned row = blockIdx.x + gridDim.x * blockIdx.y;
+  const size_t plane = (size_t)H * W, o0 = (size_t)ys * W + xs;
+  const bool live = xs < W;
+  double acc[kStatSlots] = {0, 0, 0, 0, 0, 0};
+  double nacc[1] = {0.0};
+  float mk[3] = {0.f, 0.f, 0.f}, pp[3] = {0.f, 0.f, 0.f}, xv[3] = {0.f, 0.f, 0.f};
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const size_t i = (size_t)c * plane + o0;
+      mk[c] = mask[i]; pp[c] = p[i]; xv[c] = x0[i];
+    }
+  }
+  if (COMM) comm_wait_b(comm);
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const size_t i = (size_t)c * plane + o0;
+      const float gp = (COMM ? comm_load1(grad + i) : grad[i]) * mk[c];
+      grad[i] = gp;
+      nacc[0] += (double)gp * (double)gp;
+      float pv = pp[c];
+      if (o.kind == 0) {
+        float mm = m[i], vv = v[i];
+        adamw_element(pv, mm, vv, gp, o);
+        p[i] = pv; m[i] = mm; v[i] = vv;
+      } else {
+        float sg = sign_direction(gp);
+        pv = pv - o.lr * sg;
+        p[i] = pv;
+      }
+      const float xn = eps * tanhf(pv);
+      const float sn = xv[c] + xn;
+      s_next[i] = sn;
+      stat_accumulate(sn, xn, acc);
+    }
+  }
+  block_sum_store2<kStatSlots, 1>(acc, img_rows_out + (size_t)row * kStatSlots, nacc, norm_rows + row);
+}
+
 __global__ void __launch_bounds__(kBlock) k_plan_head(DStage st, const float* __restrict__ src, long long src_cstride,
                                                       int src_rstride, float* __restrict__ canvas,
                                                       const double* __restrict__ norm_rows, int norm_count,

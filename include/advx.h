@@ -129,6 +129,9 @@ const char* advx_last_error(void);
 #define ADVX_TUNE_IMG_XCD 9         /* rows per group (default 8) of the XCD-aware grids of the image-sized gathers: launched 1-D, groups of that many
                                      rows of workgroups are dealt to the 8 XCDs in turn, so that one XCD's L2 fetches the source rows of its groups only;
                                      0: (column chunk, row, layer) grids dealt round-robin workgroup by workgroup (rounds 1-3).  Same results */
+#define ADVX_TUNE_TAIL3 13          /* 1 (default): the prepared chain's image kernels (prepare, tail, update) handle the three channels of a pixel in
+                                     one thread on a (chunk, row) grid for images of 250 k positions and more; 0: one thread per element (rounds
+                                     1-3).  Same per-pixel results; the statistics / ||g|| partials are summed over another partition */
 #define ADVX_TUNE_BLUR_THREADS 12   /* 512 (default) / 256: threads per 32 x 32 tile of the merged blur backward (radius <= 4).  The per-pixel
                                      results are the same; the ||g|| partial of a tile is summed in another order */
 #define ADVX_TUNE_HEAD3 10          /* canvases of >= value * 1000 positions (default 50) are resized by the three-channel windowed forward;
