@@ -99,3 +99,54 @@ def test_round4_forms_leave_the_bits_of_the_forms_they_replaced(name):
                 assert st[key] == pytest.approx(st_ref[key], rel=1e-6), (name, variant, key)
             else:
                 assert st[key] == st_ref[key], (name, variant, key)
+
+
+@pytest.mark.parametrize("H,W,maker", [(512, 512, "llava"), (512, 640, "llava"), (512, 512, "qwen2vl"), (336, 336, "llava")])
+def test_prepared_split_tail_and_reprepare_share_the_partition(H, W, maker):
+    """The prepared chain's image kernels all run on ONE partition of the image (three channels per thread from 250 k positions,
+    one element per thread below): advx_prepared_bwd in one call and its data-parallel split (advx_prepared_bwd_grad, [all-reduce],
+    advx_prepared_update) must leave IDENTICAL tensors AND identical device statistics - the partial sums are the same doubles
+    added in the same order.  (Resume = re-preparing: tests/test_gpu_e2e.py::test_resume_continues_bit_for_bit.)"""
+    from adversarialvlm_amd import ops
+    from adversarialvlm_amd.pgd import PixelPGD
+    from adversarialvlm_amd.plan import Plan
+    mk = {"llava": lambda: Plan.llava(H, W), "qwen2vl": lambda: Plan.qwen2vl(H, W)}[maker]
+    gen = torch.Generator().manual_seed(3)
+    x0 = torch.rand(3, H, W, generator=gen).to(DEV)
+    mask = (torch.rand(3, H, W, generator=gen) > 0.2).float().to(DEV)
+    B = 2
+
+    def run(split):
+        plan = mk()
+        eng = PixelPGD(x0, [plan], lr=1e-2, mask=mask, seed=9, fused_mode="prepared")
+        g = torch.Generator().manual_seed(17)
+        outs = []
+        for t in range(3):
+            eng.forward(B)
+            go = (torch.randn(B, plan.out_numel, generator=g) * 0.05).to(DEV)
+            if not split:
+                eng.backward_update([go])
+            else:
+                # the two halves the data-parallel engine runs around its all-reduce, on one rank
+                opt = eng._opt_scalars(True)
+                nxt = 1 - eng.s_cur
+                ops.prepared_bwd_grad(plan, go, B, eng.p, eng.x0, eng.eps, eng.imgfit_scale(), eng.grad, eng.rows_in, eng.par,
+                                      eng.stats, eng.prep_scratch, eng.workspaces[0])
+                ops.prepared_update(plan, eng.p, eng.m, eng.v, eng.grad, eng.mask, eng.x0, eng.eps, opt, eng.s_bufs[nxt], eng.par,
+                                    eng.stats, eng.prep_scratch, eng.workspaces[0])
+                eng.s_cur = nxt
+                eng.par = 1 - eng.par
+                eng.rows_in = eng.rows_bwd
+                eng._scheduler_step()
+                eng.iteration += 1
+                eng._last = None
+            outs += [eng.p.clone(), eng.m.clone(), eng.v.clone(), eng.grad.clone(), eng.s_bufs[eng.s_cur].clone()]
+        eng.forward(B)                               # reduces the statistics partials of the last image
+        return outs, eng.stats_dict()
+
+    a, st_a = run(False)
+    b, st_b = run(True)
+    for k, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), (k, float((u - v).abs().max()))
+    for key in st_a:
+        assert st_a[key] == st_b[key], key
