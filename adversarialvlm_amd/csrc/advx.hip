@@ -2972,8 +2972,10 @@ struct PreparedScratch {
   dim3 grid3;
 };
 // large images: workgroup = (chunk of 256 pixels of a row, row), three channels per thread (measured: pays from 250 k positions)
+// (a function of the geometry and of ADVX_TUNE_TAIL3 only - NOT of ADVX_TUNE_GENERIC_KERNELS, which callers switch around
+// single calls: the number of partial rows a step leaves must not change under an engine that asked for it once)
 bool prepared_three(const advx_plan* p) {
-  return !g_generic_kernels && g_tail3 && (long long)p->info.in_h * p->info.in_w >= kRows3MinPositions;
+  return g_tail3 && (long long)p->info.in_h * p->info.in_w >= kRows3MinPositions;
 }
 long long prepared_flat_rows(const advx_plan* p) { return (3LL * p->info.in_h * p->info.in_w + kBlock - 1) / kBlock; }
 long long prepared_rows_now(const advx_plan* p) {
