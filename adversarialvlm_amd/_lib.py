@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libadvx_hip.so")
 
 ADVX_OK = 0
+E_UNSUPPORTED = -4          # ADVX_E_UNSUPPORTED
 KIND_LLAVA, KIND_MLLAMA, KIND_PHI3, KIND_QWEN2VL = 0, 1, 2, 3
 MODE_AA_BILINEAR, MODE_BILINEAR, MODE_BICUBIC = 0, 1, 2
 OPT_ADAMW, OPT_SIGN = 0, 1
@@ -23,7 +24,8 @@ TUNE_GENERIC_KERNELS = 1
 TUNE_FULL_TAP_ROWS = 3
 TUNE_SEPARATE_CROP = 4
 TUNE_PAIR_LEAN = 5
-TUNE_XCD_MAP, TUNE_BWD_XCD, TUNE_ROW_BATCH, TUNE_IMG_XCD, TUNE_HEAD3, TUNE_BLUR_THREADS, TUNE_TAIL3 = 6, 7, 8, 9, 10, 12, 13
+TUNE_XCD_MAP, TUNE_BWD_XCD, TUNE_ROW_BATCH, TUNE_IMG_XCD, TUNE_HEAD3, TUNE_BLUR_THREADS, TUNE_TAIL3, TUNE_COLLECT_UPDATE = \
+    6, 7, 8, 9, 10, 12, 13, 14
 
 
 class AdvxError(RuntimeError):
@@ -85,6 +87,9 @@ SIGNATURES = {
     "advx_crop_compose_rows": (_I32, [_P, _I32, _I32, _P, _PI32, _PI32]),
     "advx_image_grid_map": (_I32, [_I32, _I32, _I32, _I32, _PI32, _PI32]),
     "advx_collect_crop": (_I32, [_P, _P, _I32, _P, _I32, _P, _I64, _I32, _I32, _P, _P, _P]),
+    "advx_collect_update_supported": (_I32, [_P, _I32, _I32, _P]),
+    "advx_collect_update": (_I32, [_P, _P, _I32, _P, _I64, _I32, _I32, _P, _P, _P, _P, _F, _F, _P, _I32, _P, _P, _P, C.POINTER(OptScalars),
+                                   _P, _P, _I32, _P]),
     "advx_emit_multi": (_I32, [_I32, _P, _P, _P, _P, _P, _I32, _U64, _P, _P, _P, _P, _I32, _P]),
     "advx_collect_multi": (_I32, [_I32, _P, _P, _P, _P, _I32, _P, _P, _P]),
     "advx_forward_multi": (_I32, [_P, _P, _I32, _I32, _F, _I32, _F, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _I32, _U64, _P, _P, _P,

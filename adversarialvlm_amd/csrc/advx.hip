@@ -48,6 +48,7 @@ static int32_t fail(int32_t code, const std::string& msg) {
 static int g_generic_kernels = 0;
 static int g_pair_nt_loads = 0;
 static int g_xcd_map = 2;        // ADVX_TUNE_XCD_MAP: 0 = grids as they come (rounds 1-3), 1 = gx padded to a multiple of 8, 2 = padded + a contiguous range of column blocks per XCD
+static int g_collect_update = 1; // ADVX_TUNE_COLLECT_UPDATE: advx_collect_update offered (0: advx_collect_update_supported says no)
 static int g_tail3 = 1;          // ADVX_TUNE_TAIL3: the prepared chain's image kernels on the three-channel partition from kRows3MinPositions up
 static int g_blur_threads = 512; // ADVX_TUNE_BLUR_THREADS: threads per 32 x 32 tile of the merged blur backward (256: rounds 1-3)
 static int g_head3 = 50;         // ADVX_TUNE_HEAD3: canvases of >= value * 1000 positions take the three-channel windowed forward (0: never)
@@ -69,6 +70,11 @@ extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
     g_head3 = 50;
     g_blur_threads = 512;
     g_tail3 = 1;
+    g_collect_update = 1;
+    return ADVX_OK;
+  }
+  if (what == ADVX_TUNE_COLLECT_UPDATE) {
+    g_collect_update = value;          // 2: 256 threads per workgroup (development)
     return ADVX_OK;
   }
   if (what == ADVX_TUNE_TAIL3) {
@@ -2225,6 +2231,107 @@ extern "C" int32_t advx_image_bwd_update(float* p, const float* s, const float* 
   LAUNCH_CHECK();
   if (finalize_norm) {
     hipLaunchKernelGGL(k_finalize_norm, dim3(1), dim3(kBlock), 0, st, partials, -1, stats);   // count: left by the producer
+    LAUNCH_CHECK();
+  }
+  return ADVX_OK;
+}
+
+// advx_collect[_crop] + advx_image_bwd_update(no blur, no separate window) in ONE call with the transposed resize inside the
+// optimiser's launch (k_collect_update3): for a single plan whose stage 0 reads the image - as it stands, or through the
+// composed crop window - when the transposed tables' rows fit a compiled window (<= 4 taps; <= 6 for a one-copy gradient), from
+// 250 k positions (where three channels per thread pay).  advx_collect_update_supported says whether a step can take it; otherwise the two calls.
+namespace {
+struct CollectUpdatePick { bool ok = false; int T = 0, mode = 0, rows_per_block = 1, threads = 128; dim3 grid; ImgGrid ig; };
+CollectUpdatePick pick_collect_update(const advx_plan* p, int H, int W, const int32_t* crop, const float* ws) {
+  CollectUpdatePick r;
+  if (g_generic_kernels || !g_collect_update || !g_row_batch || !p || p->st[0].info.src != 0) return r;
+  if (p->st[0].info.src_h != H || p->st[0].info.src_w != W || (long long)H * W < kRows3MinPositions) return r;
+  for (int k = 1; k < p->info.n_stage; ++k)
+    if (p->st[k].info.src < 1) return r;
+  const int threads = g_collect_update == 2 ? kBlock : 128;
+  const int gx = (W + threads - 1) / threads;
+  if (gx > kNormCountSlot) return r;
+  r.threads = threads;
+  r.rows_per_block = (int)(((long long)gx * H + kNormCountSlot - 1) / kNormCountSlot);      // 1 up to 2048 (chunk, row) pairs
+  r.ig = img_grid(gx, (H + r.rows_per_block - 1) / r.rows_per_block, 1, &r.grid);
+  int rows;
+  if (crop) {
+    ComposeGeom g;
+    if (!compose_geom(p, H, W, crop, &g)) return r;
+    rows = compose_exact(p, H, W, crop, g).tr;
+    if (rows <= 0) return r;
+  } else {
+    if (!p->uploaded) return r;
+    rows = std::max(p->dstage[0].tth.stride, p->dstage[0].ttw.stride);
+  }
+  const CanvasGrad cg = stage_grad(p, 0, ws);
+  r.mode = (cg.copies == 1 && !cg.dgrad) ? 1 : (cg.copies == 1 && cg.dgrad) ? 2 : (cg.copies == 2 && !cg.dgrad) ? 3 : 0;
+  r.T = rows <= 4 ? pick_window(rows) : (rows <= 6 && r.mode == 1 ? rows : 0);      // as launch_stage_bwd picks k_stage_bwd3_w
+  r.ok = r.T > 0 && r.mode > 0;
+  return r;
+}
+}  // namespace
+
+extern "C" int32_t advx_collect_update_supported(advx_plan* p, int32_t H, int32_t W, const int32_t* crop) {
+  if (!p) return 0;
+  if (!p->uploaded && advx_plan_upload(p, nullptr) != ADVX_OK) return 0;
+  float dummy = 0.0f;
+  return pick_collect_update(p, H, W, crop, &dummy).ok ? 1 : 0;
+}
+
+extern "C" int32_t advx_collect_update(advx_plan* p, const void* grad_out, int32_t batch, float* ws, int64_t ws_floats, int32_t H,
+                                       int32_t W, const int32_t* crop, float* image_scratch, float* pp, const float* s, float eps,
+                                       float imgfit_scale, float* grad_p, int32_t accumulate, const float* mask, float* m, float* v,
+                                       const advx_opt_scalars* opt, float* stats, float* update_scratch, int32_t finalize_norm,
+                                       void* stream) {
+  REQUIRE(p && grad_out && ws && image_scratch && pp && s && grad_p && mask && opt && stats && update_scratch, ADVX_E_BADARG,
+          "advx_collect_update: null argument");
+  REQUIRE(batch >= 1 && batch <= 65535, ADVX_E_BADARG, "advx_collect_update: batch out of range");
+  REQUIRE(ws_floats >= p->info.workspace_floats, ADVX_E_SHAPE, "advx_collect_update: workspace too small");
+  int32_t rc = check_opt(opt, m, v);
+  if (rc) return rc;
+  rc = advx_plan_upload(p, stream);
+  if (rc) return rc;
+  const CollectUpdatePick pick = pick_collect_update(p, H, W, crop, ws);
+  REQUIRE(pick.ok, ADVX_E_UNSUPPORTED, "advx_collect_update: this step takes advx_collect[_crop] + advx_image_bwd_update");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = 3LL * H * W;
+  Bump b{image_scratch};
+  (void)b.take(partial_floats(H, W));
+  const float* table_area = b.base + b.used;
+  DStage D = p->dstage[0];
+  if (crop) {
+    rc = build_composed_stage(p, H, W, crop, b, st, &D, /*may_reuse=*/true);     // the forward's tables, if still there
+    if (rc) return rc;
+  }
+  rc = reduce_to_canvas(p, grad_out, batch, ws, st);
+  if (rc) return rc;
+  for (int k = p->info.n_stage - 1; k >= 1; --k) {
+    const DStage& Dk = p->dstage[k];
+    int acc = 0;
+    float* gsrc = dgrad_target(p, p->st[k].info.src - 1, ws, &acc);
+    launch_stage_bwd(Dk, stage_grad(p, k, ws), gsrc, (long long)Dk.src_h * Dk.src_w, Dk.src_w, acc, st);
+    LAUNCH_CHECK();
+  }
+  const CanvasGrad cg = stage_grad(p, 0, ws);
+  const float c_fit = imgfit_scale / (float)n;
+  double* partials = reinterpret_cast<double*>(update_scratch);
+  const OptScalars o = to_dev(opt);
+#define ADVX_CU(T_, M_)                                                                                                      \
+  hipLaunchKernelGGL((k_collect_update3<T_, M_>), pick.grid, dim3(pick.threads), 0, st, D, cg, s, eps, c_fit, accumulate, pp, \
+                     m, v, grad_p, mask, o, partials, pick.rows_per_block, pick.ig)
+#define ADVX_CU_M(T_) do { if (pick.mode == 1) ADVX_CU(T_, 1); else if (pick.mode == 2) ADVX_CU(T_, 2); else ADVX_CU(T_, 3); } while (0)
+  if (pick.T == 2) ADVX_CU_M(2);
+  else if (pick.T == 3) ADVX_CU_M(3);
+  else if (pick.T == 4) ADVX_CU_M(4);
+  else if (pick.T == 5) ADVX_CU(5, 1);
+  else ADVX_CU(6, 1);
+#undef ADVX_CU_M
+#undef ADVX_CU
+  LAUNCH_CHECK();
+  tables_forget(table_area);     // as advx_collect_crop / advx_image_bwd_update: a later call with the same window rebuilds
+  if (finalize_norm) {
+    hipLaunchKernelGGL(k_finalize_norm, dim3(1), dim3(kBlock), 0, st, partials, -1, stats);
     LAUNCH_CHECK();
   }
   return ADVX_OK;

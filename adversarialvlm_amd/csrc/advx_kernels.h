@@ -1789,6 +1789,114 @@ __global__ void __launch_bounds__(kBlock) k_bwd_update(const float* __restrict__
   if (blockIdx.x == 0 && threadIdx.x == 0) partials[2048] = (double)gridDim.x;
 }
 
+// k_stage_bwd3_w + k_bwd_update<0> in ONE launch (round 4): the transposed resize of a plan's stage 0 (or of the composed
+// crop window o stage 0) gathered for the three channels of an image pixel and, on the values still in registers, image-fit',
+// tanh', [accumulate], mask, ||g|| partial and the optimiser - what the two launches do per element, in their order (the
+// gradient w.r.t. s is rounded to float exactly where k_stage_bwd3_w would have stored it).  One launch and one round trip of
+// that gradient less per step of a single-plan chain without blur.  Grid (chunk of 256 pixels, rows_per_block image rows); at
+// most 2048 workgroups (the ||g|| partials' room: the host picks rows_per_block for that).  T = 0: stage_bwd_value's loops.
+template <int T, int MODE>
+__global__ void __launch_bounds__(kBlock) k_collect_update3(DStage st, CanvasGrad cg, const float* __restrict__ s, float eps, float c_fit,
+                                                            int accumulate, float* __restrict__ p, float* __restrict__ m,
+                                                            float* __restrict__ v, float* __restrict__ grad,
+                                                            const float* __restrict__ mask, OptScalars o,
+                                                            double* __restrict__ partials, int rows_per_block, ImgGrid ig) {
+  constexpr int TT = (T > 0) ? T : 1;
+  constexpr int COPIES = (MODE == 3) ? 2 : 1;
+  constexpr bool DG = MODE == 2;
+  BlockXYZ blk;
+  if (!xcd_band_block(ig, blk)) return;          // padding of the XCD-aware grid (the whole workgroup)
+  const int xs = blk.x * blockDim.x + threadIdx.x;
+  const unsigned row = blk.x + ig.gx * blk.y;
+  const int y_end = min(st.src_h, (int)(blk.y + 1) * rows_per_block);
+  double acc[1] = {0.0};
+  if (xs < st.src_w)
+  for (int ys = blk.y * rows_per_block; ys < y_end; ++ys) {
+    const size_t plane_s = (size_t)st.src_h * st.src_w, o0 = (size_t)ys * st.src_w + xs;
+    const bool adam = o.apply && o.kind == 0;
+    float pp[3], sv[3], mk[3], g0[3], mm[3], vv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const size_t i = (size_t)c * plane_s + o0;
+      pp[c] = p[i]; sv[c] = s[i]; mk[c] = mask[i];
+      g0[c] = accumulate ? grad[i] : 0.0f;
+      mm[c] = adam ? m[i] : 0.0f;
+      vv[c] = adam ? v[i] : 0.0f;
+    }
+    float gsum[3];
+    if (T > 0) {
+      const int oy = st.tth.start[ys], oyc = st.tth.count[ys];
+      const int ox = st.ttw.start[xs], oxc = st.ttw.count[xs];
+      const float* wy = st.tth.w + (size_t)ys * st.tth.stride;
+      const float* wx = st.ttw.w + (size_t)xs * st.ttw.stride;
+      const size_t plane = (size_t)st.can_h * st.can_w;
+      const int ly = max(oyc - 1, 0), lx = max(oxc - 1, 0);
+      float wyv[TT], wxv[TT], r[3][TT][TT][COPIES + 1];
+#pragma unroll
+      for (int a = 0; a < TT; ++a) { wyv[a] = wy[min(a, ly)]; wxv[a] = wx[min(a, lx)]; }
+#pragma unroll
+      for (int a = 0; a < TT; ++a) {
+        const size_t rowc = (size_t)(st.off_y + oy + min(a, ly)) * st.can_w + st.off_x + ox;
+#pragma unroll
+        for (int b = 0; b < TT; ++b)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const size_t q = (size_t)c * plane + rowc + min(b, lx);
+#pragma unroll
+            for (int t = 0; t < COPIES; ++t) r[c][a][b][t] = cg.g[(size_t)t * cg.copy_stride + q];
+            if (DG) r[c][a][b][COPIES] = cg.dgrad[q];
+          }
+      }
+      gsum[0] = gsum[1] = gsum[2] = 0.0f;
+#pragma unroll
+      for (int a = 0; a < TT; ++a) {
+        float h[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int b = 0; b < TT; ++b)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            float g = 0.0f;
+#pragma unroll
+            for (int t = 0; t < COPIES; ++t) g += r[c][a][b][t];
+            if (DG) g += r[c][a][b][COPIES];
+            h[c] = (b < oxc) ? h[c] + wxv[b] * g : h[c];
+          }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gsum[c] = (a < oyc) ? gsum[c] + wyv[a] * h[c] : gsum[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gsum[c] = st.normalise ? gsum[c] / st.stdv[c] : gsum[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gsum[c] = stage_bwd_value(st, cg, c, ys, xs);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const size_t i = (size_t)c * plane_s + o0;
+      const float gx = gsum[c] + imgfit_grad(sv[c], c_fit);      // k_bwd_update<0>: gs[i] + imgfit'(s[i])
+      float pv = pp[c];
+      const float t = tanhf(pv);
+      float g = (gx * eps) * (1.0f - t * t);
+      if (accumulate) g = g0[c] + g;
+      g = g * mk[c];                                             // attack_model.py:336
+      grad[i] = g;
+      acc[0] += (double)g * (double)g;
+      if (o.apply) {
+        if (o.kind == 0) {
+          float m1 = mm[c], v1 = vv[c];
+          adamw_element(pv, m1, v1, g, o);
+          p[i] = pv; m[i] = m1; v[i] = v1;
+        } else {
+          float sg = sign_direction(g);
+          p[i] = pv - o.lr * sg;
+        }
+      }
+    }
+  }
+  block_sum_store<1>(acc, partials + row);
+  if (row == 0 && threadIdx.x == 0) partials[2048] = (double)(ig.gx * ig.gy);
+}
+
 // ================================================================= fused (identity plan)
 // LLaVA at native resolution: process() is (s - mean)/std with s = x0 + eps*tanh(p).
 // The step is software-pipelined over two launches:

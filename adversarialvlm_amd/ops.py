@@ -176,6 +176,35 @@ def collect_crop(plan, grad_out, batch, crop, image_scratch, grad_s, accumulate=
     return grad_s
 
 
+def collect_update_supported(plan, H, W, crop=None):
+    """Whether collect[_crop] + image_bwd_update of a step without blur can go through `collect_update` (one launch less)."""
+    _keep, cp = _crop_arg(crop)
+    return bool(L.load().advx_collect_update_supported(plan.handle, int(H), int(W), cp))
+
+
+def collect_update(plan, grad_out, batch, p, s, epsilon, imgfit_scale, grad_p, mask, m, v, opt, stats, image_scratch,
+                   update_scratch, crop=None, accumulate=False, finalize_norm=True, workspace=None, if_supported=False):
+    """collect (crop=None) or collect_crop (a composing window) AND image_bwd_update(blur=None) in one call: the transposed
+    resize of stage 0 runs inside the optimiser's launch.  Where `collect_update_supported` says no: AdvxError
+    (ADVX_E_UNSUPPORTED), or None with if_supported=True (nothing launched)."""
+    _require_cuda(grad_out, p, s, grad_p, mask, stats, image_scratch, update_scratch)
+    grad_out = _boundary(plan, grad_out, "grad_out")
+    if grad_out.numel() != batch * plan.out_numel:
+        raise L.AdvxError("grad_out has the wrong number of elements")
+    if workspace is None:
+        workspace = torch.empty(plan.workspace_floats, dtype=torch.float32, device=grad_out.device)
+    _, H, W = p.shape
+    _keep, cp = _crop_arg(crop)
+    rc = L.load().advx_collect_update(plan.handle, L.ptr(grad_out), int(batch), L.ptr(workspace), int(workspace.numel()),
+                                      int(H), int(W), cp, L.ptr(image_scratch), L.ptr(p), L.ptr(s), float(epsilon),
+                                      float(imgfit_scale), L.ptr(grad_p), int(accumulate), L.ptr(mask), L.ptr(m), L.ptr(v),
+                                      C.byref(opt), L.ptr(stats), L.ptr(update_scratch), int(bool(finalize_norm)), _stream(p))
+    if rc == L.E_UNSUPPORTED and if_supported:
+        return None            # nothing was launched: the caller takes the two calls
+    L.check(rc, "advx_collect_update")
+    return grad_p
+
+
 def _ptr_array(tensors):
     return (C.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 

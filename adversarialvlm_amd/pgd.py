@@ -167,6 +167,7 @@ class PixelPGD:
             self.s = torch.empty_like(self.x0)
             self.argument = torch.empty_like(self.x0)
             self.garg = torch.empty_like(self.x0)
+            self._collect_update = None       # whether ops.collect_update takes this engine's steps (asked on the first one)
             self.img_scratch = ops.image_scratch(H, W, blur_kernel or 0, dev)
             self.workspaces = [torch.empty(pl.workspace_floats, dtype=torch.float32, device=dev) for pl in self.plans]
             self.noise_on_padding = bool(noise_on_padding)
@@ -410,6 +411,26 @@ class PixelPGD:
             self.rows_in = self.rows_bwd
             self.s_cur = nxt
         else:
+            if (len(self.plans) == 1 and st["blur"] is None and not (self.exchange and take_step)
+                    and (st["crop"] is None or st.get("composed")) and self._collect_update is not False):
+                # one plan, no blur, nothing between the backward and the optimiser: the transposed resize of stage 0
+                # (through the composed window's table, if any) inside the optimiser's launch - where the library offers it
+                pl, g, B = self.plans[0], grads[0], st["batches"][0]
+                done = ops.collect_update(pl, g.reshape(B, pl.out_numel), B, self.p, self.s, self.eps, self.imgfit_scale(),
+                                          self.grad, self.mask, self.m, self.v, opt, self.stats, self.img_scratch,
+                                          self.upd_scratch, crop=st["crop"], accumulate=accumulate, finalize_norm=False,
+                                          workspace=self.workspaces[0], if_supported=True)
+                if st["crop"] is None:
+                    self._collect_update = done is not None       # without a window the answer never changes
+            else:
+                done = None
+            if done is not None:
+                self._norm_pending = True
+                if take_step:
+                    self._scheduler_step()
+                self.iteration += 1
+                self._last = None
+                return take_step
             if len(self.plans) > 1:
                 # batch reductions, then every plan's transposed resize summed in one launch
                 ops.collect_multi(self.plans, [g.reshape(B, pl.out_numel) for pl, g, B in zip(self.plans, grads, st["batches"])],
