@@ -48,7 +48,7 @@ static int32_t fail(int32_t code, const std::string& msg) {
 static int g_generic_kernels = 0;
 static int g_pair_nt_loads = 0;
 static int g_xcd_map = 2;        // ADVX_TUNE_XCD_MAP: 0 = grids as they come (rounds 1-3), 1 = gx padded to a multiple of 8, 2 = padded + a contiguous range of column blocks per XCD
-static int g_collect_update = 1; // ADVX_TUNE_COLLECT_UPDATE: advx_collect_update offered (0: advx_collect_update_supported says no)
+static int g_collect_update = 1;   // ADVX_TUNE_COLLECT_UPDATE: images of >= value * 1000 positions are offered advx_collect_update (0: never)
 static int g_tail3 = 1;          // ADVX_TUNE_TAIL3: the prepared chain's image kernels on the three-channel partition from kRows3MinPositions up
 static int g_blur_threads = 512; // ADVX_TUNE_BLUR_THREADS: threads per 32 x 32 tile of the merged blur backward (256: rounds 1-3)
 static int g_head3 = 50;         // ADVX_TUNE_HEAD3: canvases of >= value * 1000 positions take the three-channel windowed forward (0: never)
@@ -74,7 +74,7 @@ extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
     return ADVX_OK;
   }
   if (what == ADVX_TUNE_COLLECT_UPDATE) {
-    g_collect_update = value;          // 2: 256 threads per workgroup (development)
+    g_collect_update = value < 0 ? 0 : value;
     return ADVX_OK;
   }
   if (what == ADVX_TUNE_TAIL3) {
@@ -2238,17 +2238,17 @@ extern "C" int32_t advx_image_bwd_update(float* p, const float* s, const float* 
 
 // advx_collect[_crop] + advx_image_bwd_update(no blur, no separate window) in ONE call with the transposed resize inside the
 // optimiser's launch (k_collect_update3): for a single plan whose stage 0 reads the image - as it stands, or through the
-// composed crop window - when the transposed tables' rows fit a compiled window (<= 4 taps; <= 6 for a one-copy gradient), from
-// 250 k positions (where three channels per thread pay).  advx_collect_update_supported says whether a step can take it; otherwise the two calls.
+// composed crop window - when the transposed tables' rows fit a compiled window (<= 4 taps; <= 6 for a one-copy gradient).  Pays
+// at every size measured (336^2: 10.3 -> 7.5 us; 512^2: 11.6 -> 8.9), unlike the three-channel gather on its own below 250 k positions.  advx_collect_update_supported says whether a step can take it; otherwise the two calls.
 namespace {
 struct CollectUpdatePick { bool ok = false; int T = 0, mode = 0, rows_per_block = 1, threads = 128; dim3 grid; ImgGrid ig; };
 CollectUpdatePick pick_collect_update(const advx_plan* p, int H, int W, const int32_t* crop, const float* ws) {
   CollectUpdatePick r;
   if (g_generic_kernels || !g_collect_update || !g_row_batch || !p || p->st[0].info.src != 0) return r;
-  if (p->st[0].info.src_h != H || p->st[0].info.src_w != W || (long long)H * W < kRows3MinPositions) return r;
+  if (p->st[0].info.src_h != H || p->st[0].info.src_w != W || (long long)H * W < (long long)g_collect_update * 1000) return r;
   for (int k = 1; k < p->info.n_stage; ++k)
     if (p->st[k].info.src < 1) return r;
-  const int threads = g_collect_update == 2 ? kBlock : 128;
+  const int threads = 128;            // as k_stage_bwd3_w: little waste on the last chunk of a 336 / 512 / 672-wide row
   const int gx = (W + threads - 1) / threads;
   if (gx > kNormCountSlot) return r;
   r.threads = threads;

@@ -129,7 +129,7 @@ const char* advx_last_error(void);
 #define ADVX_TUNE_IMG_XCD 9         /* rows per group (default 8) of the XCD-aware grids of the image-sized gathers: launched 1-D, groups of that many
                                      rows of workgroups are dealt to the 8 XCDs in turn, so that one XCD's L2 fetches the source rows of its groups only;
                                      0: (column chunk, row, layer) grids dealt round-robin workgroup by workgroup (rounds 1-3).  Same results */
-#define ADVX_TUNE_COLLECT_UPDATE 14 /* 1 (default): advx_collect_update_supported may say yes; 0: it never does (the two calls) */
+#define ADVX_TUNE_COLLECT_UPDATE 14 /* images of >= value * 1000 positions (default 1) are offered advx_collect_update; 0: none (the two calls) */
 #define ADVX_TUNE_TAIL3 13          /* 1 (default): the prepared chain's image kernels (prepare, tail, update) handle the three channels of a pixel in
                                      one thread on a (chunk, row) grid for images of 250 k positions and more; 0: one thread per element (rounds
                                      1-3).  Same per-pixel results; the statistics / ||g|| partials are summed over another partition */
@@ -337,8 +337,8 @@ int32_t advx_image_bwd_update(float* p, const float* s, const float* grad_argume
  * launch that gathers the transposed resize of stage 0 (through the composed table when `crop_ijhw` is given, as advx_collect_crop)
  * for the three channels of an image pixel and applies image-fit', tanh', [accumulate], mask, ||g|| partial and the optimiser to
  * them - the two calls' arithmetic, one launch and one round trip of the image gradient less (attack_model.py:332-346).
- * advx_collect_update_supported: whether this step can take it (one plan whose stage 0 reads the image of H x W >= 250 k
- * positions, transposed rows of <= 4 taps (<= 6 for a plan with one canvas copy); crop_ijhw NULL or a composing window); the call
+ * advx_collect_update_supported: whether this step can take it (one plan whose stage 0 reads the image,
+ * transposed rows of <= 4 taps (<= 6 for a plan with one canvas copy); crop_ijhw NULL or a composing window); the call
  * returns ADVX_E_UNSUPPORTED otherwise and the caller takes the two calls.  finalize_norm as advx_image_bwd_update's. */
 int32_t advx_collect_update_supported(advx_plan* plan, int32_t H, int32_t W, const int32_t* crop_ijhw);
 int32_t advx_collect_update(advx_plan* plan, const void* grad_out, int32_t batch, float* ws, int64_t ws_floats, int32_t H, int32_t W,

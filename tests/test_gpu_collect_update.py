@@ -1,8 +1,8 @@
 """GPU tier: advx_collect_update against the two calls it replaces (advx_collect / advx_collect_crop, then advx_image_bwd_update
 without blur), tensor for tensor, bit for bit - AdamW and the sign step, first and later iterations of an accumulation window,
 with and without applying the step, every processor family, with and without a composing crop window.  ||g|| comes from another
-partition of the image (doubles): relative 1e-6.  Where the one-launch form is not offered (small images, long transposed rows,
-a window that does not compose) the call must say so and launch nothing."""
+partition of the image (doubles): relative 1e-6.  Where the one-launch form is not offered (long transposed rows, a window that does
+not compose) the call must say so and launch nothing."""
 import pytest
 import torch
 
@@ -29,6 +29,7 @@ def _plan(maker, H, W):
 
 
 CASES = [  # (maker, H, W, crop window)
+    ("llava", 336, 336, (20, 30, 280, 300)), ("mllama", 336, 336, None), ("llava", 97, 130, (3, 5, 80, 101)), ("qwen2vl", 200, 300, None),
     ("llava", 512, 512, None), ("llava", 512, 512, (40, 30, 400, 420)), ("llava", 500, 640, None),
     ("llava", 672, 672, (0, 0, 672, 672)), ("qwen2vl", 512, 512, None), ("qwen2vl", 512, 512, (16, 24, 470, 450)),
     ("phi3", 512, 512, None), ("phi3", 600, 520, (10, 20, 560, 480)), ("mllama", 600, 600, None),
@@ -86,7 +87,7 @@ def test_collect_update_equals_the_two_calls(maker, H, W, crop, kind, accumulate
 
 
 def test_every_family_is_offered_the_one_launch_form_at_full_size():
-    """The chains the bench tools quote (512 x 512 and up, with and without the composing window) take the one-launch form."""
+    """Every family, with the image as it stands or through a composing window, takes the one-launch form."""
     from adversarialvlm_amd import ops
     for maker, H, W, crop in CASES:
         plan = _plan(maker, H, W)
@@ -94,8 +95,12 @@ def test_every_family_is_offered_the_one_launch_form_at_full_size():
         assert ops.collect_update_supported(plan, H, W, crop) == composes, (maker, H, W, crop)
 
 
-@pytest.mark.parametrize("maker,H,W,crop", [("llava", 336, 400, None), ("llava", 97, 130, (3, 5, 80, 101)),
-                                            ("llava", 400, 500, None)])
+@pytest.mark.parametrize("maker,H,W,crop", [
+    ("llava", 100, 120, None),                        # up-sampling: a pixel of the image reaches more than six canvas rows
+    ("qwen2vl", 512, 512, (16, 24, 470, 450)),        # a window that does not compose with the plan's stage 0
+    ("phi3", 600, 520, (10, 20, 560, 480)),
+    ("llava", 24, 30, None),                          # fewer than 1000 positions
+])
 def test_collect_update_refuses_what_it_does_not_cover_and_launches_nothing(maker, H, W, crop):
     from adversarialvlm_amd import _lib as L
     from adversarialvlm_amd import ops

@@ -27,6 +27,11 @@ def main():
         plans, B = [Plan.llava(H, W)], 64
         kw = dict(use_crop=True, **(dict(blur_kernel=9) if "blur" in which else {}))
         crop = (40, 30, 400, 420)
+    elif which == "llava336-crop":                      # native resolution + window, no blur
+        H = W = 336
+        plans, B = [Plan.llava(H, W)], 64
+        kw = dict(use_crop=True)
+        crop = (20, 30, 280, 300)
     elif which == "llava336-blur5-crop":                # native resolution + blur 5 + window (tools/generic_bench.py's row)
         H = W = 336
         plans, B = [Plan.llava(H, W)], 64
