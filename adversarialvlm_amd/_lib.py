@@ -144,7 +144,8 @@ SIGNATURES = {
     "advx_comm_destroy": (_I32, [_P]),
     "advx_fused_bwd_dp": (_I32, [_P, _P, _P, _I32, _I32, _P, _P, _F, _F, _P, _P, _P, C.POINTER(OptScalars), _P, _P, _P, _P,
                                  C.c_double, _P]),
-    "advx_ce_fwd": (_I32, [_P, _I32, _I64, _I64, _I32, _P, _I64, _I64, _P, _P, _P, _P]),
+    "advx_ce_fwd": (_I32, [_P, _I32, _I64, _I64, _I32, _P, _I64, _I64, _P, _P, _P, _P, _P]),
+    "advx_ce_scratch_floats": (_I64, [_I64, _I64, _I32]),
     "advx_ce_bwd": (_I32, [_P, _I32, _I64, _I64, _I32, _I32, _P, _I64, _I64, _P, _P, _P, _P, _P]),
     "advx_profile_begin": (_I32, [_I32, _I32]),
     "advx_profile_end": (_I32, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

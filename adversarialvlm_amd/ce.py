@@ -34,9 +34,11 @@ class _SuffixCE(torch.autograd.Function):
         row_loss = torch.empty(B * T, dtype=torch.float32, device=dev)
         row_lse = torch.empty(B * T, dtype=torch.float32, device=dev)
         mean_n = torch.empty(2, dtype=torch.float32, device=dev)
-        L.check(L.load().advx_ce_fwd(_raw(logits), io_code(logits.dtype), logits.stride(0), logits.stride(1), T,
+        io = io_code(logits.dtype)
+        scratch = torch.empty(int(L.load().advx_ce_scratch_floats(B * T, V, io)), dtype=torch.float32, device=dev)
+        L.check(L.load().advx_ce_fwd(_raw(logits), io, logits.stride(0), logits.stride(1), T,
                                      L.ptr(targets), B * T, V, L.ptr(row_loss), L.ptr(row_lse), L.ptr(mean_n),
-                                     L.current_stream(dev)), "advx_ce_fwd")
+                                     L.ptr(scratch), L.current_stream(dev)), "advx_ce_fwd")
         ctx.save_for_backward(logits, targets, row_lse, mean_n)
         ctx.T = T
         return mean_n[0].clone()

@@ -3377,22 +3377,42 @@ extern "C" int32_t advx_prepared_bwd_dp(advx_plan* p, advx_comm* c, const float*
 }
 
 // ------------------------------------------------------ suffix-only cross entropy (advx_ce.h)
+namespace {
+long long ce_fwd_chunks(long long vocab, int io_dtype) {
+  const long long per_block = (long long)kCeFwdVecs * kBlock * (io_dtype == 0 ? 4 : 8);      // elements a workgroup takes
+  return std::max<long long>(1, (vocab + per_block - 1) / per_block);
+}
+}  // namespace
+extern "C" int64_t advx_ce_scratch_floats(int64_t rows, int64_t vocab, int32_t io_dtype) {
+  if (rows < 1 || vocab < 1) return 0;
+  return 2 * rows * ce_fwd_chunks(vocab, io_dtype) + 4;
+}
+
 extern "C" int32_t advx_ce_fwd(const void* logits, int32_t io_dtype, int64_t batch_stride, int64_t row_stride, int32_t T,
                                const int64_t* targets, int64_t rows, int64_t vocab, float* row_loss, float* row_lse,
-                               float* mean_and_n, void* stream) {
-  REQUIRE(logits && targets && row_loss && row_lse && mean_and_n, ADVX_E_BADARG, "advx_ce_fwd: null argument");
+                               float* mean_and_n, float* scratch, void* stream) {
+  REQUIRE(logits && targets && row_loss && row_lse && mean_and_n && scratch, ADVX_E_BADARG, "advx_ce_fwd: null argument");
   REQUIRE(io_dtype >= 0 && io_dtype <= 2, ADVX_E_BADARG, "advx_ce_fwd: io_dtype must be ADVX_IO_F32 / F16 / BF16");
   REQUIRE(T >= 1 && rows >= 1 && rows % T == 0 && rows < (1LL << 31) && vocab >= 1, ADVX_E_SHAPE, "advx_ce_fwd: bad shape");
+  const long long chunks = ce_fwd_chunks(vocab, io_dtype);
+  REQUIRE(chunks <= 65535, ADVX_E_SHAPE, "advx_ce_fwd: vocabulary too large");
+  REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 7u) == 0, ADVX_E_BADARG, "advx_ce_fwd: scratch must be 8-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const long long* tg = reinterpret_cast<const long long*>(targets);
-#define ADVX_CE(IO)                                                                                               \
-  hipLaunchKernelGGL(k_ce_fwd<IO>, dim3((unsigned)rows), dim3(kBlock), 0, st, logits, (long long)batch_stride,    \
-                     (long long)row_stride, (int)T, tg, (long long)vocab, row_loss, row_lse)
+  float2* parts = reinterpret_cast<float2*>(scratch);
+  const dim3 grid((unsigned)rows, (unsigned)chunks);
+  const unsigned finish_threads = (unsigned)std::min<long long>(kCeFinishThreads, ((rows + kWave - 1) / kWave) * kWave);
+#define ADVX_CE(IO)                                                                                                        \
+  do {                                                                                                                     \
+    hipLaunchKernelGGL(k_ce_fwd<IO>, grid, dim3(kBlock), 0, st, logits, (long long)batch_stride, (long long)row_stride,    \
+                       (int)T, (long long)vocab, parts);                                                                   \
+    LAUNCH_CHECK();                                                                                                        \
+    hipLaunchKernelGGL(k_ce_finish<IO>, dim3(1), dim3(finish_threads), 0, st, logits, (long long)batch_stride,             \
+                       (long long)row_stride, (int)T, tg, (long long)rows, (long long)vocab, (const float2*)parts,         \
+                       (int)chunks, row_loss, row_lse, mean_and_n);                                                        \
+  } while (0)
   if (io_dtype == 0) ADVX_CE(0); else if (io_dtype == 1) ADVX_CE(1); else ADVX_CE(2);
 #undef ADVX_CE
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_ce_mean, dim3(1), dim3(kBlock), 0, st, (const float*)row_loss, tg, (long long)rows, (long long)vocab,
-                     mean_and_n);
   LAUNCH_CHECK();
   return ADVX_OK;
 }
@@ -3406,9 +3426,13 @@ extern "C" int32_t advx_ce_bwd(const void* logits, int32_t io_dtype, int64_t bat
           "advx_ce_bwd: bad shape");
   hipStream_t st = (hipStream_t)stream;
   const long long* tg = reinterpret_cast<const long long*>(targets);
-  const unsigned blocks = (unsigned)((rows / T) * K);
+  const unsigned kept = (unsigned)((rows / T) * K);
+  const long long per_block = (long long)kCeBwdVecs * kBlock * (io_dtype == 0 ? 4 : 8);      // elements a workgroup takes
+  const unsigned chunks = (unsigned)std::min<long long>(65535, std::max<long long>(1, (vocab + per_block - 1) / per_block));
+  REQUIRE((long long)chunks * per_block >= vocab, ADVX_E_SHAPE, "advx_ce_bwd: vocabulary too large");
+  const dim3 blocks(kept, chunks);
 #define ADVX_CE(IO)                                                                                              \
-  hipLaunchKernelGGL(k_ce_bwd<IO>, dim3(blocks), dim3(kBlock), 0, st, logits, (long long)batch_stride,            \
+  hipLaunchKernelGGL(k_ce_bwd<IO>, blocks, dim3(kBlock), 0, st, logits, (long long)batch_stride,                  \
                      (long long)row_stride, (int)T, (int)K, tg, (long long)vocab, row_lse, mean_and_n, upstream, grad)
   if (io_dtype == 0) ADVX_CE(0); else if (io_dtype == 1) ADVX_CE(1); else ADVX_CE(2);
 #undef ADVX_CE

@@ -586,12 +586,15 @@ int32_t advx_fused_bwd_dp(advx_plan* plan, advx_comm* comm, const void* grad_out
  * [B, S, V] logits tensor of the reference never exists.  logits: [B, K, V] in the model's
  * dtype (element strides batch_stride / row_stride), the first T positions of every row block
  * supervised by targets[B*T] (int64; values outside [0, V) are ignored).
- *   advx_ce_fwd : row_loss[B*T], row_lse[B*T], mean_and_n = {mean loss, number of valid rows}.
+ *   advx_ce_fwd : row_loss[B*T], row_lse[B*T], mean_and_n = {mean loss, number of valid rows}; `scratch`: at least
+ *                 advx_ce_scratch_floats(B*T, V, io_dtype) floats, 8-byte aligned (the row chunks' max and sum of exp:
+ *                 a row is read once, by one workgroup per 16 384 halfs / 8 192 floats, two launches in all).
  *   advx_ce_bwd : grad[B, K, V] = (softmax - onehot) * upstream[0] / n_valid on the T supervised
  *                 positions, zeros on the others; same layout as logits, may alias it. */
 int32_t advx_ce_fwd(const void* logits, int32_t io_dtype, int64_t batch_stride, int64_t row_stride, int32_t T,
                     const int64_t* targets, int64_t rows, int64_t vocab, float* row_loss, float* row_lse,
-                    float* mean_and_n, void* stream);
+                    float* mean_and_n, float* scratch, void* stream);
+int64_t advx_ce_scratch_floats(int64_t rows, int64_t vocab, int32_t io_dtype);
 int32_t advx_ce_bwd(const void* logits, int32_t io_dtype, int64_t batch_stride, int64_t row_stride, int32_t T,
                     int32_t K, const int64_t* targets, int64_t rows, int64_t vocab, const float* row_lse,
                     const float* mean_and_n, const float* upstream, void* grad, void* stream);

@@ -37,6 +37,42 @@ def test_suffix_ce_matches_torch(dtype, tol, B, K, T, V):
     assert not bool(got[:, T:, :].any())                       # unsupervised kept positions: exact zeros
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("B,K,T,V,lead", [
+    (3, 4, 3, 32003, 0),          # a vocabulary that is no multiple of the 16-byte vector: rows start at every phase
+    (2, 3, 2, 128256, 0),         # Llama-3.2-Vision: the 1024-thread form
+    (2, 3, 3, 152064, 0),         # Qwen2-VL
+    (2, 3, 2, 200003, 0),         # longer than any register form: two passes over memory
+    (3, 5, 4, 4099, 3),           # a view that starts 3 elements into its rows: gradient rows sit at another phase
+    (2, 2, 2, 5, 1), (2, 2, 1, 9, 0), (1, 1, 1, 16, 2),      # rows shorter than a vector or two
+])
+def test_suffix_ce_vector_forms_and_row_phases(dtype, tol, B, K, T, V, lead):
+    """Round 4: 16-byte accesses.  A row's elements in front of its first 16-byte boundary and behind its last whole vector
+    go one per thread; the forward holds a row in registers (256 x 16 or 1024 x 20 vectors) or streams it twice; the backward
+    needs logits and gradient rows at the same phase or goes element by element."""
+    from adversarialvlm_amd.ce import suffix_cross_entropy
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(V + 7 * K + lead)
+    big = (torch.randn(B, K, V + lead, generator=gen) * 3.0).to(dtype)
+    targets = torch.randint(0, V, (B, T), generator=gen)
+    targets[0, 0] = V - 1                                   # the last element of a row (a tail element when V % 8 != 0)
+    targets[-1, -1] = 0                                     # ... and the first one (a head element in a shifted view)
+    ref_in = big[:, :, lead:].double().clone().requires_grad_(True)
+    ref = F.cross_entropy(ref_in[:, :T, :].permute(0, 2, 1), targets)
+    (ref * 0.37).backward()
+    holder = big.to(dev).clone().requires_grad_(True)
+    x = holder[:, :, lead:] if lead else holder
+    loss = suffix_cross_entropy(x, targets.to(dev))
+    (loss * 0.37).backward()
+    assert float(loss.detach()) == pytest.approx(float(ref.detach()), rel=1e-6)
+    got, want = holder.grad[:, :, lead:].double().cpu(), ref_in.grad
+    floor = 1e-7 * float(want.abs().max()) + (6.1e-8 if dtype == torch.float16 else 0.0)
+    assert bool(((got - want).abs() <= tol * want.abs() + floor).all())
+    assert not bool(got[:, T:, :].any())
+    if lead:
+        assert not bool(holder.grad[:, :, :lead].any())     # nothing written in front of the view
+
+
 def test_suffix_ce_strided_view_and_ignored_targets():
     """logits as a slice of a larger tensor (what `logits_to_keep` hands back is contiguous, a
     user slice need not be) and targets outside the vocabulary are ignored like ignore_index."""
