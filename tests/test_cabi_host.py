@@ -290,6 +290,43 @@ def test_multi_plan_entry_points_validate_before_any_device_work(lib):
     assert lib.advx_update_flush(0, fake(1), fake(2), None) == E_BADARG
 
 
+def test_round4_entry_points_validate_before_any_device_work(lib):
+    """advx_collect_update / advx_ce_fwd / advx_ce_bwd: argument checks before the first HIP call; advx_ce_scratch_floats is plain
+    host arithmetic (two floats per row chunk of 16 384 halfs / 8 192 floats, plus slack)."""
+    import ctypes as C
+    from adversarialvlm_amd import _lib as L
+    from adversarialvlm_amd.plan import Plan
+    E_BADARG, E_SHAPE = -1, -2
+    fake = lambda k: C.c_void_p(0x1000 * (k + 1))              # never dereferenced: checks fail first
+    a = Plan.llava(40, 52, 32, 32)
+    opt = L.OptScalars()
+    args = lambda go, batch, wsf: (a.handle, go, batch, fake(1), wsf, 40, 52, None, fake(2), fake(3), fake(4), 0.5, 1.0, fake(5), 0,
+                                   fake(6), fake(7), fake(8), C.byref(opt), fake(9), fake(10), 1, None)
+    assert lib.advx_collect_update(*args(None, 1, a.workspace_floats)) == E_BADARG
+    assert lib.advx_collect_update(*args(fake(0), 0, a.workspace_floats)) == E_BADARG
+    assert lib.advx_collect_update(*args(fake(0), 1, 1)) == E_SHAPE and b"workspace" in lib.advx_last_error()
+    assert lib.advx_collect_update_supported(None, 40, 52, None) == 0
+    # scratch of the cross entropy's forward
+    assert lib.advx_ce_scratch_floats(0, 32000, 1) == 0 and lib.advx_ce_scratch_floats(8, 0, 1) == 0
+    assert lib.advx_ce_scratch_floats(512, 32064, 1) == 2 * 512 * 2 + 4          # 32 064 halfs: two chunks of 16 384
+    assert lib.advx_ce_scratch_floats(512, 32064, 0) == 2 * 512 * 4 + 4          # ... four of 8 192 floats
+    assert lib.advx_ce_scratch_floats(512, 152064, 2) == 2 * 512 * 10 + 4        # Qwen2-VL
+    assert lib.advx_ce_scratch_floats(3, 5, 2) == 2 * 3 + 4
+    tg = (C.c_int64 * 4)(0, 1, 2, 3)
+    fwd = lambda logits, io, T, rows, V, scratch: lib.advx_ce_fwd(logits, io, 6 * V, V, T, tg, rows, V, fake(1), fake(2), fake(3),
+                                                                  scratch, None)
+    assert fwd(None, 1, 2, 4, 100, fake(4)) == E_BADARG
+    assert fwd(fake(0), 1, 2, 4, 100, None) == E_BADARG
+    assert fwd(fake(0), 7, 2, 4, 100, fake(4)) == E_BADARG and b"io_dtype" in lib.advx_last_error()
+    assert fwd(fake(0), 1, 3, 4, 100, fake(4)) == E_SHAPE                        # rows no multiple of T
+    assert fwd(fake(0), 1, 2, 4, 0, fake(4)) == E_SHAPE
+    assert fwd(fake(0), 1, 2, 4, 100, C.c_void_p(0x1004)) == E_BADARG and b"aligned" in lib.advx_last_error()
+    bwd = lambda T, K, rows, V: lib.advx_ce_bwd(fake(0), 1, K * V, V, T, K, tg, rows, V, fake(1), fake(2), fake(3), fake(4), None)
+    assert bwd(2, 1, 4, 100) == E_SHAPE                                          # fewer kept than supervised positions
+    assert bwd(3, 3, 4, 100) == E_SHAPE
+    assert lib.advx_ce_bwd(fake(0), 1, 300, 100, 2, 3, tg, 4, 100, None, fake(2), fake(3), fake(4), None) == E_BADARG
+
+
 def test_plain_c_host_compiles_and_links_against_the_header(tmp_path):
     """CPU tier: tests/cabi/pair_steps.c - a host that is neither Python nor torch - builds with gcc against include/advx.h and
     links libadvx_hip.so (it RUNS in the GPU tier, tests/test_gpu_cabi_c_host.py): the header is plain C and every symbol it
