@@ -51,6 +51,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# dmabuf IPC (RCCL and the peer exchange between processes need it on this driver); must be in the environment before the first
+# HIP call of the process, whoever launched it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch  # noqa: E402
 
 H = W = 336
