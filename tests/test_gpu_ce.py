@@ -73,6 +73,39 @@ def test_suffix_ce_vector_forms_and_row_phases(dtype, tol, B, K, T, V, lead):
         assert not bool(holder.grad[:, :, :lead].any())     # nothing written in front of the view
 
 
+def test_suffix_ce_random_shapes_phases_and_ignored_targets():
+    """Sixty random (B, K, T, V, view offset, dtype) draws - every split of a row into head elements, whole vectors, tail elements
+    and chunks - with some targets ignored, against float64 cross entropy of the same logits."""
+    from adversarialvlm_amd.ce import suffix_cross_entropy
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(2024)
+    tols = {torch.float32: 2e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}
+    for case in range(60):
+        dtype = [torch.float32, torch.float16, torch.bfloat16][int(rng.integers(0, 3))]
+        V = int(rng.choice([rng.integers(1, 40), rng.integers(40, 3000), rng.integers(3000, 70000)]))
+        B, K = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+        T, lead = int(rng.integers(1, K + 1)), int(rng.integers(0, 8))
+        gen = torch.Generator().manual_seed(1000 + case)
+        big = (torch.randn(B, K, V + lead, generator=gen) * 4.0).to(dtype)
+        targets = torch.randint(0, V, (B, T), generator=gen)
+        if B * T > 1 and case % 3 == 0:
+            targets[0, 0] = -100
+        ref_in = big[:, :, lead:].double().clone().requires_grad_(True)
+        ref = F.cross_entropy(ref_in[:, :T, :].permute(0, 2, 1), targets, ignore_index=-100)
+        (ref * 1.7).backward()
+        holder = big.to(dev).clone().requires_grad_(True)
+        loss = suffix_cross_entropy(holder[:, :, lead:] if lead else holder, targets.to(dev))
+        (loss * 1.7).backward()
+        what = (case, dtype, B, K, T, V, lead)
+        assert float(loss.detach()) == pytest.approx(float(ref.detach()), rel=1e-6, abs=1e-6), what
+        got, want = holder.grad[:, :, lead:].double().cpu(), ref_in.grad
+        floor = 1e-7 * float(want.abs().max()) + (6.1e-8 if dtype == torch.float16 else 0.0)
+        assert bool(((got - want).abs() <= tols[dtype] * want.abs() + floor).all()), what
+        assert not bool(got[:, T:, :].any()), what
+        if lead:
+            assert not bool(holder.grad[:, :, :lead].any()), what
+
+
 def test_suffix_ce_strided_view_and_ignored_targets():
     """logits as a slice of a larger tensor (what `logits_to_keep` hands back is contiguous, a
     user slice need not be) and targets outside the vocabulary are ignored like ignore_index."""
