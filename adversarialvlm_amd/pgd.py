@@ -324,14 +324,15 @@ class PixelPGD:
         if image_ready:
             # the previous backward_update already ran this step's image kernel into the other image buffer
             self.s, self._alt["s"] = self._alt["s"], self.s
-        res, _ = ops.forward_multi(self.p, self.x0, self.eps, self.stats, self.img_scratch, self.plans, batches, self.s,
+        res, arg = ops.forward_multi(self.p, self.x0, self.eps, self.stats, self.img_scratch, self.plans, batches, self.s,
                                    argument=self.argument if crop is not None else None, blur=blur, crop=crop,
                                    unit_noises=unit_noises if given else None, philox=ph, workspaces=self.workspaces,
                                    outs=bufs, keep_padding=keep, image_ready=image_ready)
         outs = [o.view((B * pl.out_shape[0],) + pl.out_shape[1:]) for o, pl, B in zip(res, self.plans, batches)]
         # one plan and a window that composes with its stage 0: the library applied both resizes as one table
         # (include/advx.h "Composed crop") - the backward then goes canvas -> image in one gather
-        composed = bool(crop is not None and n == 1 and ops.crop_composes(self.plans[0], self.H, self.W, crop))
+        # (forward_multi hands back no argument exactly then: no second question to the library)
+        composed = bool(crop is not None and n == 1 and arg is None)
         self._last = dict(batches=list(batches), blur=blur, crop=crop, composed=composed)
         return outs
 

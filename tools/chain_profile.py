@@ -50,6 +50,8 @@ def main():
         plans = {"mllama": lambda: [Plan.mllama(H, W)], "phi3": lambda: [Plan.phi3(H, W)], "qwen2vl": lambda: [Plan.qwen2vl(H, W)],
                  "llava": lambda: [Plan.llava(H, W)]}[which]()
         B, kw = 64, {}
+    if os.environ.get("ADVX_CHAIN_BATCH"):          # the reference's own presets run 1-4 prompts per step
+        B = int(os.environ["ADVX_CHAIN_BATCH"])
     x0 = torch.rand(3, H, W, device=dev)
     eng = PixelPGD(x0, plans, allow_fused=(chain == "prepared"), step_fusion=not os.environ.get("ADVX_NO_ANNOUNCE"), **kw)
     assert eng.mode == chain, eng.mode
