@@ -2283,6 +2283,7 @@ CollectUpdatePick pick_collect_update(const advx_plan* p, int H, int W, const in
   if (gx > kNormCountSlot) return r;
   r.threads = threads;
   r.rows_per_block = (int)(((long long)gx * H + kNormCountSlot - 1) / kNormCountSlot);      // 1 up to 2048 (chunk, row) pairs
+  while ((long long)gx * ((H + r.rows_per_block - 1) / r.rows_per_block) > kNormCountSlot) ++r.rows_per_block;   // the last, partial group of rows counts too (3 chunks x 683 groups = 2049)
   r.ig = img_grid(gx, (H + r.rows_per_block - 1) / r.rows_per_block, 1, &r.grid);
   int rows;
   if (crop) {

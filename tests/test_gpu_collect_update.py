@@ -34,6 +34,7 @@ CASES = [  # (maker, H, W, crop window)
     ("llava", 672, 672, (0, 0, 672, 672)), ("qwen2vl", 512, 512, None), ("qwen2vl", 512, 512, (16, 24, 470, 450)),
     ("phi3", 512, 512, None), ("phi3", 600, 520, (10, 20, 560, 480)), ("mllama", 600, 600, None),
     ("mllama", 520, 700, (8, 8, 500, 640)), ("llava", 1030, 770, None), ("llava", 1500, 1400, (100, 50, 1200, 1300)),
+    ("llava", 1365, 340, None),          # 3 chunks x 683 row pairs = 2049 workgroups unless the last partial group is counted
 ]
 
 

@@ -43,6 +43,9 @@ def main():
         plans, B = [mk(H, W)], 64
         kw = dict(use_crop=True)
         crop = (20, 30, H - 56, H - 36)
+    elif which == "cross-noblur":                # four of the reference's five cross-model scripts run without blur
+        H = W = 336
+        plans, B, kw = [Plan.phi3(H, W), Plan.qwen2vl(H, W), Plan.mllama(H, W)], 16, dict(cross_mode=True)
     elif which == "cross":                       # BASELINE configs 4/5 in the shape tools/generic_bench.py times
         H = W = 336
         plans, B, kw = [Plan.phi3(H, W), Plan.qwen2vl(H, W), Plan.mllama(H, W)], 16, dict(blur_kernel=5, cross_mode=True)
