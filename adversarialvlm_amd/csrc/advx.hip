@@ -3148,7 +3148,10 @@ extern "C" int32_t advx_prepared_supported(const advx_plan* p) {
 extern "C" int64_t advx_prepared_scratch_floats(const advx_plan* p) {
   if (!p) return 0;
   const long long n = 3LL * p->info.in_h * p->info.in_w;
-  const long long rows = std::max<long long>((n + kBlock - 1) / kBlock, grid_for(n, kMaxStatBlocks));
+  // the larger of the partitions a step may leave its partial rows on: one per 256 elements, or (three channels per thread, large
+  // images) one per (chunk of 256 pixels of a row, row) - more rows than the former only for images narrower than 86 pixels
+  const long long rows3 = (long long)((p->info.in_w + kBlock - 1) / kBlock) * p->info.in_h;
+  const long long rows = std::max<long long>(std::max<long long>((n + kBlock - 1) / kBlock, grid_for(n, kMaxStatBlocks)), rows3);
   return 2 * (2 * rows * kStatSlots + rows) + 64;
 }
 

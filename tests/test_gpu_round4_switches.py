@@ -106,7 +106,8 @@ def test_round4_forms_leave_the_bits_of_the_forms_they_replaced(name):
                 assert st[key] == st_ref[key], (name, variant, key)
 
 
-@pytest.mark.parametrize("H,W,maker", [(512, 512, "llava"), (512, 640, "llava"), (512, 512, "qwen2vl"), (336, 336, "llava")])
+@pytest.mark.parametrize("H,W,maker", [(512, 512, "llava"), (512, 640, "llava"), (512, 512, "qwen2vl"), (336, 336, "llava"),
+                                       (6000, 48, "llava-narrow")])      # one partial row per image row: MORE rows than one per 256 elements
 def test_prepared_split_tail_and_reprepare_share_the_partition(H, W, maker):
     """The prepared chain's image kernels all run on ONE partition of the image (three channels per thread from 250 k positions,
     one element per thread below): advx_prepared_bwd in one call and its data-parallel split (advx_prepared_bwd_grad, [all-reduce],
@@ -115,7 +116,7 @@ def test_prepared_split_tail_and_reprepare_share_the_partition(H, W, maker):
     from adversarialvlm_amd import ops
     from adversarialvlm_amd.pgd import PixelPGD
     from adversarialvlm_amd.plan import Plan
-    mk = {"llava": lambda: Plan.llava(H, W), "qwen2vl": lambda: Plan.qwen2vl(H, W)}[maker]
+    mk = {"llava": lambda: Plan.llava(H, W), "qwen2vl": lambda: Plan.qwen2vl(H, W), "llava-narrow": lambda: Plan.llava(H, W, 64, 48)}[maker]
     gen = torch.Generator().manual_seed(3)
     x0 = torch.rand(3, H, W, generator=gen).to(DEV)
     mask = (torch.rand(3, H, W, generator=gen) > 0.2).float().to(DEV)
