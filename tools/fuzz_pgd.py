@@ -45,10 +45,24 @@ def one_processor(rng, H, W, allow_phi3=True):
     return kind, Phi3Oracle(num_crops=nc), Plan.phi3(H, W, num_crops=nc)
 
 
+LARGE = False      # --large: images of 250 k positions and more, also very narrow / very flat ones (the kernels with three
+                   # channels per thread, the (chunk, row) partitions and their scratch sizes; the default sizes never get there)
+
+
 def draw_case(rng):
     H, W = int(rng.integers(12, 140)), int(rng.integers(12, 140))
     if rng.random() < 0.2:
         H = W = int(rng.choice([32, 64, 112]))               # sizes the pair / one-launch chains accept
+    if LARGE:
+        shape = rng.choice(["square", "narrow", "flat", "odd"])
+        if shape == "square":
+            H = W = int(rng.choice([512, 520, 600, 672]))
+        elif shape == "narrow":
+            W = int(rng.integers(20, 90)); H = int(rng.integers(255000 // W, 300000 // W))
+        elif shape == "flat":
+            H = int(rng.integers(20, 90)); W = int(rng.integers(255000 // H, 300000 // H))
+        else:
+            H = int(rng.integers(400, 700)); W = int(rng.integers(252000 // H + 1, 320000 // H + 2))
     cross = rng.random() < 0.25
     n_models = int(rng.integers(2, 4)) if cross else 1
     procs = []
@@ -60,6 +74,8 @@ def draw_case(rng):
             # fuzz_parity.py checks that the oracle rejects the same ones - draw another processor
             continue
     steps = int(rng.integers(3, 6))
+    if LARGE:
+        steps = 3                                   # the oracle takes seconds per step at these sizes
     kw = dict(optimizer=str(rng.choice(["adamw", "adamw", "sign"])), lr=float(rng.choice([1e-2, 3e-3, 1e-3])),
               gamma=float(rng.choice([1.0, 0.5, 0.9])), step_size=int(rng.integers(1, 4)))
     desc = dict(H=H, W=W, models=[p[0] for p in procs], steps=steps, **kw)
@@ -100,7 +116,7 @@ def draw_case(rng):
         if mode == "step-noise-ahead":
             kw["noise_ahead"] = True
         desc["chain"] = mode
-    batches = [int(rng.integers(1, 7)) for _ in range(n_models)]
+    batches = [int(rng.integers(1, 3 if LARGE else 7)) for _ in range(n_models)]
     desc["batches"] = batches
     return desc, procs, batches, steps, mask, kw
 
@@ -155,7 +171,7 @@ def run_case(T, dev, rng, seed):
     x0 = torch.rand(3, desc["H"], desc["W"], generator=torch.Generator().manual_seed(seed)) * 1.1 - 0.05
     try:
         worst = T._trajectory(dev, x0, [p[1] for p in procs], [p[2] for p in procs], batches, steps, mask=mask,
-                               max_ill=T.FUZZ_MAX_ILL, **kw)
+                               max_ill=max(T.FUZZ_MAX_ILL, x0.numel() // 10000 if LARGE else 0), **kw)   # tests/test_gpu_fullsize.py's rule for large images
         return "ok", desc, worst
     except AssertionError as e:
         arg = e.args[0] if e.args else None
@@ -257,7 +273,10 @@ def main():
     ap.add_argument("--budget-s", type=float, default=240.0)
     ap.add_argument("--only", type=str, default="", help="comma-separated case numbers: draw every case of the seed's "
                     "stream (the draws are what positions it) but run only these - to replay a reported failure (trajectory mode)")
+    ap.add_argument("--large", action="store_true", help="images of 250 k positions and more, extreme aspect ratios included")
     a = ap.parse_args()
+    global LARGE
+    LARGE = bool(a.large)
     only = {int(x) for x in a.only.split(",") if x.strip()}
     import test_gpu_pgd as T
     dev = torch.device("cuda:0")
@@ -285,7 +304,7 @@ def main():
         elif verdict != "ok":
             bad += 1
             print(f"FAIL case {k}: {desc}: {verdict}", flush=True)
-        elif k % 10 == 0:
+        elif k % 10 == 0 or LARGE:
             print(f"case {k}: {desc}: ok, worst {max(worst.values()):.2e} ({max(worst, key=worst.get)})", flush=True)
     print(f"{done} cases, {bad} failures, {soft} ill-conditioned (see run_case), {time.time() - t0:.0f} s; chains {seen}", flush=True)
     return 1 if bad else 0
