@@ -24,8 +24,8 @@ TUNE_GENERIC_KERNELS = 1
 TUNE_FULL_TAP_ROWS = 3
 TUNE_SEPARATE_CROP = 4
 TUNE_PAIR_LEAN = 5
-TUNE_XCD_MAP, TUNE_BWD_XCD, TUNE_ROW_BATCH, TUNE_IMG_XCD, TUNE_HEAD3, TUNE_BLUR_THREADS, TUNE_TAIL3, TUNE_COLLECT_UPDATE = \
-    6, 7, 8, 9, 10, 12, 13, 14
+TUNE_XCD_MAP, TUNE_BWD_XCD, TUNE_ROW_BATCH, TUNE_IMG_XCD, TUNE_HEAD3, TUNE_BLUR_THREADS, TUNE_TAIL3, TUNE_COLLECT_UPDATE, \
+    TUNE_DIRECT_BATCH = 6, 7, 8, 9, 10, 12, 13, 14, 15
 
 
 class AdvxError(RuntimeError):

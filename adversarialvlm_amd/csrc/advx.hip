@@ -48,6 +48,7 @@ static int32_t fail(int32_t code, const std::string& msg) {
 static int g_generic_kernels = 0;
 static int g_pair_nt_loads = 0;
 static int g_xcd_map = 2;        // ADVX_TUNE_XCD_MAP: 0 = grids as they come (rounds 1-3), 1 = gx padded to a multiple of 8, 2 = padded + a contiguous range of column blocks per XCD
+static int g_direct_batch = 1;     // ADVX_TUNE_DIRECT_BATCH: one or two prompts of a plain plan are summed inside advx_collect_update's gather (0: batch reduction first)
 static int g_collect_update = 1;   // ADVX_TUNE_COLLECT_UPDATE: images of >= value * 1000 positions are offered advx_collect_update (0: never)
 static int g_tail3 = 1;          // ADVX_TUNE_TAIL3: the prepared chain's image kernels on the three-channel partition from kRows3MinPositions up
 static int g_blur_threads = 512; // ADVX_TUNE_BLUR_THREADS: threads per 32 x 32 tile of the merged blur backward (256: rounds 1-3)
@@ -71,6 +72,11 @@ extern "C" int32_t advx_set_tuning(int32_t what, int32_t value) {
     g_blur_threads = 512;
     g_tail3 = 1;
     g_collect_update = 1;
+    g_direct_batch = 1;
+    return ADVX_OK;
+  }
+  if (what == ADVX_TUNE_DIRECT_BATCH) {
+    g_direct_batch = value ? 1 : 0;
     return ADVX_OK;
   }
   if (what == ADVX_TUNE_COLLECT_UPDATE) {
@@ -2335,8 +2341,20 @@ extern "C" int32_t advx_collect_update(advx_plan* p, const void* grad_out, int32
     rc = build_composed_stage(p, H, W, crop, b, st, &D, /*may_reuse=*/true);     // the forward's tables, if still there
     if (rc) return rc;
   }
-  rc = reduce_to_canvas(p, grad_out, batch, ws, st);
-  if (rc) return rc;
+  // One or two prompts of a plan whose pixel_values ARE its canvas (LLaVA: one plain emit, float32 boundary): the "batch
+  // reduction" is a copy (0 + g) or one addition ((0 + g0) + g1) - the gather reads grad_out itself, as one canvas copy or as
+  // two (canvas_grad_at adds the copies in that order: the same floats), and the launch of the reduction is gone.  At the
+  // reference's own batch sizes (1-4 prompts, attack_clamp_tanh_llava.sh:32) the step is five launches long and runs at the
+  // host's pace.
+  const DPlan& pl = p->dplan;
+  const bool direct = g_direct_batch && batch <= 2 && p->io == 0 && p->info.n_stage == 1 && pl.n_emit == 1 &&
+                      pl.e[0].kind == ADVX_EMIT_PLAIN && pl.e[0].stage == 0 && pl.e[0].out_begin == 0 &&
+                      pl.e[0].out_count == p->info.out_numel && p->info.out_numel == 3LL * D.can_h * D.can_w && pick.mode == 1 &&
+                      (batch == 1 || pick.T <= 4);
+  if (!direct) {
+    rc = reduce_to_canvas(p, grad_out, batch, ws, st);
+    if (rc) return rc;
+  }
   for (int k = p->info.n_stage - 1; k >= 1; --k) {
     const DStage& Dk = p->dstage[k];
     int acc = 0;
@@ -2344,14 +2362,21 @@ extern "C" int32_t advx_collect_update(advx_plan* p, const void* grad_out, int32
     launch_stage_bwd(Dk, stage_grad(p, k, ws), gsrc, (long long)Dk.src_h * Dk.src_w, Dk.src_w, acc, st);
     LAUNCH_CHECK();
   }
-  const CanvasGrad cg = stage_grad(p, 0, ws);
+  CanvasGrad cg = stage_grad(p, 0, ws);
+  int mode = pick.mode;
+  if (direct) {
+    cg.g = reinterpret_cast<const float*>(grad_out);
+    cg.copies = batch;
+    cg.copy_stride = p->info.out_numel;
+    mode = batch == 1 ? 1 : 3;
+  }
   const float c_fit = imgfit_scale / (float)n;
   double* partials = reinterpret_cast<double*>(update_scratch);
   const OptScalars o = to_dev(opt);
 #define ADVX_CU(T_, M_)                                                                                                      \
   hipLaunchKernelGGL((k_collect_update3<T_, M_>), pick.grid, dim3(pick.threads), 0, st, D, cg, s, eps, c_fit, accumulate, pp, \
                      m, v, grad_p, mask, o, partials, pick.rows_per_block, pick.ig)
-#define ADVX_CU_M(T_) do { if (pick.mode == 1) ADVX_CU(T_, 1); else if (pick.mode == 2) ADVX_CU(T_, 2); else ADVX_CU(T_, 3); } while (0)
+#define ADVX_CU_M(T_) do { if (mode == 1) ADVX_CU(T_, 1); else if (mode == 2) ADVX_CU(T_, 2); else ADVX_CU(T_, 3); } while (0)
   if (pick.T == 2) ADVX_CU_M(2);
   else if (pick.T == 3) ADVX_CU_M(3);
   else if (pick.T == 4) ADVX_CU_M(4);

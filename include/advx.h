@@ -129,6 +129,7 @@ const char* advx_last_error(void);
 #define ADVX_TUNE_IMG_XCD 9         /* rows per group (default 8) of the XCD-aware grids of the image-sized gathers: launched 1-D, groups of that many
                                      rows of workgroups are dealt to the 8 XCDs in turn, so that one XCD's L2 fetches the source rows of its groups only;
                                      0: (column chunk, row, layer) grids dealt round-robin workgroup by workgroup (rounds 1-3).  Same results */
+#define ADVX_TUNE_DIRECT_BATCH 15   /* 1 (default): advx_collect_update sums one or two prompts of a plain float32 plan inside its gather; 0: batch reduction first */
 #define ADVX_TUNE_COLLECT_UPDATE 14 /* images of >= value * 1000 positions (default 1) are offered advx_collect_update; 0: none (the two calls) */
 #define ADVX_TUNE_TAIL3 13          /* 1 (default): the prepared chain's image kernels (prepare, tail, update) handle the three channels of a pixel in
                                      one thread on a (chunk, row) grid for images of 250 k positions and more; 0: one thread per element (rounds

@@ -39,15 +39,15 @@ CASES = [  # (maker, H, W, crop window)
 
 
 @pytest.mark.parametrize("maker,H,W,crop", CASES)
-@pytest.mark.parametrize("kind,accumulate,apply", [("adamw", 0, 1), ("adamw", 1, 1), ("sign", 0, 1), ("adamw", 1, 0)])
-def test_collect_update_equals_the_two_calls(maker, H, W, crop, kind, accumulate, apply):
+@pytest.mark.parametrize("kind,accumulate,apply,B", [("adamw", 0, 1, 2), ("adamw", 1, 1, 1), ("sign", 0, 1, 3), ("adamw", 1, 0, 2)])
+def test_collect_update_equals_the_two_calls(maker, H, W, crop, kind, accumulate, apply, B):
     from adversarialvlm_amd import _lib as L
     from adversarialvlm_amd import ops
     plan = _plan(maker, H, W)
     if not ops.collect_update_supported(plan, H, W, crop):
         pytest.skip("the library does not offer the one-launch form for this geometry (covered by the refusal test)")
+    # B = 1, 2: a plain float32 plan's prompts are summed inside the gather (ADVX_TUNE_DIRECT_BATCH); 3: batch reduction first
     gen = torch.Generator().manual_seed(H * 1000 + W + (crop[2] if crop else 0))
-    B = 2
     x0 = torch.rand(3, H, W, generator=gen).to(DEV)
     p0 = (torch.randn(3, H, W, generator=gen) * 0.6).to(DEV)
     m0 = (torch.randn(3, H, W, generator=gen) * 1e-3).to(DEV)

@@ -4,7 +4,7 @@ Each `ADVX_TUNE_*` switch of round 4 (include/advx.h) selects between two ways o
 the transposed resizes as compiled windows / a window row at a time or with one memory round trip per tap (ROW_BATCH), the gathers'
 grids dealt to the XCDs in row groups or workgroup by workgroup (IMG_XCD), canvases resized three channels per thread or one
 (HEAD3), the readers of B x P_out mapped to the XCDs like the writers or not (BWD_XCD), the merged blur backward with eight or four
-waves per tile (BLUR_THREADS), the prepared chain's image kernels with three channels or one element per thread (TAIL3), the transposed resize of a single plan inside the optimiser's launch or before it (COLLECT_UPDATE).  Whole chains are stepped with every switch
+waves per tile (BLUR_THREADS), the prepared chain's image kernels with three channels or one element per thread (TAIL3), the transposed resize of a single plan inside the optimiser's launch or before it (COLLECT_UPDATE), one or two prompts summed inside that gather or by a batch reduction first (DIRECT_BATCH).  Whole chains are stepped with every switch
 off in turn and with all of them off; every tensor they leave must be IDENTICAL to the default build's.  (That the specialised
 kernels equal the general ones is tests/test_gpu_fastpaths.py; parity with the oracle is the other GPU tests'.)"""
 import pytest
@@ -13,7 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
-ROW_BATCH, IMG_XCD, HEAD3, BWD_XCD, BLUR_THREADS, TAIL3, COLLECT_UPDATE, RESET_ALL = 8, 9, 10, 7, 12, 13, 14, 0
+ROW_BATCH, IMG_XCD, HEAD3, BWD_XCD, BLUR_THREADS, TAIL3, COLLECT_UPDATE, DIRECT_BATCH, RESET_ALL = 8, 9, 10, 7, 12, 13, 14, 15, 0
 
 
 def _chains():
@@ -28,6 +28,7 @@ def _chains():
         "llava_odd_crop": (97, 130, lambda: [Plan.llava(97, 130, 56, 72)], [3], dict(allow_fused=False, use_crop=True), (3, 5, 80, 101)),
         "llava512_crop": (512, 512, lambda: [Plan.llava(512, 512)], [2], dict(allow_fused=False, use_crop=True), (40, 30, 400, 420)),
         "llava512_accum": (512, 512, lambda: [Plan.llava(512, 512)], [2], dict(allow_fused=False, grad_accum_steps=2), None),
+        "llava512_crop_one_prompt": (512, 512, lambda: [Plan.llava(512, 512)], [1], dict(allow_fused=False, use_crop=True), (60, 20, 380, 440)),
         "qwen512_crop": (512, 512, lambda: [Plan.qwen2vl(512, 512, **q)], [2], dict(allow_fused=False, use_crop=True), (16, 24, 470, 450)),
         "qwen512_prepared": (512, 512, lambda: [Plan.qwen2vl(512, 512, **q)], [2], dict(fused_mode="prepared"), None),
         "qwen512_generic": (512, 512, lambda: [Plan.qwen2vl(512, 512, **q)], [2], dict(allow_fused=False), None),
@@ -80,6 +81,7 @@ VARIANTS = {
     "blur_threads_256": [(BLUR_THREADS, 256)],
     "tail3_off": [(TAIL3, 0)],
     "collect_update_off": [(COLLECT_UPDATE, 0)],
+    "direct_batch_off": [(DIRECT_BATCH, 0)],
     "tail3_loops": [(ROW_BATCH, 0)],
     "all_off": [(ROW_BATCH, 0), (IMG_XCD, 0), (HEAD3, 0), (BWD_XCD, 0), (BLUR_THREADS, 256), (TAIL3, 0),
                 (COLLECT_UPDATE, 0)],
