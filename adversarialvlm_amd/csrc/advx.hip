@@ -1141,6 +1141,25 @@ static CanvasGrad stage_grad(const advx_plan* p, int k, const float* ws) {
   return canvas_grad_of(p->dplan, k, p->dstage[k].can_h, p->dstage[k].can_w, ws, dgrad);
 }
 
+// One or two prompts of a plan whose pixel_values ARE its canvas (LLaVA: one plain emit, float32 boundary): the "batch
+// reduction" is a copy (0 + g) or one addition ((0 + g0) + g1) - a transposed gather can read grad_out itself, as one canvas
+// copy or as two (canvas_grad_at adds the copies in that order: the same floats), and the launch of the reduction is gone.  At
+// the reference's own batch sizes (1-4 prompts, attack_clamp_tanh_llava.sh:32) a step is a handful of launches and runs at
+// the host's pace.  mode / T: what the caller's gather was picked with (1 = one copy, no nested gradient).  -> true: *cg and
+// *mode describe grad_out; the caller skips reduce_to_canvas.
+static bool direct_batch(const advx_plan* p, const void* grad_out, int batch, const DStage& D, int T, CanvasGrad* cg, int* mode) {
+  const DPlan& pl = p->dplan;
+  if (!g_direct_batch || g_generic_kernels || batch > 2 || p->io != 0 || p->info.n_stage != 1 || pl.n_emit != 1 ||
+      pl.e[0].kind != ADVX_EMIT_PLAIN || pl.e[0].stage != 0 || pl.e[0].out_begin != 0 || pl.e[0].out_count != p->info.out_numel ||
+      p->info.out_numel != 3LL * D.can_h * D.can_w || *mode != 1 || T <= 0 || (batch == 2 && T > 4))
+    return false;
+  cg->g = reinterpret_cast<const float*>(grad_out);
+  cg->copies = batch;
+  cg->copy_stride = p->info.out_numel;
+  *mode = batch == 1 ? 1 : 3;
+  return true;
+}
+
 extern "C" int32_t advx_collect(advx_plan* p, const float* grad_out, int32_t batch, float* grad_argument,
                                 int32_t accumulate, float* ws, int64_t ws_floats, void* stream) {
   REQUIRE(p && grad_out && grad_argument && ws, ADVX_E_BADARG, "advx_collect: null argument");
@@ -2341,16 +2360,9 @@ extern "C" int32_t advx_collect_update(advx_plan* p, const void* grad_out, int32
     rc = build_composed_stage(p, H, W, crop, b, st, &D, /*may_reuse=*/true);     // the forward's tables, if still there
     if (rc) return rc;
   }
-  // One or two prompts of a plan whose pixel_values ARE its canvas (LLaVA: one plain emit, float32 boundary): the "batch
-  // reduction" is a copy (0 + g) or one addition ((0 + g0) + g1) - the gather reads grad_out itself, as one canvas copy or as
-  // two (canvas_grad_at adds the copies in that order: the same floats), and the launch of the reduction is gone.  At the
-  // reference's own batch sizes (1-4 prompts, attack_clamp_tanh_llava.sh:32) the step is five launches long and runs at the
-  // host's pace.
-  const DPlan& pl = p->dplan;
-  const bool direct = g_direct_batch && batch <= 2 && p->io == 0 && p->info.n_stage == 1 && pl.n_emit == 1 &&
-                      pl.e[0].kind == ADVX_EMIT_PLAIN && pl.e[0].stage == 0 && pl.e[0].out_begin == 0 &&
-                      pl.e[0].out_count == p->info.out_numel && p->info.out_numel == 3LL * D.can_h * D.can_w && pick.mode == 1 &&
-                      (batch == 1 || pick.T <= 4);
+  CanvasGrad cg = stage_grad(p, 0, ws);
+  int mode = pick.mode;
+  const bool direct = direct_batch(p, grad_out, batch, D, pick.T, &cg, &mode);      // one or two prompts: no batch reduction
   if (!direct) {
     rc = reduce_to_canvas(p, grad_out, batch, ws, st);
     if (rc) return rc;
@@ -2361,14 +2373,6 @@ extern "C" int32_t advx_collect_update(advx_plan* p, const void* grad_out, int32
     float* gsrc = dgrad_target(p, p->st[k].info.src - 1, ws, &acc);
     launch_stage_bwd(Dk, stage_grad(p, k, ws), gsrc, (long long)Dk.src_h * Dk.src_w, Dk.src_w, acc, st);
     LAUNCH_CHECK();
-  }
-  CanvasGrad cg = stage_grad(p, 0, ws);
-  int mode = pick.mode;
-  if (direct) {
-    cg.g = reinterpret_cast<const float*>(grad_out);
-    cg.copies = batch;
-    cg.copy_stride = p->info.out_numel;
-    mode = batch == 1 ? 1 : 3;
   }
   const float c_fit = imgfit_scale / (float)n;
   double* partials = reinterpret_cast<double*>(update_scratch);
@@ -3283,16 +3287,18 @@ extern "C" int32_t advx_prepared_bwd(advx_plan* p, const float* grad_out, int32_
   REQUIRE(rows_in >= 0 && rows_in <= std::max<long long>(prepared_flat_rows(p), f.tail_blocks), ADVX_E_BADARG, "advx_prepared_bwd: rows_in out of range");
   const DStage& D = p->dstage[0];
   const long long n = 3LL * p->info.in_h * p->info.in_w;
-  rc = reduce_to_canvas(p, grad_out, batch, ws, st);
-  if (rc) return rc;
+  // the transposed gather as a compiled window where the tables' rows fit one (<= 4 taps) and the canvas gradient has one
+  // of the three shapes that occur; else the run-time loops
+  CanvasGrad cg = stage_grad(p, 0, ws);
+  const int T = g_row_batch ? pick_window(std::max(D.tth.stride, D.ttw.stride)) : 0;
+  int mode = (cg.copies == 1 && !cg.dgrad) ? 1 : (cg.copies == 1 && cg.dgrad) ? 2 : (cg.copies == 2 && !cg.dgrad) ? 3 : 0;
+  if (!direct_batch(p, grad_out, batch, D, T, &cg, &mode)) {          // one or two prompts of a plain plan: the tail reads grad_out
+    rc = reduce_to_canvas(p, grad_out, batch, ws, st);
+    if (rc) return rc;
+  }
   prepared_upper_bwd(p, ws, st);
   LAUNCH_CHECK();
   {
-    // the transposed gather as a compiled window where the tables' rows fit one (<= 4 taps) and the canvas gradient has one
-    // of the three shapes that occur; else the run-time loops
-    const CanvasGrad cg = stage_grad(p, 0, ws);
-    const int T = g_row_batch ? pick_window(std::max(D.tth.stride, D.ttw.stride)) : 0;
-    const int mode = (cg.copies == 1 && !cg.dgrad) ? 1 : (cg.copies == 1 && cg.dgrad) ? 2 : (cg.copies == 2 && !cg.dgrad) ? 3 : 0;
 #define ADVX_TAIL(T_, M_)                                                                                              \
   hipLaunchKernelGGL((k_plan_tail<T_, M_>), dim3(f.tail_blocks), dim3(kBlock), 0, st, D, cg, pp, x0, eps,               \
                      imgfit_scale / (float)n, mask, m, v, grad_p, to_dev(opt), s_next, f.img_rows[1 - parity], f.norm_rows, \

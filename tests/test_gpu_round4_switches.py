@@ -22,6 +22,9 @@ def _chains():
     return {
         # (H, W, plans, batches, engine keywords, crop window)
         "llava512_prepared": (512, 512, lambda: [Plan.llava(512, 512)], [3], dict(fused_mode="prepared"), None),
+        "llava512_prepared_one_prompt": (512, 512, lambda: [Plan.llava(512, 512)], [1], dict(fused_mode="prepared"), None),
+        "llava500x640_prepared_two_prompts": (500, 640, lambda: [Plan.llava(500, 640)], [2], dict(fused_mode="prepared"), None),
+        "llava200_prepared_two_prompts": (200, 260, lambda: [Plan.llava(200, 260, 96, 128)], [2], dict(fused_mode="prepared"), None),
         "llava512_generic": (512, 512, lambda: [Plan.llava(512, 512)], [3], dict(allow_fused=False), None),
         "llava512_blur_crop": (512, 512, lambda: [Plan.llava(512, 512)], [2], dict(allow_fused=False, blur_kernel=9, use_crop=True),
                                (40, 30, 400, 420)),
