@@ -1145,8 +1145,9 @@ static CanvasGrad stage_grad(const advx_plan* p, int k, const float* ws) {
 // reduction" is a copy (0 + g) or one addition ((0 + g0) + g1) - a transposed gather can read grad_out itself, as one canvas
 // copy or as two (canvas_grad_at adds the copies in that order: the same floats), and the launch of the reduction is gone.  At
 // the reference's own batch sizes (1-4 prompts, attack_clamp_tanh_llava.sh:32) a step is a handful of launches and runs at
-// the host's pace.  mode / T: what the caller's gather was picked with (1 = one copy, no nested gradient).  -> true: *cg and
-// *mode describe grad_out; the caller skips reduce_to_canvas.
+// the host's pace.  mode / T: what the caller's gather was picked with (1 = one copy, no nested gradient; T = the compiled window,
+// 1 where the caller's launcher picks its kernel from *cg itself).  -> true: *cg and *mode describe grad_out; the caller skips
+// reduce_to_canvas.
 static bool direct_batch(const advx_plan* p, const void* grad_out, int batch, const DStage& D, int T, CanvasGrad* cg, int* mode) {
   const DPlan& pl = p->dplan;
   if (!g_direct_batch || g_generic_kernels || batch > 2 || p->io != 0 || p->info.n_stage != 1 || pl.n_emit != 1 ||
@@ -1168,14 +1169,20 @@ extern "C" int32_t advx_collect(advx_plan* p, const float* grad_out, int32_t bat
   int32_t rc = advx_plan_upload(p, stream);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  rc = reduce_to_canvas(p, grad_out, batch, ws, st);
-  if (rc) return rc;
+  // one or two prompts of a plain float32 plan: stage 0's gather reads grad_out itself (direct_batch)
+  CanvasGrad cg0 = stage_grad(p, 0, ws);
+  int mode0 = (cg0.copies == 1 && !cg0.dgrad) ? 1 : 0;
+  const bool direct = direct_batch(p, grad_out, batch, p->dstage[0], 1, &cg0, &mode0);
+  if (!direct) {
+    rc = reduce_to_canvas(p, grad_out, batch, ws, st);
+    if (rc) return rc;
+  }
   for (int k = p->info.n_stage - 1; k >= 0; --k) {
     const DStage& D = p->dstage[k];
     const advx_stage_info& s = p->st[k].info;
     int acc = accumulate;
     float* gsrc = (s.src == 0) ? grad_argument : dgrad_target(p, s.src - 1, ws, &acc);
-    launch_stage_bwd(D, stage_grad(p, k, ws), gsrc, (long long)D.src_h * D.src_w, D.src_w, acc, st);
+    launch_stage_bwd(D, (k == 0 && direct) ? cg0 : stage_grad(p, k, ws), gsrc, (long long)D.src_h * D.src_w, D.src_w, acc, st);
     LAUNCH_CHECK();
   }
   return ADVX_OK;
@@ -1834,8 +1841,13 @@ extern "C" int32_t advx_collect_crop(advx_plan* p, const void* grad_out, int32_t
   DStage D;
   rc = build_composed_stage(p, H, W, crop, b, st, &D, /*may_reuse=*/true);     // the forward's tables, if still there
   if (rc) return rc;
-  rc = reduce_to_canvas(p, grad_out, batch, ws, st);
-  if (rc) return rc;
+  CanvasGrad cg0 = stage_grad(p, 0, ws);
+  int mode0 = (cg0.copies == 1 && !cg0.dgrad) ? 1 : 0;
+  const bool direct = direct_batch(p, grad_out, batch, D, 1, &cg0, &mode0);      // one or two prompts: no batch reduction
+  if (!direct) {
+    rc = reduce_to_canvas(p, grad_out, batch, ws, st);
+    if (rc) return rc;
+  }
   for (int k = p->info.n_stage - 1; k >= 1; --k) {
     const DStage& Dk = p->dstage[k];
     const advx_stage_info& sk = p->st[k].info;
@@ -1847,7 +1859,7 @@ extern "C" int32_t advx_collect_crop(advx_plan* p, const void* grad_out, int32_t
   }
   ComposeGeom cgeo;
   const int tr_rows = compose_geom(p, H, W, crop, &cgeo) ? compose_exact(p, H, W, crop, cgeo).tr : 0;
-  launch_stage_bwd(D, stage_grad(p, 0, ws), grad_s, (long long)H * W, W, accumulate, st, tr_rows);
+  launch_stage_bwd(D, direct ? cg0 : stage_grad(p, 0, ws), grad_s, (long long)H * W, W, accumulate, st, tr_rows);
   LAUNCH_CHECK();
   // the tables have served their step: the image-level backward that follows carves its buffers over them, so a later call
   // with the same window must rebuild, not trust the record
