@@ -134,7 +134,10 @@ __device__ inline long long ce_scalar_index(const CeRowSplit& sp, long long voca
 // target positions), Qwen2-VL's 152 064 ten.  The row's few elements outside its whole vectors go with chunk 0.
 // (Rounds 1-3: one workgroup per row, two passes over memory with 2-byte loads - 0.28-0.37 TB/s, tools/ce_bench.py; one
 // workgroup per row holding the whole row in registers: 2.1 TB/s - each workgroup's latency, not the memory, was the bound.)
-constexpr int kCeFwdVecs = 8;
+#ifndef ADVX_CE_FWD_VECS
+#define ADVX_CE_FWD_VECS 8      // 16-byte vectors per thread held in registers by k_ce_fwd (4 and 16 measured: profiles/r04/w_ce_bench.log)
+#endif
+constexpr int kCeFwdVecs = ADVX_CE_FWD_VECS;
 template <int IO>
 __global__ void __launch_bounds__(kBlock) k_ce_fwd(const void* __restrict__ logits, long long sb, long long st, int T,
                                                    long long vocab, float2* __restrict__ chunk_max_sum) {
